@@ -1,0 +1,173 @@
+"""ctypes binding of ``libamp_engine.so`` (C ABI declared in ``include/amp_engine.h``).
+
+There is NO fallback: if the HIP library is missing or a call fails, this module raises.  torch is used
+only as plumbing (device memory, current stream).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the HIP runtime we bind to)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libamp_engine.so")
+ABI_VERSION = 1
+
+AMP_PHASE_DONES, AMP_PHASE_REWARD, AMP_PHASE_OBS = 1, 2, 4
+AMP_PHASE_ALL = 7
+TILE_ENVS = 64
+
+
+class AmpEngineError(RuntimeError):
+    """A libamp_engine.so entry point returned an error code."""
+
+
+class AmpMotionDesc(C.Structure):
+    _fields_ = [
+        ("n_clips", C.c_int32), ("n_dof", C.c_int32), ("n_bodies", C.c_int32), ("reserved", C.c_int32),
+        ("n_frames", C.c_int64), ("dt", C.c_double), ("clip_frames", C.POINTER(C.c_int64)),
+        ("dof_positions", C.c_void_p), ("dof_velocities", C.c_void_p), ("body_positions", C.c_void_p),
+        ("body_rotations", C.c_void_p), ("body_linear_velocities", C.c_void_p), ("body_angular_velocities", C.c_void_p),
+    ]
+
+
+class AmpEnvCfg(C.Structure):
+    _fields_ = [
+        ("n_dof", C.c_int32), ("n_key", C.c_int32), ("num_amp_observations", C.c_int32),
+        ("num_actor_observations", C.c_int32), ("use_last_actions", C.c_int32), ("use_command", C.c_int32),
+        ("history_include_last_actions", C.c_int32), ("history_include_command", C.c_int32),
+        ("early_termination", C.c_int32), ("reward_mode", C.c_int32), ("max_episode_length", C.c_int64),
+        ("termination_height", C.c_float), ("rew_termination", C.c_float), ("rew_action_l2", C.c_float),
+        ("rew_joint_pos_limits", C.c_float), ("rew_joint_acc_l2", C.c_float), ("rew_joint_vel_l2", C.c_float),
+        ("rew_track_vel", C.c_double), ("track_sigma", C.c_double), ("track_floor", C.c_double),
+    ]
+
+
+class AmpSimState(C.Structure):
+    _fields_ = [
+        ("joint_pos", C.c_void_p), ("joint_pos_stride", C.c_int64),
+        ("joint_vel", C.c_void_p), ("joint_vel_stride", C.c_int64),
+        ("joint_acc", C.c_void_p), ("joint_acc_stride", C.c_int64),
+        ("actions", C.c_void_p), ("actions_stride", C.c_int64),
+        ("root_pos", C.c_void_p), ("root_pos_stride", C.c_int64),
+        ("root_quat", C.c_void_p), ("root_quat_stride", C.c_int64),
+        ("root_lin_vel", C.c_void_p), ("root_lin_vel_stride", C.c_int64),
+        ("root_ang_vel", C.c_void_p), ("root_ang_vel_stride", C.c_int64),
+        ("body_pos", C.c_void_p), ("body_pos_stride", C.c_int64),
+        ("key_body", C.c_int32 * 8),
+        ("soft_limits", C.c_void_p), ("soft_limits_stride", C.c_int64),
+        ("episode_length", C.c_void_p), ("command", C.c_void_p), ("last_actions", C.c_void_p),
+    ]
+
+
+class AmpEnvBuffers(C.Structure):
+    _fields_ = [
+        ("amp_obs_buffer", C.c_void_p), ("policy_obs", C.c_void_p), ("actor_history", C.c_void_p),
+        ("just_reset", C.c_void_p), ("reward", C.c_void_p), ("reward_terms", C.c_void_p), ("died", C.c_void_p),
+        ("time_out", C.c_void_p), ("reset_mask", C.c_void_p), ("reset_tile_counts", C.c_void_p),
+    ]
+
+
+class AmpDiscDesc(C.Structure):
+    _fields_ = [
+        ("in_dim", C.c_int32), ("h1", C.c_int32), ("h2", C.c_int32), ("reserved", C.c_int32),
+        ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p), ("w3", C.c_void_p), ("b3", C.c_void_p),
+    ]
+
+
+_vp, _i64, _i32, _f32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float
+
+# name -> (restype, argtypes); every symbol include/amp_engine.h declares
+SIGNATURES = {
+    "amp_abi_version": (C.c_int, []),
+    "amp_last_error": (C.c_char_p, []),
+    "amp_device_name": (C.c_int, [C.c_char_p, _i64]),
+    "amp_motion_create": (C.c_int, [C.POINTER(AmpMotionDesc), C.POINTER(_vp)]),
+    "amp_motion_destroy": (C.c_int, [_vp]),
+    "amp_motion_set_obs_layout": (C.c_int, [_vp, C.POINTER(_i32), _i32, C.POINTER(_i32), _i32, _vp]),
+    "amp_motion_frame_blend": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "amp_motion_sample": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "amp_collect_reference": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "amp_reset_reference_state": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _vp, _vp, _vp, _vp]),
+    "amp_policy_obs_size": (_i64, [C.POINTER(AmpEnvCfg)]),
+    "amp_actor_history_frame_size": (_i64, [C.POINTER(AmpEnvCfg)]),
+    "amp_env_step": (C.c_int, [C.POINTER(AmpEnvCfg), C.POINTER(AmpSimState), C.POINTER(AmpEnvBuffers), _i64, C.c_uint32, _vp]),
+    "amp_reset_compact_workspace_bytes": (_i64, [_i64]),
+    "amp_reset_compact": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "amp_reset_compact_tiles": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "amp_disc_create": (C.c_int, [C.POINTER(AmpDiscDesc), _vp, C.POINTER(_vp)]),
+    "amp_disc_destroy": (C.c_int, [_vp]),
+    "amp_disc_set_scaler": (C.c_int, [_vp, _vp, _vp, _f32, _f32, _vp]),
+    "amp_disc_workspace_bytes": (_i64, [_vp, _i64]),
+    "amp_disc_style_reward": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle of libamp_engine.so; raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP engine has not been built.  Run "
+            "`python -c \"import __graft_entry__ as g; g.build()\"` (needs hipcc, cross-compiles gfx950).  "
+            "humanoid_amp_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.amp_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"libamp_engine.so has ABI version {got}, this package expects {ABI_VERSION}: rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().amp_last_error().decode("utf-8", "replace")
+        raise AmpEngineError(f"{what or 'libamp_engine'} failed (code {rc}): {msg}")
+
+
+def require_gpu(device) -> torch.device:
+    """The engine computes on a HIP device only; anything else is an error, never a silent CPU path."""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise AmpEngineError(f"humanoid_amp_amd computes on an MI355X (torch device 'cuda:N'); got device '{dev}'. "
+                             "There is no CPU fallback.")
+    if not torch.cuda.is_available():
+        raise AmpEngineError("no HIP device is visible to torch; humanoid_amp_amd has no CPU fallback")
+    return dev
+
+
+def stream_ptr(device=None) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def dptr(t, dtype=None, name: str = "tensor") -> C.c_void_p:
+    """Device pointer of a contiguous GPU tensor (None -> NULL), with dtype / layout checks."""
+    if t is None:
+        return C.c_void_p(None)
+    if not isinstance(t, torch.Tensor) or t.device.type != "cuda":
+        raise AmpEngineError(f"{name} must be a torch tensor on a HIP device")
+    if dtype is not None and t.dtype != dtype:
+        raise AmpEngineError(f"{name} must have dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise AmpEngineError(f"{name} must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def strided_view(t: torch.Tensor, inner: int, name: str):
+    """(pointer, env stride in elements) of a [N, inner] fp32 view whose last dim is contiguous."""
+    if t.device.type != "cuda" or t.dtype != torch.float32:
+        raise AmpEngineError(f"{name} must be a float32 tensor on a HIP device")
+    if t.dim() != 2 or t.shape[1] != inner or (inner > 1 and t.stride(1) != 1):
+        raise AmpEngineError(f"{name} must be a [N, {inner}] view with a contiguous last dim, got {tuple(t.shape)} / {t.stride()}")
+    return C.c_void_p(t.data_ptr()), int(t.stride(0))

@@ -1,0 +1,116 @@
+// Shared host/device helpers of libamp_engine.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/amp_engine.h"
+
+namespace amp {
+
+// ---- error plumbing: no exception crosses the C ABI ------------------------------------------------
+char* last_error_buf();  // thread-local, 512 bytes
+inline int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(last_error_buf(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define AMP_HIP(expr)                                                                                      \
+  do {                                                                                                     \
+    hipError_t _e = (expr);                                                                                \
+    if (_e != hipSuccess) return ::amp::fail(AMP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+#define AMP_REQUIRE(cond, ...)                                   \
+  do {                                                           \
+    if (!(cond)) return ::amp::fail(AMP_ERR_INVALID, __VA_ARGS__); \
+  } while (0)
+
+inline int launch_status(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(AMP_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+  return AMP_OK;
+}
+
+constexpr int kWave = 64;     // gfx950 wavefront
+constexpr int kBlock = 256;   // 4 waves, one per SIMD
+constexpr int kMaxKey = 8;
+
+// ---- device-side math restating the reference's fp32 op order (compiled with -ffp-contract=off) ----
+struct Quat {
+  float w, x, y, z;
+};
+
+__device__ __forceinline__ float lerp_ref(float a, float b, float t) {
+  // (1 - t) * a + t * b : sub, mul, mul, add -- motions/motion_loader.py:215
+  return (1.0f - t) * a + t * b;
+}
+
+__device__ __forceinline__ Quat slerp_ref(Quat q0, Quat q1, float t) {
+  // motions/motion_loader.py:247-279 (wxyz; no renormalisation; branch order matters)
+  float c = ((q0.w * q1.w + q0.x * q1.x) + q0.y * q1.y) + q0.z * q1.z;
+  if (c < 0.0f) {
+    q1.w = -q1.w;
+    q1.x = -q1.x;
+    q1.y = -q1.y;
+    q1.z = -q1.z;
+  }
+  c = fabsf(c);
+  const float half = acosf(c);
+  const float s = sqrtf(1.0f - c * c);
+  const float ra = sinf((1.0f - t) * half) / s;
+  const float rb = sinf(t * half) / s;
+  Quat o;
+  o.w = ra * q0.w + rb * q1.w;
+  o.x = ra * q0.x + rb * q1.x;
+  o.y = ra * q0.y + rb * q1.y;
+  o.z = ra * q0.z + rb * q1.z;
+  if (fabsf(s) < 0.001f) {
+    o.w = 0.5f * q0.w + 0.5f * q1.w;
+    o.x = 0.5f * q0.x + 0.5f * q1.x;
+    o.y = 0.5f * q0.y + 0.5f * q1.y;
+    o.z = 0.5f * q0.z + 0.5f * q1.z;
+  }
+  if (fabsf(c) >= 1.0f) o = q0;
+  return o;
+}
+
+struct Vec3 {
+  float x, y, z;
+};
+
+__device__ __forceinline__ Vec3 cross_ref(Vec3 a, Vec3 b) {
+  return Vec3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+__device__ __forceinline__ Vec3 quat_apply_ref(Quat q, Vec3 v) {
+  // Isaac Lab quat_apply: t = 2 * (q_xyz x v);  v + w * t + q_xyz x t   (call sites g1_amp_env.py:495-496)
+  const Vec3 u{q.x, q.y, q.z};
+  Vec3 t = cross_ref(u, v);
+  t.x *= 2.0f;
+  t.y *= 2.0f;
+  t.z *= 2.0f;
+  const Vec3 c = cross_ref(u, t);
+  return Vec3{(v.x + q.w * t.x) + c.x, (v.y + q.w * t.y) + c.y, (v.z + q.w * t.z) + c.z};
+}
+
+__device__ __forceinline__ Vec3 quat_rotate_inverse_ref(Quat q, Vec3 v) {
+  // Isaac Lab quat_rotate_inverse: a - b + c  (call site g1_amp_env.py:253)
+  const float s = 2.0f * (q.w * q.w) - 1.0f;
+  const Vec3 u{q.x, q.y, q.z};
+  const Vec3 cr = cross_ref(u, v);
+  const float d = (u.x * v.x + u.y * v.y) + u.z * v.z;
+  Vec3 o;
+  o.x = (v.x * s - (cr.x * q.w) * 2.0f) + (u.x * d) * 2.0f;
+  o.y = (v.y * s - (cr.y * q.w) * 2.0f) + (u.y * d) * 2.0f;
+  o.z = (v.z * s - (cr.z * q.w) * 2.0f) + (u.z * d) * 2.0f;
+  return o;
+}
+
+}  // namespace amp

@@ -1,0 +1,483 @@
+// Motion table kernels: frame/blend index (fp64), LERP x5 + SLERP sampling, fused expert AMP
+// observations, reference-state reset.  gfx950 only; built with -ffp-contract=off (SURVEY.md section 7:
+// sqrt(1 - c*c) must not become an fma, the quaternion dot must keep its rounding).
+//
+// Work decomposition (all kernels): a workgroup owns a TILE of 256 consecutive samples.
+//   phase A  one sample per lane: fp64 frame/blend index math (+ the per-sample quaternion work) -> LDS
+//   phase B  the tile's output is one contiguous run of floats; lanes walk it flat, so every store is a
+//            full-wave coalesced 256-B write, and the two bracketing table rows of a sample are read as
+//            contiguous row segments (the tables are <= 1.4 MB: L2 / Infinity-Cache resident).
+#include "amp_common.hpp"
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+namespace amp {
+
+struct ClipMeta {
+  const int64_t* first;  // [C] global index of the clip's first frame
+  const int64_t* span;   // [C] frames - 1
+  const double* dur;     // [C] dt * (frames - 1)
+  double dt;
+  int32_t n_clips;
+};
+
+struct MotionView {
+  ClipMeta clips;
+  const float* dof_pos;
+  const float* dof_vel;
+  const float* body_pos;
+  const float* body_rot;
+  const float* body_lin;
+  const float* body_ang;
+  const float* hot;  // [F, D] private hot-subset table
+  int32_t n_dof, n_bodies, n_key, D;
+};
+
+}  // namespace amp
+
+struct AmpMotion {
+  amp::MotionView v;
+  int device;
+  int64_t n_frames;
+  int64_t* d_first;
+  int64_t* d_span;
+  double* d_dur;
+  float* d_hot;
+  int32_t* d_perm;
+  int32_t ref_body;
+  int32_t key_bodies[amp::kMaxKey];
+  bool has_layout;
+};
+
+namespace amp {
+
+// motions/motion_loader.py:281-307 in fp64 with numpy semantics.
+__device__ __forceinline__ void frame_blend_ref(const ClipMeta& m, double t, int64_t clip, int64_t& i0, int64_t& i1,
+                                                double& blend) {
+  // out-of-range ids would index the clip arrays out of bounds: clamp (the host wrapper validates too)
+  clip = clip < 0 ? 0 : (clip >= m.n_clips ? m.n_clips - 1 : clip);
+  const double dur = m.dur[clip];
+  const int64_t first = m.first[clip];
+  const int64_t span = m.span[clip];
+  double phase = t / dur;
+  phase = phase < 0.0 ? 0.0 : (phase > 1.0 ? 1.0 : phase);  // np.clip
+  if (!(phase >= 0.0)) phase = 0.0;                           // NaN time: keep the index in range
+  const int64_t l0 = (int64_t)rint(phase * (double)span);    // round-half-to-even
+  const int64_t l1 = l0 + 1 < span ? l0 + 1 : span;
+  i0 = first + l0;
+  i1 = first + l1;
+  blend = rint(((t - (double)l0 * m.dt) / m.dt) * 1e5) / 1e5;  // == np.round(x, 5)
+}
+
+__global__ __launch_bounds__(kBlock) void frame_blend_kernel(ClipMeta m, const double* __restrict__ times,
+                                                             const int64_t* __restrict__ ids, int64_t n,
+                                                             int64_t* __restrict__ o0, int64_t* __restrict__ o1,
+                                                             double* __restrict__ ob) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  int64_t a, b;
+  double w;
+  frame_blend_ref(m, times[i], ids ? ids[i] : 0, a, b, w);
+  o0[i] = a;
+  o1[i] = b;
+  ob[i] = w;
+}
+
+// hot[f] = [dof_pos[perm] | dof_vel[perm] | ref pos 3 | ref quat 4 | ref lin 3 | ref ang 3 | key pos 3*n_key]
+__global__ __launch_bounds__(kBlock) void build_hot_kernel(MotionView v, int64_t n_frames, const int32_t* __restrict__ perm,
+                                                           int32_t ref, const int32_t* __restrict__ keys,
+                                                           float* __restrict__ hot) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int D = v.D;
+  if (e >= n_frames * D) return;
+  const int64_t f = e / D;
+  const int j = (int)(e - f * D);
+  const int nd = v.n_dof, B = v.n_bodies;
+  float val;
+  if (j < nd) {
+    val = v.dof_pos[f * nd + perm[j]];
+  } else if (j < 2 * nd) {
+    val = v.dof_vel[f * nd + perm[j - nd]];
+  } else {
+    const int c = j - 2 * nd;
+    if (c < 3) val = v.body_pos[(f * B + ref) * 3 + c];
+    else if (c < 7) val = v.body_rot[(f * B + ref) * 4 + (c - 3)];
+    else if (c < 10) val = v.body_lin[(f * B + ref) * 3 + (c - 7)];
+    else if (c < 13) val = v.body_ang[(f * B + ref) * 3 + (c - 10)];
+    else {
+      const int kk = (c - 13) / 3, ax = (c - 13) % 3;
+      val = v.body_pos[(f * B + keys[kk]) * 3 + ax];
+    }
+  }
+  hot[e] = val;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MotionLoader.sample: 6 outputs (motions/motion_loader.py:373-390)
+// ------------------------------------------------------------------------------------------------
+struct SampleSlot {
+  int32_t i0, i1;
+  float blend;
+};
+
+__device__ __forceinline__ void lerp_table_tile(const float* __restrict__ table, float* __restrict__ out, int row,
+                                                int64_t tile_base, int n_tile, const SampleSlot* slots) {
+  if (!out) return;
+  // flat walk over n_tile*row contiguous output floats; (s, j) advanced incrementally (no division in the loop)
+  const int step_s = kBlock / row, step_j = kBlock % row;
+  int s = threadIdx.x / row, j = threadIdx.x % row;
+  float* o = out + tile_base * row;
+  for (int e = threadIdx.x; e < n_tile * row; e += kBlock) {
+    const SampleSlot sl = slots[s];
+    const float a = table[(int64_t)sl.i0 * row + j];
+    const float b = table[(int64_t)sl.i1 * row + j];
+    o[e] = lerp_ref(a, b, sl.blend);
+    s += step_s;
+    j += step_j;
+    if (j >= row) {
+      j -= row;
+      s += 1;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void sample_kernel(MotionView v, const double* __restrict__ times,
+                                                        const int64_t* __restrict__ ids, int64_t n,
+                                                        float* __restrict__ o_dp, float* __restrict__ o_dv,
+                                                        float* __restrict__ o_bp, float* __restrict__ o_br,
+                                                        float* __restrict__ o_bl, float* __restrict__ o_ba) {
+  __shared__ SampleSlot slots[kBlock];
+  const int64_t tile_base = (int64_t)blockIdx.x * kBlock;
+  const int n_tile = (int)((n - tile_base) < kBlock ? (n - tile_base) : kBlock);
+  if (threadIdx.x < n_tile) {
+    const int64_t i = tile_base + threadIdx.x;
+    int64_t a, b;
+    double w;
+    frame_blend_ref(v.clips, times[i], ids ? ids[i] : 0, a, b, w);
+    slots[threadIdx.x] = SampleSlot{(int32_t)a, (int32_t)b, (float)w};
+  }
+  __syncthreads();
+  const int nd = v.n_dof, B = v.n_bodies;
+  lerp_table_tile(v.dof_pos, o_dp, nd, tile_base, n_tile, slots);
+  lerp_table_tile(v.dof_vel, o_dv, nd, tile_base, n_tile, slots);
+  lerp_table_tile(v.body_pos, o_bp, B * 3, tile_base, n_tile, slots);
+  lerp_table_tile(v.body_lin, o_bl, B * 3, tile_base, n_tile, slots);
+  lerp_table_tile(v.body_ang, o_ba, B * 3, tile_base, n_tile, slots);
+  if (o_br) {
+    // one quaternion per lane: two 16-B row gathers, one 16-B coalesced store
+    const f4* __restrict__ rot = reinterpret_cast<const f4*>(v.body_rot);
+    f4* __restrict__ o = reinterpret_cast<f4*>(o_br) + tile_base * B;
+    const int step_s = kBlock / B, step_b = kBlock % B;
+    int s = threadIdx.x / B, b = threadIdx.x % B;
+    for (int e = threadIdx.x; e < n_tile * B; e += kBlock) {
+      const SampleSlot sl = slots[s];
+      const f4 a = rot[(int64_t)sl.i0 * B + b];
+      const f4 c = rot[(int64_t)sl.i1 * B + b];
+      const Quat q = slerp_ref(Quat{a.x, a.y, a.z, a.w}, Quat{c.x, c.y, c.z, c.w}, sl.blend);
+      o[e] = f4{q.w, q.x, q.y, q.z};
+      s += step_s;
+      b += step_b;
+      if (b >= B) {
+        b -= B;
+        s += 1;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// collect_reference_motions fused with compute_obs (g1_amp_env.py:445-486, 535-561)
+// ------------------------------------------------------------------------------------------------
+struct ExpertSlot {
+  int32_t i0, i1;
+  float blend;
+  float tn[6];   // tangent | normal of the slerped reference-body quaternion
+  float rp[3];   // lerped reference-body position
+  int64_t obase; // float offset of this sample's output row
+};
+
+__global__ __launch_bounds__(kBlock) void collect_reference_kernel(MotionView v, const double* __restrict__ times,
+                                                                   const int64_t* __restrict__ ids, int64_t n, int K,
+                                                                   float* __restrict__ out,
+                                                                   const int64_t* __restrict__ dst_rows) {
+  __shared__ ExpertSlot slots[kBlock];
+  const int D = v.D, nd2 = 2 * v.n_dof;
+  const int64_t total = n * K;
+  const int64_t tile_base = (int64_t)blockIdx.x * kBlock;
+  const int n_tile = (int)((total - tile_base) < kBlock ? (total - tile_base) : kBlock);
+  const float* __restrict__ hot = v.hot;
+  if (threadIdx.x < n_tile) {
+    const int64_t sidx = tile_base + threadIdx.x;
+    const int64_t r = sidx / K;
+    const int k = (int)(sidx - r * K);
+    // history time t - dt*k in fp64 (g1_amp_env.py:454-457)
+    const double t = times[r] - v.clips.dt * (double)k;
+    int64_t a, b;
+    double w;
+    frame_blend_ref(v.clips, t, ids ? ids[r] : 0, a, b, w);
+    ExpertSlot sl;
+    sl.i0 = (int32_t)a;
+    sl.i1 = (int32_t)b;
+    sl.blend = (float)w;
+    const float* r0 = hot + a * D + nd2;
+    const float* r1 = hot + b * D + nd2;
+    sl.rp[0] = lerp_ref(r0[0], r1[0], sl.blend);
+    sl.rp[1] = lerp_ref(r0[1], r1[1], sl.blend);
+    sl.rp[2] = lerp_ref(r0[2], r1[2], sl.blend);
+    const Quat q = slerp_ref(Quat{r0[3], r0[4], r0[5], r0[6]}, Quat{r1[3], r1[4], r1[5], r1[6]}, sl.blend);
+    const Vec3 tg = quat_apply_ref(q, Vec3{1.0f, 0.0f, 0.0f});
+    const Vec3 nm = quat_apply_ref(q, Vec3{0.0f, 0.0f, 1.0f});
+    sl.tn[0] = tg.x; sl.tn[1] = tg.y; sl.tn[2] = tg.z;
+    sl.tn[3] = nm.x; sl.tn[4] = nm.y; sl.tn[5] = nm.z;
+    const int64_t row = dst_rows ? dst_rows[r] : r;
+    sl.obase = (row * K + k) * (int64_t)D;
+    slots[threadIdx.x] = sl;
+  }
+  __syncthreads();
+  const int step_s = kBlock / D, step_j = kBlock % D;
+  int s = threadIdx.x / D, j = threadIdx.x % D;
+  for (int e = threadIdx.x; e < n_tile * D; e += kBlock) {
+    const ExpertSlot& sl = slots[s];
+    float val;
+    if (j > nd2 && j <= nd2 + 6) {
+      val = sl.tn[j - nd2 - 1];
+    } else {
+      const int col = (j == nd2) ? nd2 + 2 : j;  // feature "root height" reads the z column
+      val = lerp_ref(hot[(int64_t)sl.i0 * D + col], hot[(int64_t)sl.i1 * D + col], sl.blend);
+      if (j >= nd2 + 13) {
+        int ax = (j - nd2 - 13) % 3;
+        val = val - sl.rp[ax];  // key body position relative to the reference body (g1_amp_env.py:552)
+      }
+    }
+    out[sl.obase + j] = val;
+    s += step_s;
+    j += step_j;
+    if (j >= D) {
+      j -= D;
+      s += 1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// reference-state init of reset envs (g1_amp_env.py:385-411)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void reset_state_kernel(MotionView v, const double* __restrict__ times,
+                                                             const int64_t* __restrict__ ids,
+                                                             const int64_t* __restrict__ env_ids, int64_t n,
+                                                             const float* __restrict__ origins, float z_lift,
+                                                             float* __restrict__ root, float* __restrict__ o_dp,
+                                                             float* __restrict__ o_dv) {
+  __shared__ SampleSlot slots[kBlock];
+  const int D = v.D, nd = v.n_dof;
+  const int64_t tile_base = (int64_t)blockIdx.x * kBlock;
+  const int n_tile = (int)((n - tile_base) < kBlock ? (n - tile_base) : kBlock);
+  const float* __restrict__ hot = v.hot;
+  if (threadIdx.x < n_tile) {
+    const int64_t i = tile_base + threadIdx.x;
+    int64_t a, b;
+    double w;
+    frame_blend_ref(v.clips, times[i], ids ? ids[i] : 0, a, b, w);
+    const float bl = (float)w;
+    slots[threadIdx.x] = SampleSlot{(int32_t)a, (int32_t)b, bl};
+    if (root) {
+      const float* r0 = hot + a * D + 2 * nd;
+      const float* r1 = hot + b * D + 2 * nd;
+      const int64_t env = env_ids ? env_ids[i] : i;
+      float* o = root + i * 13;
+      const float* og = origins ? origins + env * 3 : nullptr;
+      const float px = lerp_ref(r0[0], r1[0], bl), py = lerp_ref(r0[1], r1[1], bl), pz = lerp_ref(r0[2], r1[2], bl);
+      o[0] = og ? px + og[0] : px;
+      o[1] = og ? py + og[1] : py;
+      o[2] = (og ? pz + og[2] : pz) + z_lift;
+      const Quat q = slerp_ref(Quat{r0[3], r0[4], r0[5], r0[6]}, Quat{r1[3], r1[4], r1[5], r1[6]}, bl);
+      o[3] = q.w; o[4] = q.x; o[5] = q.y; o[6] = q.z;
+      for (int c = 7; c < 13; ++c) o[c] = lerp_ref(r0[c], r1[c], bl);
+    }
+  }
+  __syncthreads();
+  // DoF positions / velocities are hot columns [0, nd) and [nd, 2nd), already in robot order
+  for (int which = 0; which < 2; ++which) {
+    float* out = which ? o_dv : o_dp;
+    if (!out) continue;
+    const int off = which * nd;
+    const int step_s = kBlock / nd, step_j = kBlock % nd;
+    int s = threadIdx.x / nd, j = threadIdx.x % nd;
+    float* o = out + tile_base * nd;
+    for (int e = threadIdx.x; e < n_tile * nd; e += kBlock) {
+      const SampleSlot sl = slots[s];
+      o[e] = lerp_ref(hot[(int64_t)sl.i0 * D + off + j], hot[(int64_t)sl.i1 * D + off + j], sl.blend);
+      s += step_s;
+      j += step_j;
+      if (j >= nd) {
+        j -= nd;
+        s += 1;
+      }
+    }
+  }
+}
+
+static inline unsigned grid_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace amp
+
+using namespace amp;
+
+extern "C" {
+
+int amp_motion_create(const AmpMotionDesc* d, AmpMotion** out) {
+  AMP_REQUIRE(d && out, "amp_motion_create: null argument");
+  AMP_REQUIRE(d->n_clips >= 1 && d->n_dof >= 1 && d->n_bodies >= 1, "amp_motion_create: empty shape");
+  AMP_REQUIRE(d->clip_frames, "amp_motion_create: clip_frames is null");
+  AMP_REQUIRE(d->dt > 0.0, "amp_motion_create: dt must be positive");
+  AMP_REQUIRE(d->dof_positions && d->dof_velocities && d->body_positions && d->body_rotations &&
+                  d->body_linear_velocities && d->body_angular_velocities,
+              "amp_motion_create: a motion table pointer is null");
+  int64_t total = 0;
+  for (int c = 0; c < d->n_clips; ++c) {
+    AMP_REQUIRE(d->clip_frames[c] >= 2, "amp_motion_create: clip %d has %lld frame(s); at least 2 are needed", c,
+                (long long)d->clip_frames[c]);
+    total += d->clip_frames[c];
+  }
+  AMP_REQUIRE(total == d->n_frames, "amp_motion_create: clip_frames sum to %lld but n_frames is %lld", (long long)total,
+              (long long)d->n_frames);
+  AMP_REQUIRE(total < (int64_t)1 << 31, "amp_motion_create: more than 2^31 frames");
+  AmpMotion* h = new (std::nothrow) AmpMotion();
+  AMP_REQUIRE(h, "amp_motion_create: out of host memory");
+  *h = AmpMotion{};
+  AMP_HIP(hipGetDevice(&h->device));
+  h->n_frames = total;
+  int64_t* first = new int64_t[d->n_clips];
+  int64_t* span = new int64_t[d->n_clips];
+  double* dur = new double[d->n_clips];
+  int64_t cur = 0;
+  for (int c = 0; c < d->n_clips; ++c) {
+    first[c] = cur;
+    span[c] = d->clip_frames[c] - 1;
+    dur[c] = d->dt * (double)(d->clip_frames[c] - 1);  // motions/motion_loader.py:135
+    cur += d->clip_frames[c];
+  }
+  hipError_t e = hipMalloc(&h->d_first, sizeof(int64_t) * d->n_clips);
+  if (e == hipSuccess) e = hipMalloc(&h->d_span, sizeof(int64_t) * d->n_clips);
+  if (e == hipSuccess) e = hipMalloc(&h->d_dur, sizeof(double) * d->n_clips);
+  if (e == hipSuccess) e = hipMemcpy(h->d_first, first, sizeof(int64_t) * d->n_clips, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(h->d_span, span, sizeof(int64_t) * d->n_clips, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(h->d_dur, dur, sizeof(double) * d->n_clips, hipMemcpyHostToDevice);
+  delete[] first;
+  delete[] span;
+  delete[] dur;
+  if (e != hipSuccess) {
+    amp_motion_destroy(h);
+    return fail(AMP_ERR_HIP, "amp_motion_create: %s", hipGetErrorString(e));
+  }
+  MotionView& v = h->v;
+  v.clips = ClipMeta{h->d_first, h->d_span, h->d_dur, d->dt, d->n_clips};
+  v.dof_pos = d->dof_positions;
+  v.dof_vel = d->dof_velocities;
+  v.body_pos = d->body_positions;
+  v.body_rot = d->body_rotations;
+  v.body_lin = d->body_linear_velocities;
+  v.body_ang = d->body_angular_velocities;
+  v.hot = nullptr;
+  v.n_dof = d->n_dof;
+  v.n_bodies = d->n_bodies;
+  v.n_key = 0;
+  v.D = 0;
+  *out = h;
+  return AMP_OK;
+}
+
+int amp_motion_destroy(AmpMotion* h) {
+  if (!h) return AMP_OK;
+  (void)hipFree(h->d_first);
+  (void)hipFree(h->d_span);
+  (void)hipFree(h->d_dur);
+  (void)hipFree(h->d_hot);
+  (void)hipFree(h->d_perm);
+  delete h;
+  return AMP_OK;
+}
+
+int amp_motion_set_obs_layout(AmpMotion* h, const int32_t* dof_perm, int32_t ref_body, const int32_t* key_bodies,
+                              int32_t n_key, amp_stream_t stream) {
+  AMP_REQUIRE(h && dof_perm && key_bodies, "amp_motion_set_obs_layout: null argument");
+  AMP_REQUIRE(n_key >= 1 && n_key <= kMaxKey, "amp_motion_set_obs_layout: n_key must be in [1, %d]", kMaxKey);
+  AMP_REQUIRE(ref_body >= 0 && ref_body < h->v.n_bodies, "amp_motion_set_obs_layout: ref_body %d out of range", ref_body);
+  for (int i = 0; i < h->v.n_dof; ++i)
+    AMP_REQUIRE(dof_perm[i] >= 0 && dof_perm[i] < h->v.n_dof, "amp_motion_set_obs_layout: dof_perm[%d]=%d out of range", i,
+                dof_perm[i]);
+  for (int i = 0; i < n_key; ++i)
+    AMP_REQUIRE(key_bodies[i] >= 0 && key_bodies[i] < h->v.n_bodies, "amp_motion_set_obs_layout: key body %d out of range",
+                key_bodies[i]);
+  const int D = 2 * h->v.n_dof + 13 + 3 * n_key;
+  (void)hipFree(h->d_hot);
+  (void)hipFree(h->d_perm);
+  h->d_hot = nullptr;
+  h->d_perm = nullptr;
+  AMP_HIP(hipMalloc(&h->d_hot, sizeof(float) * h->n_frames * D));
+  AMP_HIP(hipMalloc(&h->d_perm, sizeof(int32_t) * (h->v.n_dof + kMaxKey)));
+  hipStream_t st = (hipStream_t)stream;
+  AMP_HIP(hipMemcpyAsync(h->d_perm, dof_perm, sizeof(int32_t) * h->v.n_dof, hipMemcpyHostToDevice, st));
+  AMP_HIP(hipMemcpyAsync(h->d_perm + h->v.n_dof, key_bodies, sizeof(int32_t) * n_key, hipMemcpyHostToDevice, st));
+  AMP_HIP(hipStreamSynchronize(st));  // the host arrays may be temporaries of the caller
+  h->ref_body = ref_body;
+  for (int i = 0; i < n_key; ++i) h->key_bodies[i] = key_bodies[i];
+  h->v.n_key = n_key;
+  h->v.D = D;
+  h->v.hot = h->d_hot;
+  const int64_t total = h->n_frames * D;
+  build_hot_kernel<<<grid_for(total, kBlock), kBlock, 0, st>>>(h->v, h->n_frames, h->d_perm, ref_body, h->d_perm + h->v.n_dof,
+                                                              h->d_hot);
+  int rc = launch_status("build_hot_kernel");
+  if (rc != AMP_OK) return rc;
+  h->has_layout = true;
+  return AMP_OK;
+}
+
+int amp_motion_frame_blend(const AmpMotion* h, const double* times, const int64_t* ids, int64_t n, int64_t* i0, int64_t* i1,
+                           double* blend, amp_stream_t stream) {
+  AMP_REQUIRE(h, "amp_motion_frame_blend: null handle");
+  AMP_REQUIRE(n >= 0, "amp_motion_frame_blend: negative n");
+  if (n == 0) return AMP_OK;
+  AMP_REQUIRE(times && i0 && i1 && blend, "amp_motion_frame_blend: null buffer");
+  frame_blend_kernel<<<grid_for(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(h->v.clips, times, ids, n, i0, i1, blend);
+  return launch_status("frame_blend_kernel");
+}
+
+int amp_motion_sample(const AmpMotion* h, const double* times, const int64_t* ids, int64_t n, float* dp, float* dv, float* bp,
+                      float* br, float* bl, float* ba, amp_stream_t stream) {
+  AMP_REQUIRE(h, "amp_motion_sample: null handle");
+  AMP_REQUIRE(n >= 0, "amp_motion_sample: negative n");
+  if (n == 0) return AMP_OK;
+  AMP_REQUIRE(times, "amp_motion_sample: times is null");
+  AMP_REQUIRE(n * (int64_t)h->v.n_bodies * 4 < ((int64_t)1 << 40), "amp_motion_sample: n too large");
+  AMP_REQUIRE(br == nullptr || ((uintptr_t)br % 16 == 0 && (uintptr_t)h->v.body_rot % 16 == 0),
+              "amp_motion_sample: quaternion buffers must be 16-byte aligned");
+  sample_kernel<<<grid_for(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(h->v, times, ids, n, dp, dv, bp, br, bl, ba);
+  return launch_status("sample_kernel");
+}
+
+int amp_collect_reference(const AmpMotion* h, const double* times, const int64_t* ids, int64_t n, int32_t K, float* out,
+                          const int64_t* dst_rows, amp_stream_t stream) {
+  AMP_REQUIRE(h, "amp_collect_reference: null handle");
+  AMP_REQUIRE(h->has_layout, "amp_collect_reference: call amp_motion_set_obs_layout first");
+  AMP_REQUIRE(n >= 0 && K >= 1, "amp_collect_reference: need n >= 0 and K >= 1");
+  if (n == 0) return AMP_OK;
+  AMP_REQUIRE(times && out, "amp_collect_reference: null buffer");
+  collect_reference_kernel<<<grid_for(n * K, kBlock), kBlock, 0, (hipStream_t)stream>>>(h->v, times, ids, n, K, out, dst_rows);
+  return launch_status("collect_reference_kernel");
+}
+
+int amp_reset_reference_state(const AmpMotion* h, const double* times, const int64_t* ids, const int64_t* env_ids, int64_t n,
+                              const float* origins, float z_lift, float* root, float* dp, float* dv, amp_stream_t stream) {
+  AMP_REQUIRE(h, "amp_reset_reference_state: null handle");
+  AMP_REQUIRE(h->has_layout, "amp_reset_reference_state: call amp_motion_set_obs_layout first");
+  AMP_REQUIRE(n >= 0, "amp_reset_reference_state: negative n");
+  if (n == 0) return AMP_OK;
+  AMP_REQUIRE(times, "amp_reset_reference_state: times is null");
+  reset_state_kernel<<<grid_for(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(h->v, times, ids, env_ids, n, origins, z_lift,
+                                                                             root, dp, dv);
+  return launch_status("reset_state_kernel");
+}
+
+}  // extern "C"

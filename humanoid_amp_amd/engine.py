@@ -1,0 +1,302 @@
+"""Host-side objects around the per-step kernels of ``libamp_engine.so``.
+
+* :class:`EnvStepKernel`   -- ``amp_env_step``: dones / task reward / observations of one env shard
+* :func:`reset_compact`    -- ``amp_reset_compact*``: ascending reset ids (replaces ``nonzero``)
+* :class:`AmpDiscriminator`-- ``amp_disc_*``: scaler + discriminator MLP + style reward
+
+Everything here is plumbing: argument checks, pointer marshalling, output allocation.  No arithmetic.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import torch
+
+from . import _native as nat
+
+
+# ---------------------------------------------------------------------------------------------------
+# env step
+# ---------------------------------------------------------------------------------------------------
+
+
+@dataclass
+class EnvStepConfig:
+    """Values of the reference config that the kernels need (g1_amp_env_cfg.py:22-141, humanoid_amp_env_cfg.py:23-78)."""
+
+    n_dof: int
+    num_amp_observations: int
+    max_episode_length: int
+    n_key: int = 4
+    num_actor_observations: int = 1
+    use_last_actions: bool = True          # G1: policy obs = base | last_actions [| command]; humanoid: False
+    history_include_last_actions: bool = True
+    history_include_command: bool = True
+    early_termination: bool = True
+    termination_height: float = 0.5
+    reward_mode: int = 1                   # 1: G1 task reward, 0: constant 1 (humanoid)
+    rew_termination: float = 0.0
+    rew_action_l2: float = 0.0
+    rew_joint_pos_limits: float = 0.0
+    rew_joint_acc_l2: float = 0.0
+    rew_joint_vel_l2: float = 0.0
+    rew_track_vel: float = 0.0
+    track_sigma: float = 0.5               # g1_amp_env.py:263
+    track_floor: float = 4.0               # g1_amp_env.py:264
+
+    @property
+    def use_command(self) -> bool:
+        return self.use_last_actions and self.rew_track_vel > 0.0
+
+    @property
+    def amp_frame_size(self) -> int:
+        return 2 * self.n_dof + 13 + 3 * self.n_key
+
+    def to_c(self) -> nat.AmpEnvCfg:
+        c = nat.AmpEnvCfg()
+        c.n_dof, c.n_key = self.n_dof, self.n_key
+        c.num_amp_observations, c.num_actor_observations = self.num_amp_observations, self.num_actor_observations
+        c.use_last_actions, c.use_command = int(self.use_last_actions), int(self.use_command)
+        c.history_include_last_actions = int(self.history_include_last_actions)
+        c.history_include_command = int(self.history_include_command)
+        c.early_termination, c.reward_mode = int(self.early_termination), int(self.reward_mode)
+        c.max_episode_length = int(self.max_episode_length)
+        c.termination_height = self.termination_height
+        c.rew_termination, c.rew_action_l2 = self.rew_termination, self.rew_action_l2
+        c.rew_joint_pos_limits, c.rew_joint_acc_l2 = self.rew_joint_pos_limits, self.rew_joint_acc_l2
+        c.rew_joint_vel_l2 = self.rew_joint_vel_l2
+        c.rew_track_vel, c.track_sigma, c.track_floor = float(self.rew_track_vel), float(self.track_sigma), float(self.track_floor)
+        return c
+
+
+REWARD_TERMS = ("total_reward", "rew_track_vel", "error_track_vel", "pub_termination", "pub_action_l2",
+                "pub_joint_pos_limits", "pub_joint_acc_l2", "pub_joint_vel_l2")
+
+
+class EnvStepKernel:
+    """Owns the output buffers of one env shard and launches ``amp_env_step`` on views of the sim state."""
+
+    def __init__(self, cfg: EnvStepConfig, num_envs: int, device, log_reward_terms: bool = False):
+        self.cfg = cfg
+        self.device = nat.require_gpu(device)
+        self.num_envs = int(num_envs)
+        self._lib = nat.load()
+        self._c = cfg.to_c()
+        P = int(self._lib.amp_policy_obs_size(C.byref(self._c)))
+        per = int(self._lib.amp_actor_history_frame_size(C.byref(self._c)))
+        if P < 0 or per < 0:
+            raise nat.AmpEngineError("invalid env configuration: " + self._lib.amp_last_error().decode())
+        self.policy_obs_size, self.actor_hist_per_frame = P, per
+        N, K, D, dev = self.num_envs, cfg.num_amp_observations, cfg.amp_frame_size, self.device
+        self.amp_observation_buffer = torch.zeros((N, K, D), device=dev)
+        self.policy_obs = torch.zeros((N, P), device=dev)
+        self.reward = torch.zeros(N, device=dev)
+        self.died = torch.zeros(N, dtype=torch.bool, device=dev)
+        self.time_out = torch.zeros(N, dtype=torch.bool, device=dev)
+        self.reset_mask = torch.zeros(N, dtype=torch.bool, device=dev)
+        self.reset_tile_counts = torch.zeros((N + nat.TILE_ENVS - 1) // nat.TILE_ENVS, dtype=torch.int32, device=dev)
+        self.reward_terms = torch.zeros((len(REWARD_TERMS), N), device=dev) if log_reward_terms else None
+        if cfg.num_actor_observations > 1:
+            self.actor_obs_history_buffer = torch.zeros((N, cfg.num_actor_observations - 1, per), device=dev)
+            self.just_reset_mask = torch.zeros(N, dtype=torch.bool, device=dev)
+        else:
+            self.actor_obs_history_buffer, self.just_reset_mask = None, None
+        self.reset_ids = torch.zeros(N, dtype=torch.int64, device=dev)
+        self.reset_count = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def _buffers(self) -> nat.AmpEnvBuffers:
+        b = nat.AmpEnvBuffers()
+        p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        b.amp_obs_buffer, b.policy_obs = p(self.amp_observation_buffer), p(self.policy_obs)
+        b.actor_history, b.just_reset = p(self.actor_obs_history_buffer), p(self.just_reset_mask)
+        b.reward, b.reward_terms = p(self.reward), p(self.reward_terms)
+        b.died, b.time_out, b.reset_mask = p(self.died), p(self.time_out), p(self.reset_mask)
+        b.reset_tile_counts = p(self.reset_tile_counts)
+        return b
+
+    def launch(self, phases: int, *, joint_pos=None, joint_vel=None, joint_acc=None, actions=None, root_pos=None,
+               root_quat=None, root_lin_vel=None, root_ang_vel=None, body_pos=None, key_body_indexes: Sequence[int] = (),
+               soft_limits=None, episode_length=None, command=None, last_actions=None) -> None:
+        """One ``amp_env_step`` launch.  State arguments are torch views straight off the simulator:
+        ``[N, n_dof]`` rows (any env stride), ``[N, 3|4]`` root views (e.g. ``body_pos_w[:, ref]``),
+        ``body_pos`` = ``[N, B, 3]`` with ``key_body_indexes`` into B, ``soft_limits`` ``[N, n_dof, 2]`` or ``[n_dof, 2]``."""
+        cfg, N = self.cfg, self.num_envs
+        s = nat.AmpSimState()
+
+        def put(field, t, inner):
+            if t is None:
+                return
+            if t.shape[0] != N:
+                raise nat.AmpEngineError(f"{field} has {t.shape[0]} rows, expected {N}")
+            ptr, stride = nat.strided_view(t, inner, field)
+            setattr(s, field, ptr)
+            setattr(s, field + "_stride", stride)
+
+        put("joint_pos", joint_pos, cfg.n_dof)
+        put("joint_vel", joint_vel, cfg.n_dof)
+        put("joint_acc", joint_acc, cfg.n_dof)
+        put("actions", actions, cfg.n_dof)
+        put("root_pos", root_pos, 3)
+        put("root_quat", root_quat, 4)
+        put("root_lin_vel", root_lin_vel, 3)
+        put("root_ang_vel", root_ang_vel, 3)
+        if body_pos is not None:
+            if body_pos.dim() != 3 or body_pos.shape[0] != N or body_pos.shape[2] != 3 or body_pos.stride(2) != 1 \
+                    or body_pos.stride(1) != 3 or body_pos.dtype != torch.float32 or body_pos.device.type != "cuda":
+                raise nat.AmpEngineError("body_pos must be a float32 [N, B, 3] HIP tensor with packed bodies")
+            if len(key_body_indexes) != cfg.n_key or max(key_body_indexes) >= body_pos.shape[1] or min(key_body_indexes) < 0:
+                raise nat.AmpEngineError(f"need {cfg.n_key} key body indexes inside [0, {body_pos.shape[1]})")
+            s.body_pos, s.body_pos_stride = body_pos.data_ptr(), int(body_pos.stride(0))
+            for i, k in enumerate(key_body_indexes):
+                s.key_body[i] = int(k)
+        if soft_limits is not None:
+            if soft_limits.dtype != torch.float32 or soft_limits.device.type != "cuda" or soft_limits.shape[-2:] != (cfg.n_dof, 2) \
+                    or soft_limits.stride(-1) != 1 or soft_limits.stride(-2) != 2:
+                raise nat.AmpEngineError("soft_limits must be a float32 [N, n_dof, 2] or [n_dof, 2] HIP tensor")
+            s.soft_limits = soft_limits.data_ptr()
+            s.soft_limits_stride = int(soft_limits.stride(0)) if soft_limits.dim() == 3 else 0
+            if soft_limits.dim() == 3 and soft_limits.shape[0] != N:
+                raise nat.AmpEngineError("soft_limits has the wrong number of envs")
+        s.episode_length = nat.dptr(episode_length, torch.int64, "episode_length").value if episode_length is not None else None
+        s.command = nat.dptr(command, torch.float32, "command").value if command is not None else None
+        s.last_actions = nat.dptr(last_actions, torch.float32, "last_actions").value if last_actions is not None else None
+        for name, t, shape in (("episode_length", episode_length, (N,)), ("command", command, (N, 2)),
+                               ("last_actions", last_actions, (N, cfg.n_dof))):
+            if t is not None and tuple(t.shape) != shape:
+                raise nat.AmpEngineError(f"{name} must have shape {shape}, got {tuple(t.shape)}")
+        b = self._buffers()
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.amp_env_step(C.byref(self._c), C.byref(s), C.byref(b), N, int(phases), nat.stream_ptr()),
+                      "amp_env_step")
+
+    def compact_resets(self):
+        """Ascending reset ids from ``reset_mask`` using the tile counts of the last DONES launch.
+        Returns (ids buffer [N] int64, count [1] int64), both on the device: no host sync here."""
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.amp_reset_compact_tiles(nat.dptr(self.reset_mask), nat.dptr(self.reset_tile_counts),
+                                                        self.num_envs, nat.dptr(self.reset_ids), nat.dptr(self.reset_count),
+                                                        nat.stream_ptr()), "amp_reset_compact_tiles")
+        return self.reset_ids, self.reset_count
+
+
+def reset_compact(mask: torch.Tensor):
+    """Stand-alone ``mask.nonzero().squeeze(-1)``: returns (ids [N] int64 buffer, count [1] int64) on the device."""
+    lib = nat.load()
+    dev = nat.require_gpu(mask.device)
+    if mask.dim() != 1 or mask.dtype not in (torch.bool, torch.uint8) or not mask.is_contiguous():
+        raise nat.AmpEngineError("mask must be a contiguous 1-D bool / uint8 tensor")
+    n = mask.numel()
+    ids = torch.empty(n, dtype=torch.int64, device=dev)
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    ws = torch.empty(max(int(lib.amp_reset_compact_workspace_bytes(n)), 4), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        nat.check(lib.amp_reset_compact(nat.dptr(mask), n, nat.dptr(ids), nat.dptr(count), nat.dptr(ws), nat.stream_ptr()),
+                  "amp_reset_compact")
+    return ids, count
+
+
+# ---------------------------------------------------------------------------------------------------
+# discriminator
+# ---------------------------------------------------------------------------------------------------
+
+
+class AmpDiscriminator:
+    """Inference half of skrl's AMP agent: ``amp_state_preprocessor`` -> discriminator MLP -> style reward
+    (shape agents/skrl_g1_walk_amp_cfg.yaml:31-39; scales :88-95).  Weights are copied into the engine at
+    construction; ``load_state_dict``-style updates go through :meth:`set_weights`."""
+
+    def __init__(self, weights: Sequence, device, *, running_mean: Optional[torch.Tensor] = None,
+                 running_variance: Optional[torch.Tensor] = None, epsilon: float = 1e-8, clip_threshold: float = 5.0,
+                 discriminator_reward_scale: float = 2.0, task_reward_weight: float = 0.0, style_reward_weight: float = 1.0):
+        self.device = nat.require_gpu(device)
+        self._lib = nat.load()
+        self._handle = None
+        self.reward_scale = float(discriminator_reward_scale)
+        self.task_reward_weight, self.style_reward_weight = float(task_reward_weight), float(style_reward_weight)
+        self.epsilon, self.clip_threshold = float(epsilon), float(clip_threshold)
+        self._ws = None
+        self.set_weights(weights)
+        if running_mean is not None:
+            self.set_scaler(running_mean, running_variance)
+
+    def set_weights(self, weights: Sequence) -> None:
+        """weights = [(W1 [1024,in], b1), (W2 [512,1024], b2), (W3 [1,512], b3)] in torch.nn.Linear layout."""
+        if len(weights) != 3:
+            raise ValueError("the discriminator has exactly three Linear layers")
+        flat = []
+        for w, b in weights:
+            flat.append(w.detach().to(device=self.device, dtype=torch.float32).contiguous())
+            flat.append(b.detach().to(device=self.device, dtype=torch.float32).contiguous())
+        w1, b1, w2, b2, w3, b3 = flat
+        if w2.shape[1] != w1.shape[0] or w3.shape != (1, w2.shape[0]) or b1.numel() != w1.shape[0] or b2.numel() != w2.shape[0] \
+                or b3.numel() != 1:
+            raise ValueError("inconsistent discriminator layer shapes")
+        d = nat.AmpDiscDesc()
+        d.in_dim, d.h1, d.h2 = int(w1.shape[1]), int(w1.shape[0]), int(w2.shape[0])
+        d.w1, d.b1, d.w2, d.b2, d.w3, d.b3 = (t.data_ptr() for t in flat)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.amp_disc_create(C.byref(d), nat.stream_ptr(), C.byref(h)), "amp_disc_create")
+        self._destroy()
+        self._handle = h
+        self.in_dim = d.in_dim
+
+    def set_scaler(self, running_mean: torch.Tensor, running_variance: torch.Tensor) -> None:
+        """RunningStandardScaler statistics (kept in float64 like skrl does)."""
+        m = running_mean.detach().to(device=self.device, dtype=torch.float64).contiguous()
+        v = running_variance.detach().to(device=self.device, dtype=torch.float64).contiguous()
+        if m.numel() != self.in_dim or v.numel() != self.in_dim:
+            raise ValueError(f"scaler statistics must have {self.in_dim} entries")
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.amp_disc_set_scaler(self._handle, nat.dptr(m), nat.dptr(v), self.epsilon, self.clip_threshold,
+                                                    nat.stream_ptr()), "amp_disc_set_scaler")
+            torch.cuda.current_stream().synchronize()  # m / v are temporaries
+
+    def _workspace(self, rows: int) -> torch.Tensor:
+        need = int(self._lib.amp_disc_workspace_bytes(self._handle, rows))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def style_reward(self, amp_obs: torch.Tensor, task_reward: Optional[torch.Tensor] = None, *, want_logits: bool = False):
+        """amp_obs [M, K*D] -> dict(style [M,1], combined [M,1] (if task_reward given), logits [M,1] (optional))."""
+        if amp_obs.dim() != 2 or amp_obs.shape[1] != self.in_dim or amp_obs.dtype != torch.float32 or amp_obs.stride(1) != 1:
+            raise nat.AmpEngineError(f"amp_obs must be float32 [M, {self.in_dim}] with a contiguous last dim")
+        nat.require_gpu(amp_obs.device)
+        M = amp_obs.shape[0]
+        f32 = dict(dtype=torch.float32, device=self.device)
+        style = torch.empty((M, 1), **f32)
+        logits = torch.empty((M, 1), **f32) if want_logits else None
+        combined, task = None, None
+        if task_reward is not None:
+            task = task_reward.reshape(-1).to(**f32).contiguous()
+            if task.numel() != M:
+                raise nat.AmpEngineError("task_reward must have one entry per row")
+            combined = torch.empty((M, 1), **f32)
+        ws = self._workspace(M)
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.amp_disc_style_reward(self._handle, C.c_void_p(amp_obs.data_ptr()), M, int(amp_obs.stride(0)) if M > 1 else self.in_dim,
+                                                      self.reward_scale, nat.dptr(task), self.task_reward_weight,
+                                                      self.style_reward_weight, nat.dptr(logits), nat.dptr(style),
+                                                      nat.dptr(combined), nat.dptr(ws), nat.stream_ptr()),
+                      "amp_disc_style_reward")
+        out = {"style": style}
+        if combined is not None:
+            out["combined"] = combined
+        if logits is not None:
+            out["logits"] = logits
+        return out
+
+    def _destroy(self):
+        h, self._handle = self._handle, None
+        if h is not None:
+            self._lib.amp_disc_destroy(h)
+
+    def __del__(self):
+        try:
+            self._destroy()
+        except Exception:
+            pass

@@ -1,0 +1,216 @@
+/*
+ * amp_engine.h -- C ABI of libamp_engine.so: the MI355X (gfx950) AMP observation / motion-sample /
+ * reward engine.  This is the drop-in boundary for the hot path of zhoushanghai/humanoid_amp
+ * (SURVEY.md section 8b).  Every entry point cites the reference interface it replaces
+ * (paths relative to the reference repository).
+ *
+ * Conventions
+ *   - plain C: pointers + sizes only, no torch / C++ types.
+ *   - every function returns int: AMP_OK (0) or a negative AMP_ERR_*; the message of the last failure
+ *     on the calling thread is returned by amp_last_error().  No C++ exception crosses this boundary.
+ *   - "dev" pointers are device (HBM) pointers owned by the CALLER; the library borrows them for the
+ *     duration of the enqueue (or, where stated, for the life time of a handle) and never frees them.
+ *   - all launches are asynchronous on the passed stream (hipStream_t, may be 0 = null stream).  No
+ *     entry point synchronises the device, allocates or frees device memory after *_create, so every
+ *     launch function is hipGraph-capturable.
+ *   - quaternions are wxyz; all floating-point tables / outputs are fp32; times are fp64; ids int64.
+ *   - handles are immutable after their *_create / *_set_* calls: re-entrant across streams.
+ */
+#ifndef AMP_ENGINE_H
+#define AMP_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMP_ABI_VERSION 1
+
+typedef void* amp_stream_t; /* hipStream_t */
+typedef struct AmpMotion AmpMotion;
+typedef struct AmpDisc AmpDisc;
+
+enum {
+  AMP_OK = 0,
+  AMP_ERR_INVALID = -1,     /* bad argument (null pointer, shape mismatch, out-of-range index) */
+  AMP_ERR_HIP = -2,         /* a HIP runtime call failed; amp_last_error() has hipGetErrorString */
+  AMP_ERR_UNSUPPORTED = -3, /* configuration outside what the kernels are built for */
+  AMP_ERR_NO_DEVICE = -4    /* no gfx950 device visible */
+};
+
+int amp_abi_version(void);
+const char* amp_last_error(void);
+/* Name of the device the library would run on; fails with AMP_ERR_NO_DEVICE when there is none. */
+int amp_device_name(char* buf, int64_t buf_len);
+
+/* ------------------------------------------------------------------------------------------------
+ * Motion table  (replaces MotionLoader.__init__, motions/motion_loader.py:98-164)
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t n_clips;
+  int32_t n_dof;
+  int32_t n_bodies;
+  int32_t reserved;
+  int64_t n_frames;           /* total frames of the concatenated tables */
+  double dt;                  /* 1/fps of the FIRST clip (motion_loader.py:122) */
+  const int64_t* clip_frames; /* HOST [n_clips] frames per clip, each >= 2 */
+  /* device tables, row-major fp32, BORROWED for the life time of the handle */
+  const float* dof_positions;           /* dev [F, n_dof]       */
+  const float* dof_velocities;          /* dev [F, n_dof]       */
+  const float* body_positions;          /* dev [F, n_bodies, 3] */
+  const float* body_rotations;          /* dev [F, n_bodies, 4] wxyz */
+  const float* body_linear_velocities;  /* dev [F, n_bodies, 3] */
+  const float* body_angular_velocities; /* dev [F, n_bodies, 3] */
+} AmpMotionDesc;
+
+int amp_motion_create(const AmpMotionDesc* desc, AmpMotion** out);
+int amp_motion_destroy(AmpMotion* h);
+
+/* Select the AMP hot subset: robot-order DoF permutation, reference body and key bodies
+ * (replaces the index plumbing of g1_amp_env.py:47-60,478-484).  Builds the handle's private
+ * [F, 2*n_dof + 13 + 3*n_key] device table.  dof_perm / key_bodies are HOST arrays. */
+int amp_motion_set_obs_layout(AmpMotion* h, const int32_t* dof_perm, int32_t ref_body,
+                              const int32_t* key_bodies, int32_t n_key, amp_stream_t stream);
+
+/* (t, clip) -> bracketing frame indices + signed blend; fp64/int64 numpy semantics.
+ * Replaces MotionLoader._compute_frame_blend (motion_loader.py:281-307).
+ * motion_ids may be NULL (clip 0 for every sample, motion_loader.py:365-366). */
+int amp_motion_frame_blend(const AmpMotion* h, const double* times_dev, const int64_t* motion_ids_dev, int64_t n,
+                           int64_t* index_0_dev, int64_t* index_1_dev, double* blend_dev, amp_stream_t stream);
+
+/* Replaces MotionLoader.sample for explicit times (motion_loader.py:331-390): 5x LERP + body SLERP.
+ * Outputs [n,n_dof] x2, [n,B,3], [n,B,4], [n,B,3], [n,B,3]; any output pointer may be NULL (skipped). */
+int amp_motion_sample(const AmpMotion* h, const double* times_dev, const int64_t* motion_ids_dev, int64_t n,
+                      float* dof_pos_dev, float* dof_vel_dev, float* body_pos_dev, float* body_rot_dev,
+                      float* body_lin_vel_dev, float* body_ang_vel_dev, amp_stream_t stream);
+
+/* Expert AMP observations: K history frames t - dt*k (newest first) per sample, fused with the feature
+ * extraction.  Replaces G1AmpEnv.collect_reference_motions (g1_amp_env.py:445-486) + compute_obs (:535-561).
+ * out_dev is [*, K, D] with D = 2*n_dof + 13 + 3*n_key.  Row r is written to row dst_rows_dev[r] when
+ * dst_rows_dev != NULL (the reset scatter amp_observation_buffer[env_ids] = ..., g1_amp_env.py:417), else r. */
+int amp_collect_reference(const AmpMotion* h, const double* times_dev, const int64_t* motion_ids_dev, int64_t n,
+                          int32_t K, float* out_dev, const int64_t* dst_rows_dev, amp_stream_t stream);
+
+/* Reference-state initialisation of reset envs: root_state [n,13] = (pos + env_origins[env_ids], z += z_lift,
+ * quat wxyz, lin vel, ang vel) of the reference body, DoF pos/vel in robot order.
+ * Replaces the sampling half of G1AmpEnv._reset_strategy_random (g1_amp_env.py:385-411).
+ * env_origins_dev is [num_envs,3]; env_ids_dev [n] indexes it (NULL: row r). */
+int amp_reset_reference_state(const AmpMotion* h, const double* times_dev, const int64_t* motion_ids_dev,
+                              const int64_t* env_ids_dev, int64_t n, const float* env_origins_dev, float z_lift,
+                              float* root_state_dev, float* dof_pos_dev, float* dof_vel_dev, amp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Per-step env kernels  (replace G1AmpEnv._get_dones / _get_rewards / _get_observations,
+ * g1_amp_env.py:175-242,246-330 and humanoid_amp_env.py:105-140)
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t n_dof;
+  int32_t n_key;                /* key bodies (4) */
+  int32_t num_amp_observations; /* K */
+  int32_t num_actor_observations; /* stacked actor frames (>= 1), g1_amp_env_cfg.py:47,176 */
+  int32_t use_last_actions;     /* 1: G1 policy obs = base | last_actions [| command]; 0: humanoid (policy obs = AMP frame) */
+  int32_t use_command;          /* rew_track_vel > 0 */
+  int32_t history_include_last_actions;
+  int32_t history_include_command;
+  int32_t early_termination;
+  int32_t reward_mode;          /* 0: constant 1 (humanoid_amp_env.py:128-129); 1: G1 task reward */
+  int64_t max_episode_length;
+  float termination_height;
+  float rew_termination, rew_action_l2, rew_joint_pos_limits, rew_joint_acc_l2, rew_joint_vel_l2;
+  /* fp64 on purpose: the reference derives threshold / slope from python floats before rounding to fp32 */
+  double rew_track_vel;         /* weight of the velocity-tracking reward (g1_amp_env.py:262) */
+  double track_sigma;           /* 0.5  (g1_amp_env.py:263) */
+  double track_floor;           /* 4.0  (g1_amp_env.py:264) */
+} AmpEnvCfg;
+
+/* Simulator state, strided views (strides in ELEMENTS between consecutive envs) so Isaac Lab's AoS
+ * tensors (robot.data.body_pos_w[:, ref] ...) can be passed without a gather. */
+typedef struct {
+  const float* joint_pos;    int64_t joint_pos_stride;    /* [N, n_dof] */
+  const float* joint_vel;    int64_t joint_vel_stride;    /* [N, n_dof] */
+  const float* joint_acc;    int64_t joint_acc_stride;    /* [N, n_dof]  (reward only) */
+  const float* actions;      int64_t actions_stride;      /* [N, n_dof]  (reward only) */
+  const float* root_pos;     int64_t root_pos_stride;     /* [N, 3] reference body */
+  const float* root_quat;    int64_t root_quat_stride;    /* [N, 4] wxyz */
+  const float* root_lin_vel; int64_t root_lin_vel_stride; /* [N, 3] world */
+  const float* root_ang_vel; int64_t root_ang_vel_stride; /* [N, 3] world */
+  const float* body_pos;     int64_t body_pos_stride;     /* [N, n_bodies_robot, 3] */
+  int32_t key_body[8];                                    /* robot body indices of the key bodies */
+  const float* soft_limits;  int64_t soft_limits_stride;  /* [N, n_dof, 2]; stride 0 = one row for all envs */
+  const int64_t* episode_length;                          /* [N] */
+  const float* command;                                   /* [N, 2] */
+  const float* last_actions;                              /* [N, n_dof] */
+} AmpSimState;
+
+typedef struct {
+  float* amp_obs_buffer;     /* [N, K, D] in/out, slot 0 = newest (g1_amp_env.py:67-74,187-190) */
+  float* policy_obs;         /* [N, P] */
+  float* actor_history;      /* [N, n_actor-1, per_frame] in/out, NULL when n_actor == 1 */
+  uint8_t* just_reset;       /* [N] in/out bool, NULL when n_actor == 1 (g1_amp_env.py:117-119,216-222) */
+  float* reward;             /* [N] task reward */
+  float* reward_terms;       /* optional [8, N]: total, track, track_err, termination, action_l2, limits, acc_l2, vel_l2 */
+  uint8_t* died;             /* [N] bool */
+  uint8_t* time_out;         /* [N] bool */
+  uint8_t* reset_mask;       /* [N] died | time_out */
+  int32_t* reset_tile_counts; /* optional [ceil(N/64)]: number of reset envs per 64-env tile (feeds amp_reset_compact_tiles) */
+} AmpEnvBuffers;
+
+enum { AMP_PHASE_DONES = 1, AMP_PHASE_REWARD = 2, AMP_PHASE_OBS = 4 };
+
+/* Size of one policy observation row for a configuration (g1_amp_env_cfg.py:186-206). */
+int64_t amp_policy_obs_size(const AmpEnvCfg* cfg);
+/* Size of one actor-history frame (g1_amp_env.py:96-107); 0 when num_actor_observations == 1. */
+int64_t amp_actor_history_frame_size(const AmpEnvCfg* cfg);
+
+/* One pass over the N envs doing the requested phases (any OR of AMP_PHASE_*), in the reference's
+ * order dones -> reward -> observations.  Pointers a phase does not need may be NULL. */
+int amp_env_step(const AmpEnvCfg* cfg, const AmpSimState* state, const AmpEnvBuffers* bufs, int64_t num_envs,
+                 uint32_t phases, amp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Reset-index compaction  (replaces reset_buf.nonzero(as_tuple=False).squeeze(-1) of DirectRLEnv.step,
+ * consumed by G1AmpEnv._reset_idx, g1_amp_env.py:332-358).  Ascending int64 ids, bit-exact.
+ * ------------------------------------------------------------------------------------------------ */
+int64_t amp_reset_compact_workspace_bytes(int64_t num_envs);
+/* mask_dev [N] (any non-zero byte = reset) -> ids_dev [<= N] ascending, count_dev [1] int64. */
+int amp_reset_compact(const uint8_t* mask_dev, int64_t num_envs, int64_t* ids_dev, int64_t* count_dev,
+                      void* workspace_dev, amp_stream_t stream);
+/* Same, re-using the per-64-env tile counts amp_env_step(AMP_PHASE_DONES) already produced. */
+int amp_reset_compact_tiles(const uint8_t* mask_dev, const int32_t* tile_counts_dev, int64_t num_envs,
+                            int64_t* ids_dev, int64_t* count_dev, amp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Discriminator style reward  (replaces the inference half of skrl's AMP agent: amp_state_preprocessor
+ * -> discriminator MLP -> style reward -> reward mix; shape agents/skrl_g1_walk_amp_cfg.yaml:31-39,
+ * scales :88-95, scaler :77-78.  skrl itself is third-party: parity unpinned)
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t in_dim;  /* K * D */
+  int32_t h1;      /* 1024 */
+  int32_t h2;      /* 512  */
+  int32_t reserved;
+  /* device, torch.nn.Linear layout: weight [out, in] row-major, bias [out]; COPIED at create */
+  const float* w1; const float* b1;
+  const float* w2; const float* b2;
+  const float* w3; const float* b3;
+} AmpDiscDesc;
+
+int amp_disc_create(const AmpDiscDesc* desc, amp_stream_t stream, AmpDisc** out);
+int amp_disc_destroy(AmpDisc* h);
+/* RunningStandardScaler statistics (fp64 on device, as skrl keeps them); NULL mean disables scaling. */
+int amp_disc_set_scaler(AmpDisc* h, const double* running_mean_dev, const double* running_variance_dev,
+                        float epsilon, float clip_threshold, amp_stream_t stream);
+int64_t amp_disc_workspace_bytes(const AmpDisc* h, int64_t rows);
+/* amp_obs_dev [rows, in_dim] (row stride in elements) -> logits [rows], style [rows] =
+ * -log(max(1 - sigmoid(logit), 1e-4)) * reward_scale, combined = task_w * task + style_w * style.
+ * logits / style / task / combined may be NULL. */
+int amp_disc_style_reward(const AmpDisc* h, const float* amp_obs_dev, int64_t rows, int64_t row_stride,
+                          float reward_scale, const float* task_reward_dev, float task_weight, float style_weight,
+                          float* logits_dev, float* style_dev, float* combined_dev, void* workspace_dev,
+                          amp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMP_ENGINE_H */
