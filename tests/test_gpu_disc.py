@@ -1,0 +1,86 @@
+"""GPU parity: discriminator style reward (fp32 MFMA) vs the oracle.  PARITY UNPINNED by the reference (skrl absent).
+
+Bar: |gpu - f64| <= |cpu32 - f64| + 1e-5 on logits (fp64 arbitration) and <= 1e-5 absolute on
+the style / combined reward vs the fp32 oracle.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from oracle import disc as odisc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _check(weights, x, mean, var, task, task_w, style_w, logit_scale=1.0):
+    from humanoid_amp_amd.engine import AmpDiscriminator
+
+    disc = AmpDiscriminator([(w.cuda(), b.cuda()) for w, b in weights], "cuda:0", running_mean=mean, running_variance=var,
+                            task_reward_weight=task_w, style_reward_weight=style_w)
+    out = disc.style_reward(x.cuda(), task.cuda() if task is not None else None, want_logits=True)
+    ref = odisc.forward(weights, x, mean, var, task=task, task_w=task_w, style_w=style_w)
+    with torch.no_grad():
+        xs = ref["scaled"]
+        lg64 = odisc.logits(weights, xs, dtype=torch.float64)
+    g = out["logits"].cpu().double()
+    err_gpu = (g - lg64).abs()
+    err_cpu = (ref["logits"].double() - lg64).abs()
+    assert float((err_gpu - err_cpu).max()) <= TOL * logit_scale, (float(err_gpu.max()), float(err_cpu.max()))
+    assert float(err_gpu.max()) <= 2e-5 * logit_scale
+    # d(style)/d(logit) <= reward_scale = 2: the style bar follows the logit bar
+    assert float((out["style"].cpu() - ref["style"]).abs().max()) <= TOL * logit_scale
+    if task is not None:
+        assert float((out["combined"].cpu() - ref["combined"]).abs().max()) <= TOL * logit_scale
+    return out
+
+
+def test_disc_golden_fixture():
+    fx = gu.golden("disc_k2_166")
+    w = odisc.make_weights(166, seed=int(fx["seed"]))
+    out = _check(w, torch.from_numpy(fx["amp_obs"]), torch.from_numpy(fx["running_mean"]), torch.from_numpy(fx["running_variance"]),
+                 torch.from_numpy(fx["task_reward"]), 0.5, 0.5)
+    assert np.max(np.abs(out["logits"].cpu().numpy() - fx["logits_f64"])) <= 2e-5
+    assert np.max(np.abs(out["style"].cpu().numpy() - fx["style_reward"])) <= TOL
+
+
+@pytest.mark.parametrize("in_dim,rows", [(166, 1), (166, 127), (166, 128), (166, 129), (162, 1000), (830, 513), (166, 4096)])
+def test_disc_shapes_and_ragged_rows(in_dim, rows):
+    g = torch.Generator().manual_seed(in_dim + rows)
+    w = odisc.make_weights(in_dim, seed=rows)
+    x = torch.randn(rows, in_dim, generator=g) * 2.0
+    mean = torch.randn(in_dim, generator=g, dtype=torch.float64) * 0.2
+    var = torch.rand(in_dim, generator=g, dtype=torch.float64) + 0.1
+    task = torch.randn(rows, 1, generator=g)
+    _check(w, x, mean, var, task, 0.3, 0.7)
+
+
+def test_disc_no_scaler_and_saturation():
+    """Without a scaler the input is used as is; huge logits hit the 1e-4 floor of the style reward."""
+    w = odisc.make_weights(166, seed=11)
+    w[2] = (w[2][0] * 400.0, w[2][1])
+    x = torch.randn(300, 166, generator=torch.Generator().manual_seed(1))
+    out = _check(w, x, None, None, None, 0.0, 1.0, logit_scale=400.0)  # logits are O(100) here: relative bar
+    assert float(out["style"].max()) <= -np.log(1e-4) * 2.0 + 1e-4
+    assert float(out["style"].min()) >= 0.0
+
+
+def test_disc_full_size_linearity_property():
+    """65 536 rows (BASELINE size): the pre-activation of layer 3 is linear in w3, so doubling (w3, b3) must
+    double every logit exactly (power-of-two scaling is exact in fp32)."""
+    from humanoid_amp_amd.engine import AmpDiscriminator
+
+    w = odisc.make_weights(166, seed=5)
+    x = torch.randn(65536, 166, generator=torch.Generator().manual_seed(2)).cuda()
+    a = AmpDiscriminator([(p.cuda(), q.cuda()) for p, q in w], "cuda:0").style_reward(x, want_logits=True)["logits"]
+    w2 = [w[0], w[1], (w[2][0] * 2.0, w[2][1] * 2.0)]
+    b = AmpDiscriminator([(p.cuda(), q.cuda()) for p, q in w2], "cuda:0").style_reward(x, want_logits=True)["logits"]
+    assert torch.equal(a * 2.0, b)
+    # and a row's logit does not depend on which tile / position it sits in
+    perm = torch.randperm(65536, generator=torch.Generator().manual_seed(3)).cuda()
+    c = AmpDiscriminator([(p.cuda(), q.cuda()) for p, q in w], "cuda:0").style_reward(x[perm].contiguous(), want_logits=True)["logits"]
+    assert torch.equal(c, a[perm])
+    sub = odisc.forward(w, x[:256].cpu())
+    assert float((a[:256].cpu() - sub["logits"]).abs().max()) <= 2e-5

@@ -1,0 +1,206 @@
+"""GPU parity: amp_env_step / reset compaction / reference-state reset vs the golden env-step sequences
+(outputs of the reference's own G1AmpEnv / HumanoidAmpEnv methods) and the oracle.
+
+Bars: done bits and reset ids bit-exact; AMP buffer / policy obs bit-exact except the 6 tangent|normal
+columns (<= 1e-5); rewards <= 1e-5 (29-term sums are ordered differently from ATen's vectorised sum).
+"""
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from test_oracle_golden import G1_ENV_CASES
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def cu(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def _cfg(case, fx, n_dof=29):
+    from humanoid_amp_amd.engine import EnvStepConfig
+
+    return EnvStepConfig(
+        n_dof=n_dof, num_amp_observations=case["K"], max_episode_length=int(fx["max_episode_length"]),
+        num_actor_observations=case["n_actor"], history_include_last_actions=case.get("hist_actions", True),
+        history_include_command=case.get("hist_command", True), rew_termination=case["rew_termination"],
+        rew_action_l2=case["rew_action_l2"], rew_joint_pos_limits=case["rew_joint_pos_limits"],
+        rew_joint_acc_l2=case["rew_joint_acc_l2"], rew_joint_vel_l2=case["rew_joint_vel_l2"], rew_track_vel=case["rew_track_vel"])
+
+
+def _tn_mask(width, D, nd):
+    """True for the tangent|normal columns of every D-wide frame in a row of `width` floats."""
+    c = np.arange(width) % D
+    return (c > 2 * nd) & (c <= 2 * nd + 6)
+
+
+@pytest.mark.parametrize("tag", list(G1_ENV_CASES))
+def test_g1_env_step_sequence(tag):
+    from humanoid_amp_amd.engine import EnvStepKernel, REWARD_TERMS
+    from humanoid_amp_amd import _native as nat
+    from humanoid_amp_amd.motions import MotionLoader
+
+    clipset, case = G1_ENV_CASES[tag]
+    fx = gu.golden(f"envstep_{tag}")
+    cfg = _cfg(case, fx)
+    N = fx["init_amp_observation_buffer"].shape[0]
+    ker = EnvStepKernel(cfg, N, "cuda:0", log_reward_terms=True)
+    ref, keys = int(fx["ref_body_index"]), fx["key_body_indexes"].tolist()
+    ml = MotionLoader(",".join(gu.clip_files(clipset)), "cuda:0")
+    m_ref = ml.get_body_index(["pelvis"])[0]
+    ml.set_obs_layout(fx["motion_dof_indexes"].tolist(), m_ref, ml.get_body_index(gu.G1_KEY_BODIES))
+    K, D, nd = cfg.num_amp_observations, cfg.amp_frame_size, 29
+    ker.amp_observation_buffer.copy_(cu(fx["init_amp_observation_buffer"]))
+    if cfg.num_actor_observations > 1:
+        ker.actor_obs_history_buffer.copy_(cu(fx["init_actor_obs_history_buffer"]))
+    lim = cu(fx["soft_joint_pos_limits"][0])  # [29, 2] shared by every env (stride 0)
+    origins = cu(fx["env_origins"])
+    for s in range(int(fx["n_steps"])):
+        p = f"s{s}_"
+        st = {k: cu(fx[p + "in_" + k]) for k in ("joint_pos", "joint_vel", "joint_acc", "body_pos_w", "body_quat_w",
+                                                  "body_lin_vel_w", "body_ang_vel_w", "actions", "episode_length_buf",
+                                                  "command_target_speed")}
+        # dones + reward on the post-physics state, Isaac-style AoS views (no gathers)
+        ker.launch(nat.AMP_PHASE_DONES | nat.AMP_PHASE_REWARD, joint_pos=st["joint_pos"], joint_vel=st["joint_vel"],
+                   joint_acc=st["joint_acc"], actions=st["actions"], root_pos=st["body_pos_w"][:, ref],
+                   root_quat=st["body_quat_w"][:, ref], root_lin_vel=st["body_lin_vel_w"][:, ref], soft_limits=lim,
+                   episode_length=st["episode_length_buf"], command=st["command_target_speed"])
+        assert np.array_equal(ker.died.cpu().numpy(), fx[p + "out_died"])
+        assert np.array_equal(ker.time_out.cpu().numpy(), fx[p + "out_time_out"])
+        np.testing.assert_allclose(ker.reward.cpu().numpy(), fx[p + "out_reward"], rtol=0, atol=TOL)
+        terms = ker.reward_terms.mean(dim=1).cpu().numpy()
+        for i, name in enumerate(REWARD_TERMS):
+            assert abs(float(terms[i]) - float(fx[p + "log_" + name])) <= TOL, name
+        ids, count = ker.compact_resets()
+        n_reset = int(count.item())
+        want_ids = fx[p + "out_reset_env_ids"]
+        assert n_reset == len(want_ids)
+        assert ids.dtype == torch.int64 and np.array_equal(ids[:n_reset].cpu().numpy(), want_ids)  # bit-exact
+        if n_reset:
+            rt, rid = fx[p + "reset_times"], fx[p + "reset_motion_ids"]
+            root, dpos, dvel = ml.reset_reference_state(rt, rid, env_ids=ids[:n_reset], env_origins=origins, z_lift=0.05)
+            want_root = fx[p + "out_reset_root_state"]
+            got_root = root.cpu().numpy()
+            assert np.array_equal(got_root[:, [0, 1, 2, 7, 8, 9, 10, 11, 12]], want_root[:, [0, 1, 2, 7, 8, 9, 10, 11, 12]])
+            assert np.max(np.abs(got_root[:, 3:7] - want_root[:, 3:7])) <= TOL
+            assert np.array_equal(dpos.cpu().numpy(), fx[p + "out_reset_dof_pos"])
+            assert np.array_equal(dvel.cpu().numpy(), fx[p + "out_reset_dof_vel"])
+            ml.collect_reference(rt, rid, K, out=ker.amp_observation_buffer, dst_rows=ids[:n_reset])
+            got_rows = ker.amp_observation_buffer[ids[:n_reset]].cpu().numpy().reshape(n_reset, -1)
+            want_rows = fx[p + "out_reset_amp_rows"].reshape(n_reset, -1)
+            tn = _tn_mask(K * D, D, nd)
+            assert np.array_equal(got_rows[:, ~tn], want_rows[:, ~tn]) and np.max(np.abs(got_rows - want_rows)) <= TOL
+        # observation inputs: post-reset sim state; the AMP buffer continues from OUR previous output, so put the
+        # reference's (bit-exact on all but the tangent|normal columns) buffer back to keep the sequence pinned
+        prev = fx["init_amp_observation_buffer"] if s == 0 else fx[f"s{s-1}_out_amp_obs"].reshape(N, K, D)
+        sim, amp_in = gu.obs_inputs(fx, s, prev)
+        ker.amp_observation_buffer.copy_(cu(amp_in))
+        if cfg.num_actor_observations > 1:
+            prev_h = fx["init_actor_obs_history_buffer"] if s == 0 else fx[f"s{s-1}_out_actor_obs_history_buffer"]
+            ker.actor_obs_history_buffer.copy_(cu(prev_h))
+            ker.just_reset_mask.copy_(cu(fx[p + "obsin_just_reset_mask"]))
+        g = {k: cu(v) for k, v in sim.items()}
+        ker.launch(nat.AMP_PHASE_OBS, joint_pos=g["joint_pos"], joint_vel=g["joint_vel"], root_pos=g["body_pos_w"][:, ref],
+                   root_quat=g["body_quat_w"][:, ref], root_lin_vel=g["body_lin_vel_w"][:, ref],
+                   root_ang_vel=g["body_ang_vel_w"][:, ref], body_pos=g["body_pos_w"], key_body_indexes=keys,
+                   command=cu(fx[p + "obsin_command_target_speed"]), last_actions=cu(fx[p + "obsin_last_actions"]))
+        got = ker.amp_observation_buffer.view(N, -1).cpu().numpy()
+        want = fx[p + "out_amp_obs"]
+        tn = _tn_mask(K * D, D, nd)
+        assert np.array_equal(got[:, ~tn], want[:, ~tn]), "AMP history"
+        assert np.max(np.abs(got - want)) <= TOL
+        pol, wpol = ker.policy_obs.cpu().numpy(), fx[p + "out_policy_obs"]
+        assert pol.shape == wpol.shape
+        assert np.max(np.abs(pol - wpol)) <= TOL
+        exact = np.abs(pol - wpol) == 0
+        assert exact.mean() > 0.9  # everything but tangent|normal (and their history copies) is bit-exact
+        if cfg.num_actor_observations > 1:
+            assert np.max(np.abs(ker.actor_obs_history_buffer.cpu().numpy() - fx[p + "out_actor_obs_history_buffer"])) <= TOL
+            assert not bool(ker.just_reset_mask.any())
+
+
+def test_humanoid_env_step_sequence():
+    from humanoid_amp_amd.engine import EnvStepConfig, EnvStepKernel
+    from humanoid_amp_amd import _native as nat
+
+    fx = gu.golden("envstep_humanoid3")
+    N = fx["init_amp_observation_buffer"].shape[0]
+    cfg = EnvStepConfig(n_dof=28, num_amp_observations=2, max_episode_length=int(fx["max_episode_length"]),
+                        use_last_actions=False, reward_mode=0)
+    ker = EnvStepKernel(cfg, N, "cuda:0")
+    assert ker.policy_obs_size == 81
+    ref, keys = int(fx["ref_body_index"]), fx["key_body_indexes"].tolist()
+    amp = fx["init_amp_observation_buffer"]
+    for s in range(2):
+        p = f"s{s}_"
+        g = {k: cu(fx[p + "in_" + k]) for k in ("joint_pos", "joint_vel", "body_pos_w", "body_quat_w", "body_lin_vel_w",
+                                                 "body_ang_vel_w", "episode_length_buf")}
+        ker.amp_observation_buffer.copy_(cu(amp))
+        ker.launch(nat.AMP_PHASE_ALL, joint_pos=g["joint_pos"], joint_vel=g["joint_vel"], root_pos=g["body_pos_w"][:, ref],
+                   root_quat=g["body_quat_w"][:, ref], root_lin_vel=g["body_lin_vel_w"][:, ref],
+                   root_ang_vel=g["body_ang_vel_w"][:, ref], body_pos=g["body_pos_w"], key_body_indexes=keys,
+                   episode_length=g["episode_length_buf"])
+        assert np.array_equal(ker.died.cpu().numpy(), fx[p + "out_died"])
+        assert np.array_equal(ker.time_out.cpu().numpy(), fx[p + "out_time_out"])
+        ids, count = ker.compact_resets()
+        assert np.array_equal(ids[: int(count)].cpu().numpy(), fx[p + "out_reset_env_ids"])
+        assert float((ker.reward - 1.0).abs().max()) == 0.0  # humanoid_amp_env.py:128-129
+        got, want = ker.amp_observation_buffer.view(N, -1).cpu().numpy(), fx[p + "out_amp_obs"]
+        assert np.max(np.abs(got - want)) <= TOL
+        tn = _tn_mask(162, 81, 28)
+        assert np.array_equal(got[:, ~tn], want[:, ~tn])
+        assert np.max(np.abs(ker.policy_obs.cpu().numpy() - fx[p + "out_policy_obs"])) <= TOL
+        amp = want.reshape(N, 2, 81)
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 255, 256, 257, 4096, 65536, 100003])
+@pytest.mark.parametrize("density", [0.0, 0.12, 1.0])
+def test_reset_compact_bit_exact(n, density):
+    """Bit-exact vs torch's nonzero for empty / ragged / all-set masks and sizes around every tile edge."""
+    from humanoid_amp_amd.engine import reset_compact
+
+    g = torch.Generator().manual_seed(n * 7 + int(density * 100))
+    mask = (torch.rand(n, generator=g) < density)
+    ids, count = reset_compact(mask.cuda())
+    want = mask.nonzero(as_tuple=False).squeeze(-1)
+    assert int(count) == want.numel()
+    assert torch.equal(ids[: want.numel()].cpu(), want)
+
+
+def test_env_step_full_size_properties():
+    """BASELINE size (65 536 envs, K=2): properties that need no oracle run: history shift is a pure row move,
+    compaction == nonzero, reset count == sum of tile counts, fused launch == three single-phase launches."""
+    from humanoid_amp_amd.engine import EnvStepConfig, EnvStepKernel
+    from humanoid_amp_amd import _native as nat
+
+    N, nd, K = 65536, 29, 2
+    g = torch.Generator(device="cuda").manual_seed(3)
+    r = lambda *s: torch.randn(*s, generator=g, device="cuda")  # noqa: E731
+    cfg = EnvStepConfig(n_dof=nd, num_amp_observations=K, max_episode_length=300, rew_termination=-1.0, rew_action_l2=-0.1,
+                        rew_joint_pos_limits=-10.0, rew_joint_acc_l2=-1e-6, rew_joint_vel_l2=-1e-3, rew_track_vel=1.0)
+    st = dict(joint_pos=r(N, nd), joint_vel=r(N, nd), joint_acc=r(N, nd) * 30, actions=r(N, nd) * 0.5,
+              root_pos=torch.cat([r(N, 2), torch.rand(N, 1, generator=g, device="cuda") * 0.6 + 0.35], 1).contiguous(),
+              root_quat=torch.nn.functional.normalize(r(N, 4), dim=1), root_lin_vel=r(N, 3), root_ang_vel=r(N, 3),
+              body_pos=r(N, 4, 3), key_body_indexes=[0, 1, 2, 3],
+              soft_limits=torch.tensor([[-1.41, 1.41]] * nd, device="cuda"),
+              episode_length=torch.randint(0, 300, (N,), generator=g, device="cuda"), command=r(N, 2), last_actions=r(N, nd))
+    a, b = EnvStepKernel(cfg, N, "cuda:0"), EnvStepKernel(cfg, N, "cuda:0")
+    init = r(N, K, cfg.amp_frame_size)
+    a.amp_observation_buffer.copy_(init)
+    b.amp_observation_buffer.copy_(init)
+    a.launch(nat.AMP_PHASE_ALL, **st)
+    for ph in (nat.AMP_PHASE_DONES, nat.AMP_PHASE_REWARD, nat.AMP_PHASE_OBS):
+        b.launch(ph, **st)
+    for name in ("amp_observation_buffer", "policy_obs", "reward", "died", "time_out", "reset_mask", "reset_tile_counts"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert torch.equal(a.amp_observation_buffer[:, 1], init[:, 0])           # slot 1 <- old slot 0
+    assert torch.equal(a.amp_observation_buffer[:, 0, :nd], st["joint_pos"])  # slot 0 <- new frame
+    assert torch.equal(a.policy_obs[:, 71:100], st["last_actions"]) and torch.equal(a.policy_obs[:, 100:], st["command"])
+    ids, count = a.compact_resets()
+    want = a.reset_mask.nonzero().squeeze(-1)
+    assert int(count) == want.numel() == int(a.reset_tile_counts.sum()) and torch.equal(ids[: want.numel()], want)
+    assert torch.equal(a.reset_mask, a.died | a.time_out)
+    assert 0.05 < float(a.died.float().mean()) < 0.4
