@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- AMP obs + motion-sample + reward env-steps/s on MI355X (BASELINE.json's metric).
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one env-step of the hot path for every env of the shard (humanoid_amp_amd/workloads.py), inputs
+resident in HBM.  One process per GPU; envs shard trivially (weak scaling: --envs per GPU is fixed), the only
+collective is the RCCL all-gather of the AMP replay minibatch every --rollouts steps (agents/*.yaml:65,91).
+Rank 0 prints ONE JSON line.  The CPU oracle (oracle/) is used only for the bounded `cpu_baseline` leg.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
+DOMINANT_KERNEL = "disc_gemm_kernel<1>"  # layer 2 of the discriminator: 2*M*1024*512 of the 2*M*(in*1024+1024*512+512) FLOPs
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU (weak scaling)")
+    ap.add_argument("--workload", default="g1_walk", choices=["g1_walk", "g1_dance", "humanoid3"])
+    ap.add_argument("--rollouts", type=int, default=16, help="steps between AMP-replay all-gathers (N > 1 only)")
+    ap.add_argument("--replay-minibatch", type=int, default=4096, help="rows per rank in the all-gather")
+    ap.add_argument("--minibatches", type=int, default=12, help="all-gathers per agent update (learning_epochs x mini_batches)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-envs", type=int, default=0, help="envs of the CPU sample (0 = same as --envs)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the 4096-env secondary measurement")
+    return ap.parse_args()
+
+
+def timed_steps(hot, steps, warmup, world, collective):
+    import torch.distributed as dist
+
+    for i in range(warmup):
+        hot.step()
+        if collective and (i + 1) % collective["every"] == 0:
+            collective["fn"]()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        hot.step()
+        if collective and (i + 1) % collective["every"] == 0:
+            collective["fn"]()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def cpu_baseline(spec, n_envs, seed, target_seconds=12.0, probe=True):
+    """The oracle (CPU restatement of the reference's torch path) timed on this box's host cores: same unit of
+    work, same synthetic inputs; bounded to ~target_seconds."""
+    if probe and n_envs > 4096:
+        # bounded sample: probe at 4096 envs, then take the largest power-of-two shard (<= n_envs) whose ~8 steps fit
+        small = cpu_baseline(spec, 4096, seed, target_seconds=2.0, probe=False)
+        per_env = small["ms_per_step"] * 1e-3 / 4096
+        fit = target_seconds / 8.0 / per_env
+        n = 4096
+        while n * 2 <= min(n_envs, fit):
+            n *= 2
+        n_envs = n
+
+    from humanoid_amp_amd.robots import G1_JOINT_NAMES, G1_KEY_BODY_NAMES, HUMANOID_KEY_BODY_NAMES
+    from humanoid_amp_amd.synthetic import make_state
+    from humanoid_amp_amd.workloads import G1_REWARDS, make_disc_weights
+    from humanoid_amp_amd.motions import MOTIONS_DIR
+    from oracle import disc as odisc
+    from oracle import env as oenv
+    from oracle import motion as om
+
+    # a one-GPU box owns a 16-core share of the host (more threads only oversubscribe it)
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
+    torch.set_num_threads(cores)
+    mt = om.load_tables([os.path.join(MOTIONS_DIR, c + ".npz") for c in spec.clips])
+    g1 = spec.robot == "g1"
+    perm = [mt.dof_names.index(n) for n in G1_JOINT_NAMES] if g1 else list(range(len(mt.dof_names)))
+    keys = [mt.body_names.index(n) for n in (G1_KEY_BODY_NAMES if g1 else HUMANOID_KEY_BODY_NAMES)]
+    ref = mt.body_names.index(spec.reference_body)
+    st = make_state(n_envs, spec.n_dof, spec.max_episode_length, mt.durations, seed, "cpu")
+    times, ids = st["motion_times"].numpy(), st["motion_ids"].numpy()
+    K, D = spec.K, spec.D
+    weights = make_disc_weights(K * D, seed=0)
+    mean, var = torch.zeros(K * D, dtype=torch.float64), torch.ones(K * D, dtype=torch.float64)
+    buf = oenv.collect_reference(mt, times, ids, K, perm, ref, keys).view(n_envs, K, D).clone()
+    lim = st["soft_limits"].unsqueeze(0).expand(n_envs, -1, -1)
+    cfg = dict(G1_REWARDS)
+
+    def step():
+        with torch.no_grad():
+            expert = oenv.collect_reference(mt, times, ids, K, perm, ref, keys)
+            died, tout = oenv.dones(st["episode_length"], spec.max_episode_length, st["root_pos"][:, 2], 0.5)
+            if g1:
+                task, _ = oenv.g1_task_reward(cfg, st["root_lin_vel"], st["root_quat"], st["command"], died, st["actions"],
+                                              st["joint_pos"], lim, st["joint_acc"], st["joint_vel"])
+            else:
+                task = torch.ones(n_envs)
+            reset_ids = oenv.reset_env_ids(died, tout)
+            obs = oenv.compute_obs(st["joint_pos"], st["joint_vel"], st["root_pos"], st["root_quat"], st["root_lin_vel"],
+                                   st["root_ang_vel"], st["body_pos"])
+            amp = oenv.shift_history(buf, obs)
+            pol = oenv.actor_observation(obs, st["last_actions"], st["command"], use_command=True) if g1 else obs
+            out = odisc.forward(weights, amp, mean, var, task=task.unsqueeze(-1), task_w=spec.task_weight,
+                                style_w=spec.style_weight)
+        return expert, reset_ids, pol, out
+
+    step()  # warm-up (first touch, thread pool)
+    t0 = time.perf_counter()
+    step()
+    one = time.perf_counter() - t0
+    reps = int(max(3, min(20, target_seconds / max(one, 1e-6))))
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        step()
+        ts.append(time.perf_counter() - t0)
+    med = sorted(ts)[len(ts) // 2]
+    return {"value": n_envs / med, "unit": "env-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_envs} envs x {reps} steps of the oracle (torch-CPU restatement), median; {spec.name}",
+            "ms_per_step": med * 1e3}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+
+    import humanoid_amp_amd  # noqa: F401  (fails loudly if libamp_engine.so is missing)
+    from humanoid_amp_amd import _native as nat
+    from humanoid_amp_amd.distributed import ReplayAllGather
+    from humanoid_amp_amd.workloads import WORKLOADS, HotPath, algorithmic_bytes_per_env_step, disc_flops_per_row
+
+    spec = WORKLOADS[args.workload]
+    hot = HotPath(spec, args.envs, device, seed=1234 + rank)
+    collective = None
+    if world > 1:
+        ag = ReplayAllGather(hot.kernel.amp_observation_buffer.view(args.envs, -1), args.replay_minibatch, seed=rank)
+        collective = {"every": args.rollouts, "fn": lambda: [ag() for _ in range(args.minibatches)]}
+
+    # ---- timed region: exactly --steps steps, the dominant kernel bracketed by HIP events on its stream --------
+    with nat.KernelTrace(capacity=args.steps + args.warmup + 8, kernel_filter=DOMINANT_KERNEL) as tr:
+        dt = timed_steps(hot, args.steps, args.warmup, world, collective)
+    recs = tr.records()[-args.steps:]
+    gemm2_ms = sum(ms for _, ms in recs) / max(len(recs), 1)
+    value = args.envs * world * args.steps / dt
+
+    # ---- per-kernel picture of one step (all kernels traced; outside the timed region) ---------------------------
+    with nat.KernelTrace(capacity=16 * 8) as tr_all:
+        for _ in range(8):
+            hot.step()
+    per_kernel = {k: round(t / c * 1e3, 2) for k, (c, t) in tr_all.summary().items()}  # us per launch
+
+    out = None
+    if rank == 0:
+        flops2 = 2.0 * args.envs * 1024 * 512 + 2.0 * args.envs * 512   # layer 2 + the fused 512 -> 1 dot
+        achieved = flops2 / (gemm2_ms * 1e-3) / 1e12
+        hbm_kernels = ("collect_reference_kernel", "env_step_kernel", "compact_scatter_kernel")
+        hbm_us = sum(per_kernel.get(k, 0.0) for k in hbm_kernels)
+        alg_bytes = algorithmic_bytes_per_env_step(spec) * args.envs
+        out = {
+            "metric": "AMP obs+motion-sample+reward env-steps/s", "value": value, "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{spec.description}, {args.envs} envs per GPU, synthetic joint states, discriminator "
+                                   f"[{spec.K * spec.D},1024,512,1] seed-0 init", "envs_per_gpu": args.envs,
+                       "global_envs": args.envs * world, "parallelism": f"env-shard x{world}",
+                       "collective": (f"RCCL all-gather [{args.replay_minibatch},{spec.K * spec.D}] f32 per rank x "
+                                      f"{args.minibatches} every {args.rollouts} steps") if world > 1 else "none"},
+            "roofline": {"bound": "mfma", "kernel": DOMINANT_KERNEL, "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "avg_launch_ms": gemm2_ms, "launches_timed": len(recs), "flops_per_launch": flops2},
+            "roofline_hbm": {"bound": "hbm", "kernels": list(hbm_kernels), "achieved": alg_bytes / (hbm_us * 1e-6) / 1e9 if hbm_us else None,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (alg_bytes / (hbm_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if hbm_us else None,
+                             "bytes_per_env_step": algorithmic_bytes_per_env_step(spec), "us": hbm_us},
+            "kernel_us": per_kernel,
+            "disc_flops_per_env_step": disc_flops_per_row(spec.K * spec.D),
+        }
+
+    # ---- secondary point of the metric: 4096 envs per GPU -------------------------------------------------------
+    if not args.no_secondary and args.envs != 4096:
+        del hot
+        torch.cuda.empty_cache()
+        hot_s = HotPath(spec, 4096, device, seed=99 + rank)
+        dts = timed_steps(hot_s, max(args.steps, 50), args.warmup, world, None)
+        if rank == 0:
+            out["envs_4096"] = {"value": 4096 * world * max(args.steps, 50) / dts, "unit": "env-steps/s",
+                                "ms_per_step": dts / max(args.steps, 50) * 1e3, "envs_per_gpu": 4096}
+        del hot_s
+
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(spec, args.cpu_envs or args.envs, seed=1234)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

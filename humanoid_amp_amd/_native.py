@@ -84,6 +84,10 @@ SIGNATURES = {
     "amp_abi_version": (C.c_int, []),
     "amp_last_error": (C.c_char_p, []),
     "amp_device_name": (C.c_int, [C.c_char_p, _i64]),
+    "amp_trace_begin": (C.c_int, [_i64, C.c_char_p]),
+    "amp_trace_end": (C.c_int, []),
+    "amp_trace_count": (_i64, []),
+    "amp_trace_get": (C.c_int, [_i64, C.c_char_p, _i64, C.POINTER(C.c_float)]),
     "amp_motion_create": (C.c_int, [C.POINTER(AmpMotionDesc), C.POINTER(_vp)]),
     "amp_motion_destroy": (C.c_int, [_vp]),
     "amp_motion_set_obs_layout": (C.c_int, [_vp, C.POINTER(_i32), _i32, C.POINTER(_i32), _i32, _vp]),
@@ -171,3 +175,38 @@ def strided_view(t: torch.Tensor, inner: int, name: str):
     if t.dim() != 2 or t.shape[1] != inner or (inner > 1 and t.stride(1) != 1):
         raise AmpEngineError(f"{name} must be a [N, {inner}] view with a contiguous last dim, got {tuple(t.shape)} / {t.stride()}")
     return C.c_void_p(t.data_ptr()), int(t.stride(0))
+
+
+class KernelTrace:
+    """Context manager around the engine's HIP-event tracer: per-kernel durations of everything launched inside.
+
+    >>> with KernelTrace(capacity=4096, kernel_filter="disc_gemm_kernel<1>") as tr: ...
+    >>> tr.summary()   # {name: (calls, total_ms)} -- synchronises the current device first
+    """
+
+    def __init__(self, capacity: int = 4096, kernel_filter: str | None = None):
+        self.capacity, self.filter = int(capacity), kernel_filter
+
+    def __enter__(self):
+        check(load().amp_trace_begin(self.capacity, self.filter.encode() if self.filter else None), "amp_trace_begin")
+        return self
+
+    def __exit__(self, *exc):
+        load().amp_trace_end()
+        return False
+
+    def records(self):
+        torch.cuda.synchronize()
+        lib, out = load(), []
+        name, ms = C.create_string_buffer(64), C.c_float()
+        for i in range(int(lib.amp_trace_count())):
+            check(lib.amp_trace_get(i, name, 64, C.byref(ms)), "amp_trace_get")
+            out.append((name.value.decode(), float(ms.value)))
+        return out
+
+    def summary(self):
+        agg = {}
+        for name, ms in self.records():
+            c, t = agg.get(name, (0, 0.0))
+            agg[name] = (c + 1, t + ms)
+        return agg

@@ -38,6 +38,19 @@ inline int launch_status(const char* what) {
   return AMP_OK;
 }
 
+// ---- kernel tracer (core.hip) ----------------------------------------------------------------------
+bool trace_enabled();
+int trace_open(const char* kernel, hipStream_t st);  // -> record index or -1
+void trace_close(int rec, hipStream_t st);
+struct TraceScope {
+  int rec;
+  hipStream_t st;
+  TraceScope(const char* kernel, hipStream_t s) : rec(trace_enabled() ? trace_open(kernel, s) : -1), st(s) {}
+  ~TraceScope() {
+    if (rec >= 0) trace_close(rec, st);
+  }
+};
+
 constexpr int kWave = 64;     // gfx950 wavefront
 constexpr int kBlock = 256;   // 4 waves, one per SIMD
 constexpr int kMaxKey = 8;

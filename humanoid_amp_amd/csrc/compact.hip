@@ -78,7 +78,9 @@ int amp_reset_compact_tiles(const uint8_t* mask, const int32_t* counts, int64_t 
   AMP_REQUIRE(mask && counts && ids, "amp_reset_compact: null buffer");
   const int64_t n_tiles = (N + kTile - 1) / kTile;
   const unsigned grid = (unsigned)((n_tiles + 3) / 4);
-  compact_scatter_kernel<<<grid, kBlock, 0, (hipStream_t)stream>>>(mask, counts, N, n_tiles, ids, count);
+  { amp::TraceScope trace__("compact_scatter_kernel", (hipStream_t)stream);
+    compact_scatter_kernel<<<grid, kBlock, 0, (hipStream_t)stream>>>(mask, counts, N, n_tiles, ids, count);
+  }
   return launch_status("compact_scatter_kernel");
 }
 
@@ -87,7 +89,9 @@ int amp_reset_compact(const uint8_t* mask, int64_t N, int64_t* ids, int64_t* cou
   if (N > 0) {
     AMP_REQUIRE(mask && workspace, "amp_reset_compact: null buffer");
     const unsigned grid = (unsigned)((N + kBlock - 1) / kBlock);
-    tile_count_kernel<<<grid, kBlock, 0, (hipStream_t)stream>>>(mask, N, (int32_t*)workspace);
+    { amp::TraceScope trace__("tile_count_kernel", (hipStream_t)stream);
+      tile_count_kernel<<<grid, kBlock, 0, (hipStream_t)stream>>>(mask, N, (int32_t*)workspace);
+    }
     int rc = launch_status("tile_count_kernel");
     if (rc != AMP_OK) return rc;
   }

@@ -2,6 +2,8 @@
 #include "amp_common.hpp"
 
 #include <cstring>
+#include <string>
+#include <vector>
 
 namespace amp {
 char* last_error_buf() {
@@ -10,7 +12,70 @@ char* last_error_buf() {
 }
 }  // namespace amp
 
+namespace amp {
+namespace {
+struct TraceRec {
+  const char* name;
+  hipEvent_t start, stop;
+};
+std::vector<TraceRec> g_recs;   // capacity fixed at amp_trace_begin: events are created there, never in a launch
+int64_t g_used = 0;
+bool g_on = false;
+std::string g_filter;
+}  // namespace
+
+bool trace_enabled() { return g_on; }
+
+int trace_open(const char* kernel, hipStream_t st) {
+  if (!g_on || g_used >= (int64_t)g_recs.size()) return -1;
+  if (!g_filter.empty() && std::strstr(kernel, g_filter.c_str()) == nullptr) return -1;
+  const int i = (int)g_used++;
+  g_recs[i].name = kernel;
+  (void)hipEventRecord(g_recs[i].start, st);
+  return i;
+}
+
+void trace_close(int rec, hipStream_t st) { (void)hipEventRecord(g_recs[rec].stop, st); }
+}  // namespace amp
+
 extern "C" {
+
+int amp_trace_begin(int64_t capacity, const char* filter) {
+  using namespace amp;
+  if (capacity < 0 || capacity > (1 << 20)) return fail(AMP_ERR_INVALID, "amp_trace_begin: capacity out of range");
+  g_on = false;
+  for (auto& r : g_recs) {
+    (void)hipEventDestroy(r.start);
+    (void)hipEventDestroy(r.stop);
+  }
+  g_recs.clear();
+  g_used = 0;
+  g_recs.resize((size_t)capacity);
+  for (auto& r : g_recs) {
+    r.name = "";
+    if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess)
+      return fail(AMP_ERR_HIP, "amp_trace_begin: hipEventCreate failed");
+  }
+  g_filter = filter ? filter : "";
+  g_on = capacity > 0;
+  return AMP_OK;
+}
+
+int amp_trace_end(void) {
+  amp::g_on = false;
+  return AMP_OK;
+}
+
+int64_t amp_trace_count(void) { return amp::g_used; }
+
+int amp_trace_get(int64_t i, char* name_buf, int64_t name_len, float* ms) {
+  using namespace amp;
+  if (i < 0 || i >= g_used || !ms) return fail(AMP_ERR_INVALID, "amp_trace_get: bad index");
+  hipError_t e = hipEventElapsedTime(ms, g_recs[i].start, g_recs[i].stop);
+  if (e != hipSuccess) return fail(AMP_ERR_HIP, "amp_trace_get: %s", hipGetErrorString(e));
+  if (name_buf && name_len > 0) std::snprintf(name_buf, (size_t)name_len, "%s", g_recs[i].name);
+  return AMP_OK;
+}
 
 int amp_abi_version(void) { return AMP_ABI_VERSION; }
 

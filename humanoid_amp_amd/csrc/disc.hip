@@ -343,7 +343,9 @@ int amp_disc_create(const AmpDiscDesc* d, amp_stream_t stream, AmpDisc** out) {
     return fail(AMP_ERR_HIP, "amp_disc_create: %s", hipGetErrorString(e));
   }
   const int64_t total = (int64_t)h->h1 * h->k1p;
-  disc_pad_rows_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(d->w1, h->h1, h->in_dim, h->k1p, h->w1p);
+  { amp::TraceScope trace__("disc_pad_rows_kernel", st);
+    disc_pad_rows_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(d->w1, h->h1, h->in_dim, h->k1p, h->w1p);
+  }
   int rc = launch_status("disc_pad_rows_kernel");
   if (rc == AMP_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail(AMP_ERR_HIP, "amp_disc_create: stream sync failed");
   if (rc != AMP_OK) {
@@ -361,7 +363,9 @@ int amp_disc_set_scaler(AmpDisc* h, const double* mean, const double* var, float
     return AMP_OK;
   }
   AMP_REQUIRE(var, "amp_disc_set_scaler: running_variance is null");
-  disc_scaler_kernel<<<(h->k1p + 255) / 256, 256, 0, (hipStream_t)stream>>>(mean, var, h->in_dim, h->k1p, eps, h->mean, h->den);
+  { amp::TraceScope trace__("disc_scaler_kernel", (hipStream_t)stream);
+    disc_scaler_kernel<<<(h->k1p + 255) / 256, 256, 0, (hipStream_t)stream>>>(mean, var, h->in_dim, h->k1p, eps, h->mean, h->den);
+  }
   int rc = launch_status("disc_scaler_kernel");
   if (rc != AMP_OK) return rc;
   h->clip = clip;
@@ -397,7 +401,9 @@ int amp_disc_style_reward(const AmpDisc* h, const float* x, int64_t rows, int64_
   g1.mean = h->has_scaler ? h->mean : nullptr; g1.den = h->den; g1.clip = h->clip;
   g1.C = H1; g1.ldc = h->h1; g1.n_tiles = h->h1 / BN; g1.m_tiles = m_tiles;
   const unsigned grid1 = (unsigned)(((int64_t)m_tiles * g1.n_tiles + 7) / 8 * 8);
-  disc_gemm_kernel<0><<<grid1, kBlock, 0, st>>>(g1);
+  { amp::TraceScope trace__("disc_gemm_kernel<0>", st);
+    disc_gemm_kernel<0><<<grid1, kBlock, 0, st>>>(g1);
+  }
   int rc = launch_status("disc_gemm_kernel<0>");
   if (rc != AMP_OK) return rc;
 
@@ -406,12 +412,16 @@ int amp_disc_style_reward(const AmpDisc* h, const float* x, int64_t rows, int64_
   g2.W = h->w2; g2.Kp = h->h1; g2.bias = h->b2; g2.N = h->h2;
   g2.w3 = h->w3; g2.partial = partial; g2.n_tiles = h->h2 / BN; g2.m_tiles = m_tiles;
   const unsigned grid2 = (unsigned)(((int64_t)m_tiles * g2.n_tiles + 7) / 8 * 8);
-  disc_gemm_kernel<1><<<grid2, kBlock, 0, st>>>(g2);
+  { amp::TraceScope trace__("disc_gemm_kernel<1>", st);
+    disc_gemm_kernel<1><<<grid2, kBlock, 0, st>>>(g2);
+  }
   rc = launch_status("disc_gemm_kernel<1>");
   if (rc != AMP_OK) return rc;
 
-  disc_finalize_kernel<<<(unsigned)((rows + kBlock - 1) / kBlock), kBlock, 0, st>>>(partial, g2.n_tiles, h->b3, rows, scale, task,
+  { amp::TraceScope trace__("disc_finalize_kernel", st);
+    disc_finalize_kernel<<<(unsigned)((rows + kBlock - 1) / kBlock), kBlock, 0, st>>>(partial, g2.n_tiles, h->b3, rows, scale, task,
                                                                                    task_w, style_w, logits, style, combined);
+  }
   return launch_status("disc_finalize_kernel");
 }
 

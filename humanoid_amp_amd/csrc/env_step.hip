@@ -336,7 +336,9 @@ int amp_env_step(const AmpEnvCfg* cfg, const AmpSimState* st, const AmpEnvBuffer
                      sizeof(int) * kTileEnvs;
   AMP_REQUIRE(lds <= 64 * 1024, "amp_env_step: observation tile needs %zu B of LDS (> 64 KiB)", lds);
   const unsigned grid = (unsigned)((N + kTileEnvs - 1) / kTileEnvs);
-  env_step_kernel<<<grid, kBlock, lds, (hipStream_t)stream>>>(p, *st, *bf, N);
+  { amp::TraceScope trace__("env_step_kernel", (hipStream_t)stream);
+    env_step_kernel<<<grid, kBlock, lds, (hipStream_t)stream>>>(p, *st, *bf, N);
+  }
   return launch_status("env_step_kernel");
 }
 

@@ -426,8 +426,10 @@ int amp_motion_set_obs_layout(AmpMotion* h, const int32_t* dof_perm, int32_t ref
   h->v.D = D;
   h->v.hot = h->d_hot;
   const int64_t total = h->n_frames * D;
-  build_hot_kernel<<<grid_for(total, kBlock), kBlock, 0, st>>>(h->v, h->n_frames, h->d_perm, ref_body, h->d_perm + h->v.n_dof,
+  { amp::TraceScope trace__("build_hot_kernel", st);
+    build_hot_kernel<<<grid_for(total, kBlock), kBlock, 0, st>>>(h->v, h->n_frames, h->d_perm, ref_body, h->d_perm + h->v.n_dof,
                                                               h->d_hot);
+  }
   int rc = launch_status("build_hot_kernel");
   if (rc != AMP_OK) return rc;
   h->has_layout = true;
@@ -440,7 +442,9 @@ int amp_motion_frame_blend(const AmpMotion* h, const double* times, const int64_
   AMP_REQUIRE(n >= 0, "amp_motion_frame_blend: negative n");
   if (n == 0) return AMP_OK;
   AMP_REQUIRE(times && i0 && i1 && blend, "amp_motion_frame_blend: null buffer");
-  frame_blend_kernel<<<grid_for(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(h->v.clips, times, ids, n, i0, i1, blend);
+  { amp::TraceScope trace__("frame_blend_kernel", (hipStream_t)stream);
+    frame_blend_kernel<<<grid_for(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(h->v.clips, times, ids, n, i0, i1, blend);
+  }
   return launch_status("frame_blend_kernel");
 }
 
@@ -453,7 +457,9 @@ int amp_motion_sample(const AmpMotion* h, const double* times, const int64_t* id
   AMP_REQUIRE(n * (int64_t)h->v.n_bodies * 4 < ((int64_t)1 << 40), "amp_motion_sample: n too large");
   AMP_REQUIRE(br == nullptr || ((uintptr_t)br % 16 == 0 && (uintptr_t)h->v.body_rot % 16 == 0),
               "amp_motion_sample: quaternion buffers must be 16-byte aligned");
-  sample_kernel<<<grid_for(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(h->v, times, ids, n, dp, dv, bp, br, bl, ba);
+  { amp::TraceScope trace__("sample_kernel", (hipStream_t)stream);
+    sample_kernel<<<grid_for(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(h->v, times, ids, n, dp, dv, bp, br, bl, ba);
+  }
   return launch_status("sample_kernel");
 }
 
@@ -464,7 +470,9 @@ int amp_collect_reference(const AmpMotion* h, const double* times, const int64_t
   AMP_REQUIRE(n >= 0 && K >= 1, "amp_collect_reference: need n >= 0 and K >= 1");
   if (n == 0) return AMP_OK;
   AMP_REQUIRE(times && out, "amp_collect_reference: null buffer");
-  collect_reference_kernel<<<grid_for(n * K, kBlock), kBlock, 0, (hipStream_t)stream>>>(h->v, times, ids, n, K, out, dst_rows);
+  { amp::TraceScope trace__("collect_reference_kernel", (hipStream_t)stream);
+    collect_reference_kernel<<<grid_for(n * K, kBlock), kBlock, 0, (hipStream_t)stream>>>(h->v, times, ids, n, K, out, dst_rows);
+  }
   return launch_status("collect_reference_kernel");
 }
 
@@ -475,8 +483,10 @@ int amp_reset_reference_state(const AmpMotion* h, const double* times, const int
   AMP_REQUIRE(n >= 0, "amp_reset_reference_state: negative n");
   if (n == 0) return AMP_OK;
   AMP_REQUIRE(times, "amp_reset_reference_state: times is null");
-  reset_state_kernel<<<grid_for(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(h->v, times, ids, env_ids, n, origins, z_lift,
+  { amp::TraceScope trace__("reset_state_kernel", (hipStream_t)stream);
+    reset_state_kernel<<<grid_for(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(h->v, times, ids, env_ids, n, origins, z_lift,
                                                                              root, dp, dv);
+  }
   return launch_status("reset_state_kernel");
 }
 

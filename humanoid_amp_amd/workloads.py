@@ -1,0 +1,136 @@
+"""The BASELINE.json workloads as runnable objects: one env-step of the AMP hot path on one env shard.
+
+One env-step, per env:
+  1. motion-sample: (t, clip) -> K expert frames -> expert AMP obs [K*D]        (amp_collect_reference)
+  2. sim AMP obs + K-history shift + policy obs                                  (amp_env_step, OBS)
+  3. done mask + ascending reset-id compaction                                   (amp_env_step DONES + amp_reset_compact_tiles)
+  4. task reward (G1; humanoid: constant 1)                                      (amp_env_step, REWARD)
+  5. scaler + discriminator MLP + style reward + reward mix                      (amp_disc_style_reward)
+Physics is excluded (closed PhysX step in the reference).
+"""
+
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from .engine import AmpDiscriminator, EnvStepConfig, EnvStepKernel
+from .motions import MOTIONS_DIR, MotionLoader
+from .robots import G1_JOINT_NAMES, G1_KEY_BODY_NAMES, HUMANOID_KEY_BODY_NAMES
+from .synthetic import make_state
+
+# reward scales of the self-consistent G1 config family (g1_amp_env_cfg.py:86-91)
+G1_REWARDS = dict(rew_termination=-1.0, rew_action_l2=-0.1, rew_joint_pos_limits=-10.0, rew_joint_acc_l2=-1.0e-06,
+                  rew_joint_vel_l2=-0.001, rew_track_vel=1.0)
+
+
+@dataclass(frozen=True)
+class WorkloadSpec:
+    name: str
+    description: str
+    clips: tuple
+    n_dof: int
+    K: int
+    robot: str               # "g1" | "humanoid"
+    reference_body: str
+    episode_length_s: float
+    decimation: int
+    task_weight: float       # agents/*.yaml task_reward_weight
+    style_weight: float
+
+    @property
+    def D(self) -> int:
+        return 2 * self.n_dof + 25
+
+    @property
+    def max_episode_length(self) -> int:
+        import math
+
+        return math.ceil(self.episode_length_s / ((1.0 / 60.0) * self.decimation))
+
+
+WORKLOADS = {
+    # BASELINE.json configs[1] / configs[4]: "G1-AMP-Walk" (29 DoF in every clip; "23-DoF" is prose only)
+    "g1_walk": WorkloadSpec("g1_walk", "G1-AMP-Walk, G1_walk.npz (399 frames, 11 bodies), 29-DoF, K=2, D=83", ("G1_walk",),
+                            29, 2, "g1", "pelvis", 10.0, 2, 0.0, 1.0),
+    # configs[2]: long multi-phase clip, K = 10
+    "g1_dance": WorkloadSpec("g1_dance", "G1-AMP-Dance, G1_dance.npz (601 frames, 39 bodies), 29-DoF, K=10, D=83", ("G1_dance",),
+                             29, 10, "g1", "pelvis", 10.0, 1, 1.0, 1.0),
+    # configs[3]: walk+run+dance multi-clip blend, 28 DoF
+    "humanoid3": WorkloadSpec("humanoid3", "Humanoid-AMP walk+run+dance 3-clip table (1138 frames, 15 bodies), 28-DoF, K=2, D=81",
+                              ("humanoid_walk", "humanoid_run", "humanoid_dance"), 28, 2, "humanoid", "torso", 10.0, 2, 0.0, 1.0),
+}
+
+
+def algorithmic_bytes_per_env_step(spec: WorkloadSpec) -> int:
+    """HBM bytes of a fused ideal, exactly SURVEY.md section 8d's accounting (2 682 B at K=2, 10 650 B at K=10 for
+    G1; 2 310 B humanoid): the motion tables are cache-resident and excluded."""
+    D, K, nd = spec.D, spec.K, spec.n_dof
+    g1 = spec.robot == "g1"
+    reads = D * 4 + (2 * nd * 4 + 8 if g1 else 0) + 8 + 16 + (K - 1) * D * 4
+    policy = ((D - 12) + nd + 2) * 4 if g1 else D * 4
+    writes = K * D * 4 + K * D * 4 + policy + 18
+    return reads + writes
+
+
+def disc_flops_per_row(in_dim: int, h1: int = 1024, h2: int = 512) -> int:
+    return 2 * (in_dim * h1 + h1 * h2 + h2)
+
+
+class HotPath:
+    """All device state of one env shard + ``step()`` = one env-step of the hot path."""
+
+    def __init__(self, spec: WorkloadSpec, num_envs: int, device, seed: int = 0, log_reward_terms: bool = False):
+        self.spec, self.num_envs = spec, int(num_envs)
+        self.device = nat.require_gpu(device)
+        files = ",".join(os.path.join(MOTIONS_DIR, c + ".npz") for c in spec.clips)
+        self.motion = MotionLoader(files, self.device)
+        ml = self.motion
+        if spec.robot == "g1":
+            perm, keys = ml.get_dof_index(G1_JOINT_NAMES), ml.get_body_index(G1_KEY_BODY_NAMES)
+        else:
+            perm, keys = list(range(ml.num_dofs)), ml.get_body_index(HUMANOID_KEY_BODY_NAMES)
+        D = ml.set_obs_layout(perm, ml.get_body_index([spec.reference_body])[0], keys)
+        assert D == spec.D
+        rewards = G1_REWARDS if spec.robot == "g1" else {}
+        self.cfg = EnvStepConfig(n_dof=spec.n_dof, num_amp_observations=spec.K, max_episode_length=spec.max_episode_length,
+                                 use_last_actions=spec.robot == "g1", reward_mode=1 if spec.robot == "g1" else 0, **rewards)
+        self.kernel = EnvStepKernel(self.cfg, self.num_envs, self.device, log_reward_terms=log_reward_terms)
+        self.state = make_state(self.num_envs, spec.n_dof, spec.max_episode_length, ml.durations, seed, self.device)
+        self.expert_obs = torch.zeros((self.num_envs, spec.K * D), device=self.device)
+        # discriminator: torch.nn.Linear default init under torch.manual_seed(0); scaler mean 0 / var 1
+        self.disc_weights = make_disc_weights(spec.K * D, seed=0)
+        self.disc = AmpDiscriminator(self.disc_weights, self.device,
+                                     running_mean=torch.zeros(spec.K * D, dtype=torch.float64),
+                                     running_variance=torch.ones(spec.K * D, dtype=torch.float64),
+                                     task_reward_weight=spec.task_weight, style_reward_weight=spec.style_weight)
+        # expert rows are a plausible AMP history to start from
+        self.motion.collect_reference(self.state["motion_times"], self.state["motion_ids"], spec.K,
+                                      out=self.kernel.amp_observation_buffer)
+        self._sim = {k: self.state[k] for k in ("joint_pos", "joint_vel", "joint_acc", "actions", "root_pos", "root_quat",
+                                                "root_lin_vel", "root_ang_vel", "body_pos", "soft_limits", "episode_length",
+                                                "command", "last_actions")}
+        if spec.robot != "g1":
+            for k in ("joint_acc", "actions", "soft_limits", "command", "last_actions"):
+                self._sim.pop(k)
+        self.last = None
+
+    def step(self):
+        s, k = self.state, self.kernel
+        self.motion.collect_reference(s["motion_times"], s["motion_ids"], self.spec.K, out=self.expert_obs)
+        k.launch(nat.AMP_PHASE_ALL, key_body_indexes=[0, 1, 2, 3], **self._sim)
+        k.compact_resets()
+        self.last = self.disc.style_reward(k.amp_observation_buffer.view(self.num_envs, -1), k.reward)
+        return self.last
+
+
+def make_disc_weights(in_dim: int, seed: int = 0, hidden=(1024, 512)):
+    """torch.nn.Linear default init under torch.manual_seed(seed) -> [(W, b)] * 3 on the CPU."""
+    torch.manual_seed(seed)
+    dims = (in_dim,) + tuple(hidden) + (1,)
+    layers = [torch.nn.Linear(dims[i], dims[i + 1]) for i in range(3)]
+    return [(l.weight.detach().clone(), l.bias.detach().clone()) for l in layers]

@@ -45,6 +45,18 @@ const char* amp_last_error(void);
 int amp_device_name(char* buf, int64_t buf_len);
 
 /* ------------------------------------------------------------------------------------------------
+ * Kernel tracer (the reference has none: train.py:281,300 only wraps the whole run in time.time()).
+ * While tracing is on, every kernel launch whose name contains `filter` (NULL / "" = all) is bracketed by a
+ * pair of HIP events on its own stream.  Read the durations after synchronising those streams.
+ * Not thread-safe; do not toggle while another thread is launching.
+ * ------------------------------------------------------------------------------------------------ */
+int amp_trace_begin(int64_t capacity, const char* filter);
+int amp_trace_end(void);                 /* stop recording (records stay readable until the next begin) */
+int64_t amp_trace_count(void);
+/* name and duration in milliseconds of record i; AMP_ERR_HIP if its events have not completed yet */
+int amp_trace_get(int64_t i, char* name_buf, int64_t name_len, float* ms);
+
+/* ------------------------------------------------------------------------------------------------
  * Motion table  (replaces MotionLoader.__init__, motions/motion_loader.py:98-164)
  * ------------------------------------------------------------------------------------------------ */
 typedef struct {
