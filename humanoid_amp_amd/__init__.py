@@ -10,6 +10,9 @@ from . import _native
 
 _native.load()  # no CPU fallback: a missing / stale library is an ImportError here
 
+from .engine import AmpDiscriminator, EnvStepConfig, EnvStepKernel, reset_compact  # noqa: E402
+from .envs import G1AmpEnv, HumanoidAmpEnv, make  # noqa: E402
 from .motions import MotionLoader  # noqa: E402
 
-__all__ = ["MotionLoader"]
+__all__ = ["MotionLoader", "G1AmpEnv", "HumanoidAmpEnv", "make", "AmpDiscriminator", "EnvStepConfig", "EnvStepKernel",
+           "reset_compact"]

@@ -1,0 +1,271 @@
+"""G1AmpEnv / HumanoidAmpEnv: the reference's task envs with every hook routed to the HIP engine.
+
+Same hook names, attributes and agent-facing surface as the reference (g1_amp_env.py:22-486,
+humanoid_amp_env.py:22-248): ``step`` / ``reset``, ``extras["amp_obs"]`` (a VIEW of ``amp_observation_buffer``),
+``amp_observation_space`` / ``amp_observation_size``, ``collect_reference_motions(num_samples, current_times,
+motion_ids)``.  Each hook is one engine call:
+
+    _get_dones        -> amp_env_step(DONES)     (+ per-tile reset counts for the compaction)
+    _get_rewards      -> amp_env_step(REWARD)
+    reset ids         -> amp_reset_compact_tiles (replaces reset_buf.nonzero())
+    _reset_idx        -> amp_reset_reference_state + amp_collect_reference(scatter into the AMP buffer)
+    _get_observations -> amp_env_step(OBS)
+    collect_reference_motions -> amp_collect_reference
+
+The humanoid env follows the G1 calling convention for ``sample_times`` / ``motion_ids`` (the reference's
+humanoid env was not updated for this fork's tuple-returning ``sample_times`` and raises for K > 1).
+"""
+
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from .. import _native as nat
+from ..engine import EnvStepConfig, EnvStepKernel, REWARD_TERMS
+from ..motions import MotionLoader
+from ..robots import G1_BODY_NAMES, G1_JOINT_NAMES, G1_KEY_BODY_NAMES, HUMANOID_KEY_BODY_NAMES
+from .direct_rl_env import DirectRLEnv
+from .sim import SyntheticArticulation
+
+
+class Box(SimpleNamespace):
+    """Shape-only stand-in for ``gym.spaces.Box`` (gymnasium is not a dependency of the hot path)."""
+
+    def __init__(self, low, high, shape):
+        super().__init__(low=low, high=high, shape=tuple(shape), dtype=np.float32)
+
+
+class _AmpEnv(DirectRLEnv):
+    KEY_BODY_NAMES: list = []
+    ROOT_BODY = "pelvis"   # body whose state initialises the root on reset (g1_amp_env.py:398 / humanoid :194)
+    Z_LIFT = 0.05
+    IS_G1 = True
+
+    def __init__(self, cfg, render_mode: str | None = None, robot=None, log_rewards: bool = True, **kwargs):
+        self._log_rewards = bool(log_rewards)
+        super().__init__(cfg, render_mode, robot=robot, **kwargs)
+        nat.require_gpu(self.device)
+        data = self.robot.data
+        lo, hi = data.soft_joint_pos_limits[0, :, 0], data.soft_joint_pos_limits[0, :, 1]
+        self.action_offset = 0.5 * (hi + lo)
+        self.action_scale = hi - lo
+
+        self._motion_loader = MotionLoader(motion_file=self.cfg.motion_file, device=self.device)
+        self.ref_body_index = data.body_names.index(self.cfg.reference_body)
+        self.key_body_indexes = [data.body_names.index(n) for n in self.KEY_BODY_NAMES]
+        self.motion_dof_indexes = self._motion_loader.get_dof_index(data.joint_names)
+        self.motion_ref_body_index = self._motion_loader.get_body_index([self.cfg.reference_body])[0]
+        self.motion_key_body_indexes = self._motion_loader.get_body_index(self.KEY_BODY_NAMES)
+        frame = self._motion_loader.set_obs_layout(self.motion_dof_indexes, self.motion_ref_body_index,
+                                                   self.motion_key_body_indexes)
+        if frame != self.cfg.amp_observation_space:
+            raise ValueError(f"cfg.amp_observation_space = {self.cfg.amp_observation_space}, but this robot / clip emits "
+                             f"{frame}-float AMP frames (2*DoF + 1 + 6 + 3 + 3 + 12)")
+        root_idx = self._motion_loader.get_body_index([self.ROOT_BODY])[0]
+        if root_idx != self.motion_ref_body_index:
+            raise ValueError("the reset root body must be the AMP reference body")
+
+        K = self.cfg.num_amp_observations
+        self.amp_observation_size = K * self.cfg.amp_observation_space
+        self.amp_observation_space = Box(-np.inf, np.inf, (self.amp_observation_size,))
+        self.key_body_obs_size = len(self.KEY_BODY_NAMES) * 3
+        n_actor = getattr(self.cfg, "num_actor_observations", 1)
+        kcfg = EnvStepConfig(
+            n_dof=len(data.joint_names), num_amp_observations=K, max_episode_length=self.max_episode_length,
+            n_key=len(self.KEY_BODY_NAMES), num_actor_observations=n_actor, use_last_actions=self.IS_G1,
+            history_include_last_actions=getattr(self.cfg, "history_include_last_actions", True),
+            history_include_command=getattr(self.cfg, "history_include_command", True),
+            early_termination=self.cfg.early_termination, termination_height=self.cfg.termination_height,
+            reward_mode=1 if self.IS_G1 else 0,
+            **({k: float(getattr(self.cfg, k)) for k in ("rew_termination", "rew_action_l2", "rew_joint_pos_limits",
+                                                         "rew_joint_acc_l2", "rew_joint_vel_l2", "rew_track_vel")}
+               if self.IS_G1 else {}))
+        self._kernel = EnvStepKernel(kcfg, self.num_envs, self.device, log_reward_terms=self.IS_G1 and self._log_rewards)
+        if self._kernel.policy_obs_size != self.cfg.observation_space:
+            raise ValueError(f"cfg.observation_space = {self.cfg.observation_space} but the policy observation has "
+                             f"{self._kernel.policy_obs_size} entries")
+        # reference attribute names
+        self.amp_observation_buffer = self._kernel.amp_observation_buffer
+        self.observation_space = Box(-np.inf, np.inf, (self.cfg.observation_space,))
+        self.action_space = Box(-np.inf, np.inf, (self.cfg.action_space,))
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.actions = torch.zeros((self.num_envs, self.cfg.action_space), **f32)
+        self.last_actions = torch.zeros((self.num_envs, self.cfg.action_space), **f32)
+        self.command_target_speed = torch.zeros((self.num_envs, 2), **f32)
+        self.command_time_left = torch.zeros(self.num_envs, **f32)
+        self.motion_ids = torch.zeros(self.num_envs, dtype=torch.long, device=self.device)
+        self.motion_start_times = torch.zeros(self.num_envs, **f32)
+        if n_actor > 1:
+            self.actor_obs_hist_per_frame = self._kernel.actor_hist_per_frame
+            self.actor_obs_history_buffer = self._kernel.actor_obs_history_buffer
+            self._just_reset_mask = self._kernel.just_reset_mask
+
+    # ---- scene --------------------------------------------------------------------------------------------
+    def _make_robot(self):
+        raise NotImplementedError
+
+    def _setup_scene(self):
+        self.robot = self._given_robot if self._given_robot is not None else self._make_robot()
+
+    # ---- engine views of the simulator state --------------------------------------------------------------
+    def _sim_views(self):
+        d, r = self.robot.data, self.ref_body_index
+        return dict(joint_pos=d.joint_pos, joint_vel=d.joint_vel, root_pos=d.body_pos_w[:, r], root_quat=d.body_quat_w[:, r],
+                    root_lin_vel=d.body_lin_vel_w[:, r], root_ang_vel=d.body_ang_vel_w[:, r])
+
+    # ---- DirectRLEnv hooks ----------------------------------------------------------------------------------
+    def _pre_physics_step(self, actions: torch.Tensor):
+        self.actions = actions.clone()
+
+    def _apply_action(self):
+        self.robot.set_joint_position_target(self.action_offset + self.action_scale * self.actions)
+
+    def _get_dones(self):
+        self._kernel.launch(nat.AMP_PHASE_DONES, root_pos=self.robot.data.body_pos_w[:, self.ref_body_index],
+                            episode_length=self.episode_length_buf)
+        return self._kernel.died, self._kernel.time_out
+
+    def _compact_reset_ids(self) -> torch.Tensor:
+        ids, count = self._kernel.compact_resets()
+        return ids[: int(count)]  # one scalar read-back, like len(nonzero()) in the reference
+
+    def _get_observations(self) -> dict:
+        d = self.robot.data
+        self._kernel.launch(nat.AMP_PHASE_OBS, body_pos=d.body_pos_w, key_body_indexes=self.key_body_indexes,
+                            command=self.command_target_speed if self.IS_G1 else None,
+                            last_actions=self.last_actions if self.IS_G1 else None, **self._sim_views())
+        self.extras = {**{k: v for k, v in self.extras.items() if k == "log"},
+                       "amp_obs": self.amp_observation_buffer.view(-1, self.amp_observation_size)}
+        return {"policy": self._kernel.policy_obs}
+
+    def _reset_idx(self, env_ids: torch.Tensor | None):
+        if env_ids is None or len(env_ids) == self.num_envs:
+            env_ids = self.robot._ALL_INDICES
+        self.robot.reset(env_ids)
+        super()._reset_idx(env_ids)
+        strategy = self.cfg.reset_strategy
+        if strategy == "default":
+            root_state, joint_pos, joint_vel = self._reset_strategy_default(env_ids)
+        elif strategy.startswith("random"):
+            root_state, joint_pos, joint_vel = self._reset_strategy_random(env_ids, "start" in strategy)
+        else:
+            raise ValueError(f"Unknown reset strategy: {strategy}")
+        self.robot.write_root_link_pose_to_sim(root_state[:, :7], env_ids)
+        self.robot.write_root_com_velocity_to_sim(root_state[:, 7:], env_ids)
+        self.robot.write_joint_state_to_sim(joint_pos, joint_vel, None, env_ids)
+        self._after_reset(env_ids)
+
+    def _after_reset(self, env_ids):
+        pass
+
+    def _reset_strategy_default(self, env_ids):
+        d = self.robot.data
+        root_state = d.default_root_state[env_ids].clone()
+        root_state[:, :3] += self.scene.env_origins[env_ids]
+        return root_state, d.default_joint_pos[env_ids].clone(), d.default_joint_vel[env_ids].clone()
+
+    def _reset_strategy_random(self, env_ids: torch.Tensor, start: bool = False):
+        n = env_ids.shape[0]
+        motion_ids, times = self._motion_loader.sample_times(n, start=start)  # host numpy RNG, as the reference
+        ids_d = torch.from_numpy(np.asarray(motion_ids, dtype=np.int64)).to(self.device)
+        t_d = torch.from_numpy(np.asarray(times, dtype=np.float64)).to(self.device)
+        self.motion_ids[env_ids] = ids_d
+        self.motion_start_times[env_ids] = t_d.float()
+        root_state, dof_pos, dof_vel = self._motion_loader.reset_reference_state(
+            t_d, ids_d, env_ids=env_ids, env_origins=self.scene.env_origins, z_lift=self.Z_LIFT)
+        # expert history straight into amp_observation_buffer[env_ids] (g1_amp_env.py:414-419)
+        self._motion_loader.collect_reference(t_d, ids_d, self.cfg.num_amp_observations, out=self.amp_observation_buffer,
+                                              dst_rows=env_ids)
+        self._resample_commands(env_ids, on_reset=True)
+        return root_state, dof_pos, dof_vel
+
+    def _resample_commands(self, env_ids, on_reset: bool):
+        pass
+
+    # ---- agent-facing -----------------------------------------------------------------------------------------
+    def collect_reference_motions(self, num_samples: int, current_times: np.ndarray | None = None,
+                                  motion_ids: np.ndarray | None = None) -> torch.Tensor:
+        """Expert AMP observations [num_samples, K*D] (g1_amp_env.py:445-486).  ``current_times`` / ``motion_ids``
+        may be numpy arrays or device tensors."""
+        if current_times is None:
+            motion_ids, current_times = self._motion_loader.sample_times(num_samples)
+        return self._motion_loader.collect_reference(current_times, motion_ids, self.cfg.num_amp_observations)
+
+
+class G1AmpEnv(_AmpEnv):
+    KEY_BODY_NAMES = G1_KEY_BODY_NAMES
+    ROOT_BODY, Z_LIFT, IS_G1 = "pelvis", 0.05, True
+
+    def _make_robot(self):
+        return SyntheticArticulation(self.num_envs, G1_JOINT_NAMES, G1_BODY_NAMES, self.device, root_body="pelvis",
+                                     dt=self.physics_dt)
+
+    def _pre_physics_step(self, actions: torch.Tensor):
+        self.actions = actions.clone()
+        self.command_time_left -= self.step_dt   # g1_amp_env.py:146-167
+        lo, hi = self.cfg.track_vel_range
+        if hi > lo:
+            expired = (self.command_time_left <= 0.0).nonzero(as_tuple=False).flatten()
+            if len(expired) > 0:
+                self._resample_commands(expired, on_reset=False)
+
+    def _apply_action(self):
+        super()._apply_action()
+        self.last_actions = self.actions.clone()
+
+    def _resample_commands(self, env_ids, on_reset: bool):
+        lo, hi = self.cfg.track_vel_range
+        t_lo, t_hi = self.cfg.command_resampling_time_range
+        n = len(env_ids)
+        if hi > lo:
+            self.command_target_speed[env_ids] = torch.rand((n, 2), device=self.device) * (hi - lo) + lo
+            self.command_time_left[env_ids] = torch.rand(n, device=self.device) * (t_hi - t_lo) + t_lo
+        elif on_reset:  # fixed command (g1_amp_env.py:436-439)
+            self.command_target_speed[env_ids, 0] = lo
+            self.command_target_speed[env_ids, 1] = 0.0
+            self.command_time_left[env_ids] = float("inf")
+
+    def _get_rewards(self) -> torch.Tensor:
+        d = self.robot.data
+        self._kernel.launch(nat.AMP_PHASE_REWARD, joint_acc=d.joint_acc, actions=self.actions,
+                            soft_limits=d.soft_joint_pos_limits, command=self.command_target_speed, **self._sim_views())
+        if self._log_rewards:
+            # one device reduction + one read-back instead of the reference's 6-8 .mean().item() syncs (:291-305)
+            means = self._kernel.reward_terms.mean(dim=1).tolist()
+            log = dict(zip(REWARD_TERMS, means))
+            if not self.cfg.rew_track_vel > 0.0:
+                log.pop("rew_track_vel"), log.pop("error_track_vel")
+            self.extras["log"] = log
+            agent = getattr(self, "_skrl_agent", None)
+            if agent is not None:
+                try:
+                    for k, v in log.items():
+                        agent.track_data(f"Reward / {k}", v)
+                except Exception:
+                    pass
+        return self._kernel.reward
+
+    def _after_reset(self, env_ids):
+        self.last_actions[env_ids] = 0.0
+        if getattr(self.cfg, "num_actor_observations", 1) > 1:
+            self._just_reset_mask[env_ids] = True
+
+
+class HumanoidAmpEnv(_AmpEnv):
+    KEY_BODY_NAMES = HUMANOID_KEY_BODY_NAMES
+    ROOT_BODY, Z_LIFT, IS_G1 = "torso", 0.15, False
+
+    def _make_robot(self):
+        names = np.load(self.cfg.motion_file.split(",")[0]) if self.cfg.motion_file.endswith(".npz") else None
+        if names is None:
+            raise ValueError("HumanoidAmpEnv needs an explicit robot when motion_file is not a single .npz")
+        # the humanoid_28 asset's robot-side order is not recorded in the reference: clip order (unpinned)
+        return SyntheticArticulation(self.num_envs, names["dof_names"].tolist(), names["body_names"].tolist(), self.device,
+                                     root_body="torso", dt=self.physics_dt, init_height=1.0)
+
+    def _get_rewards(self) -> torch.Tensor:
+        self._kernel.launch(nat.AMP_PHASE_REWARD)
+        return self._kernel.reward
