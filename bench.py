@@ -169,8 +169,11 @@ def main():
     from humanoid_amp_amd.distributed import ReplayAllGather
     from humanoid_amp_amd.workloads import WORKLOADS, HotPath, algorithmic_bytes_per_env_step, disc_flops_per_row
 
+    import contextlib
+
     spec = WORKLOADS[args.workload]
-    hot = HotPath(spec, args.envs, device, seed=1234 + rank)
+    with contextlib.redirect_stdout(sys.stderr):  # MotionLoader prints like the reference; stdout carries only the JSON line
+        hot = HotPath(spec, args.envs, device, seed=1234 + rank)
     collective = None
     if world > 1:
         ag = ReplayAllGather(hot.kernel.amp_observation_buffer.view(args.envs, -1), args.replay_minibatch, seed=rank)
@@ -219,7 +222,8 @@ def main():
     if not args.no_secondary and args.envs != 4096:
         del hot
         torch.cuda.empty_cache()
-        hot_s = HotPath(spec, 4096, device, seed=99 + rank)
+        with contextlib.redirect_stdout(sys.stderr):
+            hot_s = HotPath(spec, 4096, device, seed=99 + rank)
         dts = timed_steps(hot_s, max(args.steps, 50), args.warmup, world, None)
         if rank == 0:
             out["envs_4096"] = {"value": 4096 * world * max(args.steps, 50) / dts, "unit": "env-steps/s",

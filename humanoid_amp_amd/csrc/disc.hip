@@ -2,8 +2,10 @@
 // -> -log(max(1 - sigmoid, 1e-4)) * scale -> reward mix.  fp32 end to end on the gfx950 matrix cores
 // (v_mfma_f32_32x32x2_f32: exact fp32 fma chain; the 1e-5 budget rules out bf16/fp8 operands).
 //
-//   layer 1  GEMM [M, in] x [in, 1024]: the running-standard-scaler is applied while the A tile is staged,
-//            bias + ReLU in the epilogue, H1 [M,1024] written once to the workspace.
+//   scale    one pass over amp_obs: RunningStandardScaler (exact fp32 divide, once per element) + zero padding of
+//            K*D to a multiple of 32 -> Xs [M, k1p] in the workspace (16-B aligned rows for the GEMM staging).
+//   layer 1  GEMM [M, k1p] x [k1p, 1024]: bias + ReLU in the epilogue, transposed through LDS so every store is
+//            a full 256-B row segment; H1 [M,1024] written once to the workspace.
 //   layer 2  GEMM [M,1024] x [1024,512]: bias + ReLU + the 512->1 output layer as an in-register dot with
 //            w3, reduced over the tile's columns (lane butterfly, then LDS across the two column waves);
 //            only per-(row, column-tile) partial logits leave the kernel.
@@ -13,9 +15,10 @@
 // LDS rows are padded to 36 floats so the four ds_read_b128 a lane issues per operand row are conflict-free.
 // Global->LDS staging is register-prefetched one k-tile ahead.  Workgroups are renumbered so that the
 // column tiles of one row tile run on the same XCD (they share the A tile through that XCD's L2).
-#include "amp_common.hpp"
+#include "disc_gemm.hpp"
 
-typedef float floatx16 __attribute__((ext_vector_type(16)));
+#include <cstdlib>
+
 typedef float f4 __attribute__((ext_vector_type(4)));  // native vector: HIP's f4 struct turns into memcpy -> scratch
 
 struct AmpDisc {
@@ -34,217 +37,8 @@ struct AmpDisc {
 
 namespace amp {
 
-constexpr int BM = 128, BN = 128, BK = 32, LDT = BK + 4;
-
-struct GemmArgs {
-  const float* A; int64_t lda; int64_t M; int32_t K;   // K = valid columns of A
-  const float* W; int32_t Kp;                          // W [N, Kp], Kp % BK == 0
-  const float* bias; int32_t N;
-  const float* mean; const float* den; float clip;     // scaler (mode 0, optional)
-  float* C; int64_t ldc;                               // mode 0 output
-  const float* w3; float* partial; int32_t n_tiles;    // mode 1 output [M, n_tiles]
-  int32_t m_tiles;
-};
-
-// XCD-aware renumbering: hardware deals workgroups round-robin over the 8 XCDs; give each XCD a contiguous
-// run of (row tile, column tile) pairs with the column tile fastest (speed only, never correctness).
-__device__ __forceinline__ bool tile_of_block(const GemmArgs& g, int& mt, int& nt) {
-  const int total = g.m_tiles * g.n_tiles;
-  const int per_xcd = (total + 7) / 8;
-  const int v = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (v >= total) return false;
-  mt = v / g.n_tiles;
-  nt = v - mt * g.n_tiles;
-  return true;
-}
-
-
-template <int MODE>
-struct Stage;
-
-// weights tile: every lane carries four f4 (rows r4 + 32*i of the [128, 32] tile)
-struct StageB {
-  f4 b0, b1, b2, b3;
-  __device__ __forceinline__ void load_b(const GemmArgs& g, int n0, int kt, int c4, int r4) {
-    const float* w = g.W + (int64_t)(n0 + r4) * g.Kp + kt * BK + 4 * c4;
-    const int64_t step = (int64_t)32 * g.Kp;
-    b0 = *reinterpret_cast<const f4*>(w);
-    b1 = *reinterpret_cast<const f4*>(w + step);
-    b2 = *reinterpret_cast<const f4*>(w + 2 * step);
-    b3 = *reinterpret_cast<const f4*>(w + 3 * step);
-  }
-  __device__ __forceinline__ void store_b(float* Bs, int c4, int r4) const {
-    float* d = &Bs[r4 * LDT + 4 * c4];
-    *reinterpret_cast<f4*>(d) = b0;
-    *reinterpret_cast<f4*>(d + 32 * LDT) = b1;
-    *reinterpret_cast<f4*>(d + 64 * LDT) = b2;
-    *reinterpret_cast<f4*>(d + 96 * LDT) = b3;
-  }
-};
-
-// layer 2: A = H1 [M, 1024], 16-B aligned rows -> f4 loads
-template <>
-struct Stage<1> : StageB {
-  f4 a0, a1, a2, a3;
-  __device__ __forceinline__ void load(const GemmArgs& g, int64_t m0, int n0, int kt, int c4, int r4, int, int) {
-    load_b(g, n0, kt, c4, r4);
-    const int64_t last = g.M - 1;
-    const int64_t ma = m0 + r4, mb = ma + 32, mc = ma + 64, md = ma + 96;
-    const float* base = g.A + kt * BK + 4 * c4;
-    a0 = *reinterpret_cast<const f4*>(base + (ma < last ? ma : last) * g.lda);
-    a1 = *reinterpret_cast<const f4*>(base + (mb < last ? mb : last) * g.lda);
-    a2 = *reinterpret_cast<const f4*>(base + (mc < last ? mc : last) * g.lda);
-    a3 = *reinterpret_cast<const f4*>(base + (md < last ? md : last) * g.lda);
-  }
-  __device__ __forceinline__ void store(float* As, float* Bs, int c4, int r4, int, int) const {
-    store_b(Bs, c4, r4);
-    float* d = &As[r4 * LDT + 4 * c4];
-    *reinterpret_cast<f4*>(d) = a0;
-    *reinterpret_cast<f4*>(d + 32 * LDT) = a1;
-    *reinterpret_cast<f4*>(d + 64 * LDT) = a2;
-    *reinterpret_cast<f4*>(d + 96 * LDT) = a3;
-  }
-};
-
-// layer 1: A = amp_obs [M, in_dim] (rows only 8-B aligned, in_dim not a multiple of 32): scalar loads, k guard,
-// and the skrl RunningStandardScaler  clamp((x - mean) / (sqrt(var) + eps), -clip, clip)  applied in flight
-template <>
-struct Stage<0> : StageB {
-  floatx16 a;
-  __device__ __forceinline__ void load(const GemmArgs& g, int64_t m0, int n0, int kt, int c4, int r4, int k1, int r1) {
-    load_b(g, n0, kt, c4, r4);
-    const int k = kt * BK + k1;
-    const bool kin = k < g.K;
-    const bool scale = g.mean != nullptr;
-    const float mu = (kin && scale) ? g.mean[k] : 0.0f;
-    const float dn = (kin && scale) ? g.den[k] : 1.0f;
-    const int64_t last = g.M - 1;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      int64_t m = m0 + r1 + 8 * i;
-      m = m < last ? m : last;
-      float x = kin ? g.A[m * g.lda + k] : 0.0f;
-      if (scale) {
-        x = (x - mu) / dn;
-        x = fminf(fmaxf(x, -g.clip), g.clip);
-      }
-      a[i] = kin ? x : 0.0f;
-    }
-  }
-  __device__ __forceinline__ void store(float* As, float* Bs, int c4, int r4, int k1, int r1) const {
-    store_b(Bs, c4, r4);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) As[(r1 + 8 * i) * LDT + k1] = a[i];
-  }
-};
-
-// One 128x128x32 tile step.  Lane (li, lh) takes k = 16*lh + s of operand row li for MFMA step s: any fixed
-// permutation of k is a valid summation order as long as A and B use the same one, and this one turns the
-// operand fetch into four ds_read_b128 per 32-row fragment.
-__device__ __forceinline__ void compute_tile(const float* As, const float* Bs, int wm, int wn, int li, int lh,
-                                             floatx16 (&acc)[2][2]) {
-  const f4* pa0 = reinterpret_cast<const f4*>(&As[(wm * 64 + li) * LDT + 16 * lh]);
-  const f4* pb0 = reinterpret_cast<const f4*>(&Bs[(wn * 64 + li) * LDT + 16 * lh]);
-  const f4* pa1 = pa0 + 32 * LDT / 4;
-  const f4* pb1 = pb0 + 32 * LDT / 4;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const f4 x0 = pa0[q], x1 = pa1[q], y0 = pb0[q], y1 = pb1[q];
-#define AMP_MFMA_STEP(c)                                                                   \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.c, y0.c, acc[0][0], 0, 0, 0); \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.c, y1.c, acc[0][1], 0, 0, 0); \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.c, y0.c, acc[1][0], 0, 0, 0); \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.c, y1.c, acc[1][1], 0, 0, 0);
-    AMP_MFMA_STEP(x)
-    AMP_MFMA_STEP(y)
-    AMP_MFMA_STEP(z)
-    AMP_MFMA_STEP(w)
-#undef AMP_MFMA_STEP
-  }
-}
-
-template <int MODE>
-__global__ __launch_bounds__(kBlock, 2) void disc_gemm_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float As[BM * LDT];
-  __shared__ __attribute__((aligned(16))) float Bs[BN * LDT];
-  int mt, nt;
-  if (!tile_of_block(g, mt, nt)) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int li = lane & 31, lh = lane >> 5;
-  const int64_t m0 = (int64_t)mt * BM;
-  const int n0 = nt * BN;
-  const int nk = g.Kp / BK;
-
-  floatx16 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-
-  // ---- staging registers (named scalars, not arrays: keeps them out of scratch) -------------------
-  const int c4 = tid & 7, r4 = tid >> 3;     // f4 mapping: row r4 + 32*i, floats [4*c4, 4*c4+4)
-  const int k1 = tid & 31, r1 = tid >> 5;    // scalar mapping: row r1 + 8*i, float k1
-  Stage<MODE> stg;
-  stg.load(g, m0, n0, 0, c4, r4, k1, r1);
-  stg.store(As, Bs, c4, r4, k1, r1);
-  __syncthreads();
-  for (int kt = 0; kt + 1 < nk; ++kt) {
-    stg.load(g, m0, n0, kt + 1, c4, r4, k1, r1);  // in flight under this tile's MFMAs
-    compute_tile(As, Bs, wm, wn, li, lh, acc);
-    __syncthreads();
-    stg.store(As, Bs, c4, r4, k1, r1);
-    __syncthreads();
-  }
-  compute_tile(As, Bs, wm, wn, li, lh, acc);
-  __syncthreads();
-
-  // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) --------
-  if (MODE == 0) {
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int col = n0 + wn * 64 + b * 32 + li;
-        const float bias = g.bias[col];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t row = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (row < g.M) g.C[row * g.ldc + col] = fmaxf(acc[a][b][r] + bias, 0.0f);
-        }
-      }
-  } else {
-    // relu(acc + b2) . w3 over this tile's 128 columns
-    float* red = As;  // [2][128] reuse (all waves passed the last barrier of the k loop)
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      float part[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) part[r] = 0.0f;
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int col = n0 + wn * 64 + b * 32 + li;
-        const float bias = g.bias[col], w = g.w3[col];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) part[r] += fmaxf(acc[a][b][r] + bias, 0.0f) * w;
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = part[r];
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        if (li == 0) red[wn * BM + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = v;
-      }
-    }
-    __syncthreads();
-    if (tid < BM) {
-      const int64_t row = m0 + tid;
-      if (row < g.M) g.partial[row * g.n_tiles + nt] = red[tid] + red[BM + tid];
-    }
-  }
-}
+constexpr int kMinN = 128;  // h1 / h2 must be multiples of the widest column tile
+constexpr int kPadK = 16;  // in_dim is zero-padded to a multiple of the layer-1 k-tile
 
 __global__ __launch_bounds__(kBlock) void disc_finalize_kernel(const float* __restrict__ partial, int n_tiles,
                                                                const float* __restrict__ b3, int64_t M, float scale,
@@ -257,6 +51,8 @@ __global__ __launch_bounds__(kBlock) void disc_finalize_kernel(const float* __re
   float s = 0.0f;
   if (n_tiles == 4) {
     s = (p[0] + p[1]) + (p[2] + p[3]);
+  } else if (n_tiles == 8) {
+    s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
   } else {
     for (int t = 0; t < n_tiles; ++t) s += p[t];
   }
@@ -289,6 +85,35 @@ __global__ void disc_pad_rows_kernel(const float* __restrict__ src, int rows, in
   dst[e] = c < k ? src[(int64_t)r * k + c] : 0.0f;
 }
 
+// amp_obs [M, in] (any row stride) -> Xs [M, kp]: skrl RunningStandardScaler
+//   clamp((x - mean) / (sqrt(var) + eps), -clip, clip)   (exact fp32 divide, once per element), zero padded to kp.
+__global__ __launch_bounds__(kBlock) void disc_scale_pad_kernel(const float* __restrict__ x, int64_t row_stride, int64_t M,
+                                                                int k, int kp, const float* __restrict__ mean,
+                                                                const float* __restrict__ den, float clip,
+                                                                float* __restrict__ xs) {
+  const int q_per_row = kp >> 2;
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= M * q_per_row) return;
+  const int64_t m = e / q_per_row;
+  const int c0 = (int)(e - m * q_per_row) * 4;
+  const float* row = x + m * row_stride;
+  f4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + i;
+    float v = 0.0f;
+    if (c < k) {
+      v = row[c];
+      if (mean) {
+        v = (v - mean[c]) / den[c];
+        v = fminf(fmaxf(v, -clip), clip);
+      }
+    }
+    o[i] = v;
+  }
+  *reinterpret_cast<f4*>(xs + m * kp + c0) = o;
+}
+
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 }  // namespace amp
@@ -314,8 +139,8 @@ int amp_disc_destroy(AmpDisc* h) {
 int amp_disc_create(const AmpDiscDesc* d, amp_stream_t stream, AmpDisc** out) {
   AMP_REQUIRE(d && out, "amp_disc_create: null argument");
   AMP_REQUIRE(d->in_dim >= 1, "amp_disc_create: in_dim must be positive");
-  AMP_REQUIRE(d->h1 >= BN && d->h1 % BN == 0 && d->h1 % BK == 0, "amp_disc_create: h1=%d must be a multiple of %d", d->h1, BN);
-  AMP_REQUIRE(d->h2 >= BN && d->h2 % BN == 0, "amp_disc_create: h2=%d must be a multiple of %d", d->h2, BN);
+  AMP_REQUIRE(d->h1 >= kMinN && d->h1 % kMinN == 0 && d->h1 % kPadK == 0, "amp_disc_create: h1=%d must be a multiple of %d", d->h1, kMinN);
+  AMP_REQUIRE(d->h2 >= kMinN && d->h2 % kMinN == 0, "amp_disc_create: h2=%d must be a multiple of %d", d->h2, kMinN);
   AMP_REQUIRE(d->w1 && d->b1 && d->w2 && d->b2 && d->w3 && d->b3, "amp_disc_create: null weight pointer");
   AmpDisc* h = new (std::nothrow) AmpDisc();
   AMP_REQUIRE(h, "amp_disc_create: out of host memory");
@@ -323,7 +148,7 @@ int amp_disc_create(const AmpDiscDesc* d, amp_stream_t stream, AmpDisc** out) {
   h->in_dim = d->in_dim;
   h->h1 = d->h1;
   h->h2 = d->h2;
-  h->k1p = (int32_t)round_up(d->in_dim, BK);
+  h->k1p = (int32_t)round_up(d->in_dim, kPadK);
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipMalloc(&h->w1p, sizeof(float) * (size_t)h->h1 * h->k1p);
   if (e == hipSuccess) e = hipMalloc(&h->b1, sizeof(float) * h->h1);
@@ -375,9 +200,10 @@ int amp_disc_set_scaler(AmpDisc* h, const double* mean, const double* var, float
 
 int64_t amp_disc_workspace_bytes(const AmpDisc* h, int64_t rows) {
   if (!h || rows < 0) return -1;
+  const int64_t xs_bytes = round_up((int64_t)sizeof(float) * rows * h->k1p, 256);
   const int64_t h1_bytes = round_up((int64_t)sizeof(float) * rows * h->h1, 256);
-  const int64_t part_bytes = round_up((int64_t)sizeof(float) * rows * (h->h2 / BN), 256);
-  return h1_bytes + part_bytes;
+  const int64_t part_bytes = round_up((int64_t)sizeof(float) * rows * (h->h2 / 64), 256);
+  return xs_bytes + h1_bytes + part_bytes;
 }
 
 int amp_disc_style_reward(const AmpDisc* h, const float* x, int64_t rows, int64_t row_stride, float scale, const float* task,
@@ -389,31 +215,53 @@ int amp_disc_style_reward(const AmpDisc* h, const float* x, int64_t rows, int64_
   AMP_REQUIRE(x && workspace, "amp_disc_style_reward: null buffer");
   AMP_REQUIRE(row_stride >= h->in_dim, "amp_disc_style_reward: row_stride %lld < in_dim %d", (long long)row_stride, h->in_dim);
   AMP_REQUIRE((uintptr_t)workspace % 16 == 0, "amp_disc_style_reward: workspace must be 16-byte aligned");
-  AMP_REQUIRE(rows <= ((int64_t)1 << 24) * BM, "amp_disc_style_reward: too many rows");
+  AMP_REQUIRE(rows <= ((int64_t)1 << 30), "amp_disc_style_reward: too many rows");
   hipStream_t st = (hipStream_t)stream;
-  float* H1 = (float*)workspace;
-  float* partial = (float*)((char*)workspace + round_up((int64_t)sizeof(float) * rows * h->h1, 256));
-  const int m_tiles = (int)((rows + BM - 1) / BM);
+  float* Xs = (float*)workspace;
+  float* H1 = (float*)((char*)Xs + round_up((int64_t)sizeof(float) * rows * h->k1p, 256));
+  float* partial = (float*)((char*)H1 + round_up((int64_t)sizeof(float) * rows * h->h1, 256));
+  // Tile choice, measured on MI355X with tools/gemm_bench.hip (interleaved rounds, profiles/r01_gemm_variants.txt):
+  // 128 x 128 x 16 with one LDS stage at 4 workgroups per CU wins whenever it yields >= 512 workgroups; smaller
+  // shards use 64 x 64 tiles so that every CU still gets several workgroups (a 4096-row layer 2 is only 128 tiles
+  // of 128 x 128: 74 us vs 40 us).
+  auto big_tiles = [&](int N) { return (rows + 127) / 128 * (N / 128) >= 512; };
+  {
+    const int64_t quads = rows * (h->k1p / 4);
+    amp::TraceScope trace__("disc_scale_pad_kernel", st);
+    disc_scale_pad_kernel<<<(unsigned)((quads + kBlock - 1) / kBlock), kBlock, 0, st>>>(
+        x, row_stride, rows, h->in_dim, h->k1p, h->has_scaler ? h->mean : nullptr, h->den, h->clip, Xs);
+  }
+  int rc = launch_status("disc_scale_pad_kernel");
+  if (rc != AMP_OK) return rc;
 
   GemmArgs g1{};
-  g1.A = x; g1.lda = row_stride; g1.M = rows; g1.K = h->in_dim;
+  g1.A = Xs; g1.lda = h->k1p; g1.M = rows; g1.K = h->k1p;
   g1.W = h->w1p; g1.Kp = h->k1p; g1.bias = h->b1; g1.N = h->h1;
-  g1.mean = h->has_scaler ? h->mean : nullptr; g1.den = h->den; g1.clip = h->clip;
-  g1.C = H1; g1.ldc = h->h1; g1.n_tiles = h->h1 / BN; g1.m_tiles = m_tiles;
-  const unsigned grid1 = (unsigned)(((int64_t)m_tiles * g1.n_tiles + 7) / 8 * 8);
-  { amp::TraceScope trace__("disc_gemm_kernel<0>", st);
-    disc_gemm_kernel<0><<<grid1, kBlock, 0, st>>>(g1);
+  g1.C = H1; g1.ldc = h->h1;
+  {
+    const bool big = big_tiles(h->h1);
+    const int bm = big ? 128 : 64;
+    g1.n_tiles = h->h1 / bm; g1.m_tiles = (int)((rows + bm - 1) / bm);
+    const unsigned grid = (unsigned)(((int64_t)g1.m_tiles * g1.n_tiles + 7) / 8 * 8);
+    amp::TraceScope trace__("disc_gemm_kernel<0>", st);
+    if (big) disc_gemm_kernel<128, 128, 16, 1, 0, 4><<<grid, kBlock, 0, st>>>(g1);
+    else disc_gemm_kernel<64, 64, 16, 1, 0, 8><<<grid, kBlock, 0, st>>>(g1);
   }
-  int rc = launch_status("disc_gemm_kernel<0>");
+  rc = launch_status("disc_gemm_kernel<0>");
   if (rc != AMP_OK) return rc;
 
   GemmArgs g2{};
   g2.A = H1; g2.lda = h->h1; g2.M = rows; g2.K = h->h1;
   g2.W = h->w2; g2.Kp = h->h1; g2.bias = h->b2; g2.N = h->h2;
-  g2.w3 = h->w3; g2.partial = partial; g2.n_tiles = h->h2 / BN; g2.m_tiles = m_tiles;
-  const unsigned grid2 = (unsigned)(((int64_t)m_tiles * g2.n_tiles + 7) / 8 * 8);
-  { amp::TraceScope trace__("disc_gemm_kernel<1>", st);
-    disc_gemm_kernel<1><<<grid2, kBlock, 0, st>>>(g2);
+  g2.w3 = h->w3; g2.partial = partial;
+  {
+    const bool big = big_tiles(h->h2);
+    const int bm = big ? 128 : 64;
+    g2.n_tiles = h->h2 / bm; g2.m_tiles = (int)((rows + bm - 1) / bm);
+    const unsigned grid = (unsigned)(((int64_t)g2.m_tiles * g2.n_tiles + 7) / 8 * 8);
+    amp::TraceScope trace__("disc_gemm_kernel<1>", st);
+    if (big) disc_gemm_kernel<128, 128, 16, 1, 1, 4><<<grid, kBlock, 0, st>>>(g2);
+    else disc_gemm_kernel<64, 64, 32, 1, 1, 4><<<grid, kBlock, 0, st>>>(g2);
   }
   rc = launch_status("disc_gemm_kernel<1>");
   if (rc != AMP_OK) return rc;

@@ -1,0 +1,215 @@
+// fp32-MFMA GEMM building block of the discriminator (included by disc.hip and tools/gemm_bench.hip).
+//   MODE 0: C = relu(A W^T + bias) stored [M, N]
+//   MODE 1: partial[m, nt] = sum over the tile's columns of relu(A W^T + bias)[m, n] * w3[n]
+// A [M, lda] and W [N, Kp] are row-major fp32 with 16-B aligned rows, Kp % BK == 0.
+//
+// Tile: BM x BN x BK_, 4 waves as 2 x 2, each wave (BM/2) x (BN/2) = TM x TN accumulators of
+// v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).  LDS rows are padded by 4 floats so the ds_read_b128 operand
+// fetches are conflict-free; lane (li, lh) consumes k = (BK_/2)*lh + s at MFMA step s (a fixed k-permutation shared
+// by A and B -- legal because fp32 addition order inside a dot product is not part of the contract).
+// STAGES_ = 1: one LDS stage, two barriers per k-tile.  STAGES_ = 2: two stages, one barrier per k-tile.
+// Global -> LDS staging is register-prefetched one k-tile ahead; the issue order is pinned with sched_barrier because
+// hipcc otherwise sinks the prefetch loads below the MFMAs and exposes their whole latency.
+#pragma once
+#include "amp_common.hpp"
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float f4 __attribute__((ext_vector_type(4)));  // native vector: HIP's float4 struct turns into memcpy -> scratch
+
+namespace amp {
+
+struct GemmArgs {
+  const float* A; int64_t lda; int64_t M; int32_t K;
+  const float* W; int32_t Kp;
+  const float* bias; int32_t N;
+  float* C; int64_t ldc;                               // mode 0 output
+  const float* w3; float* partial; int32_t n_tiles;    // mode 1 output [M, n_tiles]
+  int32_t m_tiles;
+};
+
+// XCD-aware renumbering: hardware deals workgroups round-robin over the 8 XCDs; give each XCD a contiguous
+// run of (row tile, column tile) pairs with the column tile fastest (speed only, never correctness).
+__device__ __forceinline__ bool tile_of_block(const GemmArgs& g, int& mt, int& nt) {
+  const int total = g.m_tiles * g.n_tiles;
+  const int per_xcd = (total + 7) / 8;
+  const int v = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (v >= total) return false;
+  mt = v / g.n_tiles;
+  nt = v - mt * g.n_tiles;
+  return true;
+}
+
+// Workgroup barrier that waits for this wave's LDS traffic only (__syncthreads() would also drain vmcnt, i.e. stall
+// on the global prefetch that is meant to stay in flight).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int BM_, int BN_, int BK_>
+struct Stage {
+  static constexpr int LDT = BK_ + 4, QK = BK_ / 4, RPP = kBlock / QK;  // row pitch, 16-B pieces per row, rows per pass
+  f4 a[BM_ / RPP], b[BN_ / RPP];
+  __device__ __forceinline__ void load(const GemmArgs& g, int64_t m0, int n0, int kt, int tid) {
+    const int c4 = tid % QK, r4 = tid / QK;
+    const float* w = g.W + (int64_t)(n0 + r4) * g.Kp + kt * BK_ + 4 * c4;
+    const int64_t step = (int64_t)RPP * g.Kp;
+#pragma unroll
+    for (int i = 0; i < BN_ / RPP; ++i) b[i] = *reinterpret_cast<const f4*>(w + i * step);
+    const int64_t last = g.M - 1;  // rows past M re-read the last row; their results are never stored
+    const float* base = g.A + kt * BK_ + 4 * c4;
+#pragma unroll
+    for (int i = 0; i < BM_ / RPP; ++i) {
+      const int64_t m = m0 + r4 + RPP * i;
+      a[i] = *reinterpret_cast<const f4*>(base + (m < last ? m : last) * g.lda);
+    }
+  }
+  __device__ __forceinline__ void store(float* As, float* Bs, int tid) const {
+    const int c4 = tid % QK, r4 = tid / QK;
+#pragma unroll
+    for (int i = 0; i < BN_ / RPP; ++i) *reinterpret_cast<f4*>(&Bs[(r4 + RPP * i) * LDT + 4 * c4]) = b[i];
+#pragma unroll
+    for (int i = 0; i < BM_ / RPP; ++i) *reinterpret_cast<f4*>(&As[(r4 + RPP * i) * LDT + 4 * c4]) = a[i];
+  }
+};
+
+// SWAP = false: acc[a][b] = X_a W_b^T  (C/D rows = activation rows, lanes = weight rows / output columns)
+// SWAP = true : acc[a][b] = (W_b X_a^T) (C/D rows = output columns n, lanes = activation rows m): the transposed tile,
+//               which turns a reduction over output columns into a per-lane sum over accumulator registers.
+template <int TM, int TN, int BK_, bool SWAP>
+__device__ __forceinline__ void compute_tile(const float* As, const float* Bs, int arow, int brow, int lh,
+                                             floatx16 (&acc)[TM][TN]) {
+  constexpr int LDT = BK_ + 4, NQ = BK_ / 8;  // 16-B pieces per lane per operand row
+  const f4* pa = reinterpret_cast<const f4*>(&As[arow * LDT + (BK_ / 2) * lh]);
+  const f4* pb = reinterpret_cast<const f4*>(&Bs[brow * LDT + (BK_ / 2) * lh]);
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    f4 x[TM], y[TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) x[a] = pa[a * (32 * LDT / 4) + q];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) y[b] = pb[b * (32 * LDT / 4) + q];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc[a][b] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(y[b][c], x[a][c], acc[a][b], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f32_32x32x2f32(x[a][c], y[b][c], acc[a][b], 0, 0, 0);
+  }
+}
+
+template <int BM_, int BN_, int BK_, int STAGES_, int MODE, int MINW_>
+__global__ __launch_bounds__(kBlock, MINW_) void disc_gemm_kernel(GemmArgs g) {
+  constexpr int TM = BM_ / 64, TN = BN_ / 64, LDT = BK_ + 4;
+  constexpr int STAGE_F = (BM_ + BN_) * LDT;
+  constexpr int EP_F = 4 * 32 * (TN * 32 + 4);  // epilogue transpose region (mode 0)
+  constexpr int SMEM_F = STAGES_ * STAGE_F > EP_F ? STAGES_ * STAGE_F : EP_F;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_F];
+  int mt, nt;
+  if (!tile_of_block(g, mt, nt)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int64_t m0 = (int64_t)mt * BM_;
+  const int n0 = nt * BN_;
+  const int nk = g.Kp / BK_;
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  const int arow = wm * (TM * 32) + li, brow = wn * (TN * 32) + li;
+  Stage<BM_, BN_, BK_> stg;
+  stg.load(g, m0, n0, 0, tid);
+  stg.store(smem, smem + BM_ * LDT, tid);
+  if (STAGES_ == 2) {
+    if (nk > 1) stg.load(g, m0, n0, 1, tid);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      float* cur = smem + (kt & 1) * STAGE_F;
+      float* nxt = smem + ((kt + 1) & 1) * STAGE_F;
+      if (kt + 1 < nk) stg.store(nxt, nxt + BM_ * LDT, tid);   // k-tile kt+1 (in registers since kt-1)
+      if (kt + 2 < nk) stg.load(g, m0, n0, kt + 2, tid);        // in flight under this tile's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+      compute_tile<TM, TN, BK_, MODE == 1>(cur, cur + BM_ * LDT, arow, brow, lh, acc);
+      lds_barrier();
+    }
+  } else {
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) stg.load(g, m0, n0, kt + 1, tid);        // in flight under this tile's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+      compute_tile<TM, TN, BK_, MODE == 1>(smem, smem + BM_ * LDT, arow, brow, lh, acc);
+      lds_barrier();
+      if (kt + 1 < nk) {
+        stg.store(smem, smem + BM_ * LDT, tid);
+        lds_barrier();
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) --------
+  if (MODE == 0) {
+    // bias + ReLU, then transpose each wave's 32 x (TN*32) slab through its own LDS region (the staging tiles are
+    // dead) so that a lane stores 16 B and consecutive lanes cover contiguous bytes of one output row
+    constexpr int W = TN * 32, EPL = W + 4, QPR = W / 4;  // row width, padded row, 16-B pieces per row
+    float* ep = smem + wave * (32 * EPL);
+    float bias[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) bias[b] = g.bias[n0 + wn * W + b * 32 + li];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) ep[row * EPL + b * 32 + li] = fmaxf(acc[a][b][r] + bias[b], 0.0f);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < (32 * QPR) / 64; ++i) {
+        const int idx = lane + 64 * i, row = idx / QPR, q = idx % QPR;
+        const f4 v = *reinterpret_cast<const f4*>(&ep[row * EPL + 4 * q]);
+        const int64_t grow = m0 + wm * (TM * 32) + a * 32 + row;
+        if (grow < g.M) *reinterpret_cast<f4*>(&g.C[grow * g.ldc + n0 + wn * W + 4 * q]) = v;
+      }
+      __syncthreads();
+    }
+  } else {
+    // The accumulators hold the TRANSPOSED tile (rows = output columns n, lanes = activation rows m), so
+    // relu(acc + b2) . w3 over this wave's TN*32 columns is a per-lane sum over registers: register r of lane half lh
+    // is column (r & 3) + 8 * (r >> 2) + 4 * lh, i.e. four consecutive columns per group of four registers.
+    float* red = smem;  // [2][BM]
+    const f4* bias4 = reinterpret_cast<const f4*>(g.bias + n0 + wn * (TN * 32) + 4 * lh);
+    const f4* w34 = reinterpret_cast<const f4*>(g.w3 + n0 + wn * (TN * 32) + 4 * lh);
+    float sum[TM];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) sum[a] = 0.0f;
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int grp = 0; grp < 4; ++grp) {
+        const f4 bs = bias4[b * 8 + grp * 2], ws = w34[b * 8 + grp * 2];  // columns b*32 + 8*grp + 4*lh + [0, 4)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sum[a] += fmaxf(acc[a][b][4 * grp + i] + bs[i], 0.0f) * ws[i];
+      }
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const float v = sum[a] + __shfl_xor(sum[a], 32, 64);  // the other lane half holds the other columns
+      if (lh == 0) red[wn * BM_ + wm * (TM * 32) + a * 32 + li] = v;
+    }
+    __syncthreads();
+    if (tid < BM_) {
+      const int64_t row = m0 + tid;
+      if (row < g.M) g.partial[row * g.n_tiles + nt] = red[tid] + red[BM_ + tid];
+    }
+  }
+}
+
+}  // namespace amp

@@ -35,6 +35,8 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(EnvPlan p, AmpSimState
   float* s_acc = s_act + kTileEnvs * ndp;       // [64, ndp]   (reward)
   float* s_red = s_acc + kTileEnvs * ndp;       // [4, 64]     (reward)
   int* s_flag = reinterpret_cast<int*>(s_red + 4 * kTileEnvs);  // [64] just_reset
+  float* s_lim = reinterpret_cast<float*>(s_flag + kTileEnvs);  // [64 | 1, 2*nd + 1] soft joint limits (reward)
+  const int lim_row = 2 * nd + 1;                                // odd stride: conflict-free one-env-per-lane reads
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t tile_base = (int64_t)blockIdx.x * kTileEnvs;
@@ -59,6 +61,13 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(EnvPlan p, AmpSimState
       const int64_t env = tile_base + s;
       s_act[s * ndp + j] = st.actions[env * st.actions_stride + j];
       s_acc[s * ndp + j] = st.joint_acc[env * st.joint_acc_stride + j];
+    }
+    // soft limits: one shared [nd, 2] row (stride 0) or a [64, nd, 2] block, staged with coalesced loads so the
+    // reduction below never waits on a global load per DoF
+    const int lim_rows = st.soft_limits_stride == 0 ? 1 : n_tile;
+    for (int e = tid; e < lim_rows * 2 * nd; e += kBlock) {
+      const int s = e / (2 * nd), c = e - s * 2 * nd;
+      s_lim[s * lim_row + c] = st.soft_limits[(tile_base + s) * st.soft_limits_stride + c];
     }
   }
 
@@ -123,7 +132,7 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(EnvPlan p, AmpSimState
         if (wave == 0) {
           for (int j = 0; j < nd; ++j) { const float a = s_act[lane * ndp + j]; acc += a * a; }
         } else if (wave == 1) {
-          const float* lim = st.soft_limits + (tile_base + lane) * st.soft_limits_stride;
+          const float* lim = s_lim + (st.soft_limits_stride == 0 ? 0 : lane * lim_row);
           for (int j = 0; j < nd; ++j) {
             const float x = s_obs[lane * D + j];
             float o = -fminf(x - lim[2 * j], 0.0f);
@@ -178,19 +187,34 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(EnvPlan p, AmpSimState
     const int K = p.K;
     const int64_t rowK = (int64_t)K * D;
     float* buf = bf.amp_obs_buffer + tile_base * rowK;
-    for (int e = tid; e < n_tile * D; e += kBlock) {
-      const int s = e / D, j = e - s * D;
-      float* col = buf + s * rowK + j;
-      for (int hi = K - 2; hi >= 0; hi -= 4) {
-        float h[4];
+    const int count = n_tile * D;
+    const float inv_d = 1.0f / (float)D;
+    constexpr int U = 4;  // independent columns per lane per trip: their loads are issued before any store
+    for (int e0 = tid; e0 < count; e0 += U * kBlock) {
+      float* col[U];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (hi - i >= 0) h[i] = col[(int64_t)(hi - i) * D];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (hi - i >= 0) col[(int64_t)(hi - i + 1) * D] = h[i];
+      for (int u = 0; u < U; ++u) {
+        int e = e0 + u * kBlock;
+        e = e < count ? e : count - 1;
+        const int s = (int)(((float)e + 0.5f) * inv_d);  // exact: e < 64 * D
+        col[u] = buf + s * rowK + (e - s * D);
       }
-      col[0] = s_obs[e];
+      for (int hi = K - 2; hi >= 0; hi -= 2) {
+        float h[U][2];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            if (hi - i >= 0) h[u][i] = col[u][(int64_t)(hi - i) * D];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            if (hi - i >= 0 && e0 + u * kBlock < count) col[u][(int64_t)(hi - i + 1) * D] = h[u][i];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (e0 + u * kBlock < count) col[u][0] = s_obs[e0 + u * kBlock];
     }
     // policy observation (g1_amp_env.py:195-242; humanoid_amp_env.py:126)
     const int P = p.P, Pcur = p.Pcur, Db = p.Db;
@@ -332,8 +356,9 @@ int amp_env_step(const AmpEnvCfg* cfg, const AmpSimState* st, const AmpEnvBuffer
     AMP_REQUIRE(p.n_actor == 1 || (bf->actor_history && bf->just_reset), "amp_env_step(obs): actor history buffers are null");
     for (int k = 0; k < p.n_key; ++k) AMP_REQUIRE(st->key_body[k] >= 0, "amp_env_step(obs): negative key body index");
   }
+  const bool per_env_limits = g1_rew && st->soft_limits_stride != 0;
   const size_t lds = sizeof(float) * ((size_t)kTileEnvs * p.D + 2 * (size_t)kTileEnvs * p.dof_pad + 4 * kTileEnvs) +
-                     sizeof(int) * kTileEnvs;
+                     sizeof(int) * kTileEnvs + sizeof(float) * (size_t)(per_env_limits ? kTileEnvs : 1) * (2 * p.n_dof + 1);
   AMP_REQUIRE(lds <= 64 * 1024, "amp_env_step: observation tile needs %zu B of LDS (> 64 KiB)", lds);
   const unsigned grid = (unsigned)((N + kTileEnvs - 1) / kTileEnvs);
   { amp::TraceScope trace__("env_step_kernel", (hipStream_t)stream);

@@ -196,15 +196,18 @@ struct ExpertSlot {
   int64_t obase; // float offset of this sample's output row
 };
 
+constexpr int kExpertTile = 64;  // samples per workgroup: many short workgroups hide the L2 gather latency
+constexpr int kExpertUnroll = 4; // independent (gather, gather) pairs in flight per lane
+
 __global__ __launch_bounds__(kBlock) void collect_reference_kernel(MotionView v, const double* __restrict__ times,
                                                                    const int64_t* __restrict__ ids, int64_t n, int K,
                                                                    float* __restrict__ out,
                                                                    const int64_t* __restrict__ dst_rows) {
-  __shared__ ExpertSlot slots[kBlock];
+  __shared__ ExpertSlot slots[kExpertTile];
   const int D = v.D, nd2 = 2 * v.n_dof;
   const int64_t total = n * K;
-  const int64_t tile_base = (int64_t)blockIdx.x * kBlock;
-  const int n_tile = (int)((total - tile_base) < kBlock ? (total - tile_base) : kBlock);
+  const int64_t tile_base = (int64_t)blockIdx.x * kExpertTile;
+  const int n_tile = (int)((total - tile_base) < kExpertTile ? (total - tile_base) : kExpertTile);
   const float* __restrict__ hot = v.hot;
   if (threadIdx.x < n_tile) {
     const int64_t sidx = tile_base + threadIdx.x;
@@ -234,27 +237,35 @@ __global__ __launch_bounds__(kBlock) void collect_reference_kernel(MotionView v,
     slots[threadIdx.x] = sl;
   }
   __syncthreads();
-  const int step_s = kBlock / D, step_j = kBlock % D;
-  int s = threadIdx.x / D, j = threadIdx.x % D;
-  for (int e = threadIdx.x; e < n_tile * D; e += kBlock) {
-    const ExpertSlot& sl = slots[s];
-    float val;
-    if (j > nd2 && j <= nd2 + 6) {
-      val = sl.tn[j - nd2 - 1];
-    } else {
-      const int col = (j == nd2) ? nd2 + 2 : j;  // feature "root height" reads the z column
-      val = lerp_ref(hot[(int64_t)sl.i0 * D + col], hot[(int64_t)sl.i1 * D + col], sl.blend);
-      if (j >= nd2 + 13) {
-        int ax = (j - nd2 - 13) % 3;
-        val = val - sl.rp[ax];  // key body position relative to the reference body (g1_amp_env.py:552)
-      }
+  // flat walk over the tile's n_tile*D output floats, kExpertUnroll independent elements per lane per trip:
+  // all gathers of a trip are issued before the first LERP / store
+  const int count = n_tile * D;
+  const float inv_d = 1.0f / (float)D;
+  for (int e0 = threadIdx.x; e0 < count; e0 += kExpertUnroll * kBlock) {
+    int sv[kExpertUnroll], jv[kExpertUnroll];
+    float av[kExpertUnroll], bv[kExpertUnroll];
+#pragma unroll
+    for (int u = 0; u < kExpertUnroll; ++u) {
+      int e = e0 + u * kBlock;
+      e = e < count ? e : count - 1;
+      const int s = (int)(((float)e + 0.5f) * inv_d);  // exact for e < 2^16 (|error| << 0.5 / D)
+      const int j = e - s * D;
+      sv[u] = s;
+      jv[u] = j;
+      const int col = (j >= nd2 && j <= nd2 + 6) ? nd2 + 2 : j;  // root height reads the z column; tangent|normal come from LDS
+      av[u] = hot[(int64_t)slots[s].i0 * D + col];
+      bv[u] = hot[(int64_t)slots[s].i1 * D + col];
     }
-    out[sl.obase + j] = val;
-    s += step_s;
-    j += step_j;
-    if (j >= D) {
-      j -= D;
-      s += 1;
+#pragma unroll
+    for (int u = 0; u < kExpertUnroll; ++u) {
+      if (e0 + u * kBlock < count) {
+        const ExpertSlot& sl = slots[sv[u]];
+        const int j = jv[u];
+        float val = lerp_ref(av[u], bv[u], sl.blend);
+        if (j > nd2 && j <= nd2 + 6) val = sl.tn[j - nd2 - 1];
+        if (j >= nd2 + 13) val = val - sl.rp[(j - nd2 - 13) % 3];  // key body relative to the reference body (:552)
+        out[sl.obase + j] = val;
+      }
     }
   }
 }
@@ -471,7 +482,7 @@ int amp_collect_reference(const AmpMotion* h, const double* times, const int64_t
   if (n == 0) return AMP_OK;
   AMP_REQUIRE(times && out, "amp_collect_reference: null buffer");
   { amp::TraceScope trace__("collect_reference_kernel", (hipStream_t)stream);
-    collect_reference_kernel<<<grid_for(n * K, kBlock), kBlock, 0, (hipStream_t)stream>>>(h->v, times, ids, n, K, out, dst_rows);
+    collect_reference_kernel<<<grid_for(n * K, kExpertTile), kBlock, 0, (hipStream_t)stream>>>(h->v, times, ids, n, K, out, dst_rows);
   }
   return launch_status("collect_reference_kernel");
 }

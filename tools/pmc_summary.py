@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Per-kernel means of rocprofv3 --pmc counter_collection CSVs (one or more passes).
+
+    python tools/pmc_summary.py gpurun_out/pmc_sq/*/*_counter_collection.csv [more.csv ...]
+"""
+import csv
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    for junk in ("void ", "amp::"):
+        name = name.replace(junk, "")
+    return name.split("(")[0][:48]
+
+
+def main(paths):
+    acc = defaultdict(lambda: defaultdict(list))
+    for path in paths:
+        per_dispatch = defaultdict(dict)
+        with open(path, newline="") as fh:
+            for row in csv.DictReader(fh):
+                key = (row["Dispatch_Id"], short(row["Kernel_Name"]), int(row["Grid_Size"]) // max(int(row["Workgroup_Size"]), 1))
+                per_dispatch[key][row["Counter_Name"]] = per_dispatch[key].get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+        for (_, name, grid), counters in per_dispatch.items():
+            for c, v in counters.items():
+                acc[(name, grid)][c].append(v)
+    counters = sorted({c for d in acc.values() for c in d})
+    print("| kernel | workgroups | launches | " + " | ".join(counters) + " |")
+    print("|---|---|---|" + "---|" * len(counters))
+    for (name, grid), d in sorted(acc.items(), key=lambda kv: -max(len(v) for v in kv[1].values())):
+        if name.startswith("at::") or name.startswith("__amd"):
+            continue
+        n = max(len(v) for v in d.values())
+        print(f"| {name} | {grid} | {n} | " + " | ".join(f"{sum(d[c]) / len(d[c]):.4g}" if c in d else "" for c in counters) + " |")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
