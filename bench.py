@@ -68,7 +68,7 @@ def timed_steps(hot, steps, warmup, world, collective):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
@@ -158,11 +158,17 @@ def main():
             sys.exit(2)
     import torch.distributed as dist
 
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # rehearsal knobs (CPU-side plumbing tests on a one-GPU box): AMP_BENCH_BACKEND=gloo, AMP_BENCH_DEVICE=0
+    dev_index = int(os.environ.get("AMP_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+        backend = os.environ.get("AMP_BENCH_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm (xGMI inside a node)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     import humanoid_amp_amd  # noqa: F401  (fails loudly if libamp_engine.so is missing)
     from humanoid_amp_amd import _native as nat

@@ -105,7 +105,7 @@ SIGNATURES = {
     "amp_disc_destroy": (C.c_int, [_vp]),
     "amp_disc_set_scaler": (C.c_int, [_vp, _vp, _vp, _f32, _f32, _vp]),
     "amp_disc_workspace_bytes": (_i64, [_vp, _i64]),
-    "amp_disc_style_reward": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "amp_disc_style_reward": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

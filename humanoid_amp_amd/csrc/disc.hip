@@ -90,9 +90,12 @@ __global__ void disc_pad_rows_kernel(const float* __restrict__ src, int rows, in
 __global__ __launch_bounds__(kBlock) void disc_scale_pad_kernel(const float* __restrict__ x, int64_t row_stride, int64_t M,
                                                                 int k, int kp, const float* __restrict__ mean,
                                                                 const float* __restrict__ den, float clip,
-                                                                float* __restrict__ xs) {
+                                                                float* __restrict__ xs, const float* __restrict__ task,
+                                                                float* __restrict__ task_copy) {
   const int q_per_row = kp >> 2;
   const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  // snapshot of the task reward: after this kernel the caller may overwrite amp_obs AND task_reward (next env step)
+  if (task && e < M) task_copy[e] = task[e];
   if (e >= M * q_per_row) return;
   const int64_t m = e / q_per_row;
   const int c0 = (int)(e - m * q_per_row) * 4;
@@ -203,12 +206,13 @@ int64_t amp_disc_workspace_bytes(const AmpDisc* h, int64_t rows) {
   const int64_t xs_bytes = round_up((int64_t)sizeof(float) * rows * h->k1p, 256);
   const int64_t h1_bytes = round_up((int64_t)sizeof(float) * rows * h->h1, 256);
   const int64_t part_bytes = round_up((int64_t)sizeof(float) * rows * (h->h2 / 64), 256);
-  return xs_bytes + h1_bytes + part_bytes;
+  const int64_t task_bytes = round_up((int64_t)sizeof(float) * rows, 256);
+  return xs_bytes + h1_bytes + part_bytes + task_bytes;
 }
 
 int amp_disc_style_reward(const AmpDisc* h, const float* x, int64_t rows, int64_t row_stride, float scale, const float* task,
                           float task_w, float style_w, float* logits, float* style, float* combined, void* workspace,
-                          amp_stream_t stream) {
+                          amp_event_t inputs_consumed, amp_stream_t stream) {
   AMP_REQUIRE(h, "amp_disc_style_reward: null handle");
   AMP_REQUIRE(rows >= 0, "amp_disc_style_reward: negative rows");
   if (rows == 0) return AMP_OK;
@@ -220,6 +224,7 @@ int amp_disc_style_reward(const AmpDisc* h, const float* x, int64_t rows, int64_
   float* Xs = (float*)workspace;
   float* H1 = (float*)((char*)Xs + round_up((int64_t)sizeof(float) * rows * h->k1p, 256));
   float* partial = (float*)((char*)H1 + round_up((int64_t)sizeof(float) * rows * h->h1, 256));
+  float* task_copy = (float*)((char*)partial + round_up((int64_t)sizeof(float) * rows * (h->h2 / 64), 256));
   // Tile choice, measured on MI355X with tools/gemm_bench.hip (interleaved rounds, profiles/r01_gemm_variants.txt):
   // 128 x 128 x 16 with one LDS stage at 4 workgroups per CU wins whenever it yields >= 512 workgroups; smaller
   // shards use 64 x 64 tiles so that every CU still gets several workgroups (a 4096-row layer 2 is only 128 tiles
@@ -229,10 +234,12 @@ int amp_disc_style_reward(const AmpDisc* h, const float* x, int64_t rows, int64_
     const int64_t quads = rows * (h->k1p / 4);
     amp::TraceScope trace__("disc_scale_pad_kernel", st);
     disc_scale_pad_kernel<<<(unsigned)((quads + kBlock - 1) / kBlock), kBlock, 0, st>>>(
-        x, row_stride, rows, h->in_dim, h->k1p, h->has_scaler ? h->mean : nullptr, h->den, h->clip, Xs);
+        x, row_stride, rows, h->in_dim, h->k1p, h->has_scaler ? h->mean : nullptr, h->den, h->clip, Xs, task, task_copy);
   }
   int rc = launch_status("disc_scale_pad_kernel");
   if (rc != AMP_OK) return rc;
+  // everything the caller handed in (amp_obs, task reward) has been consumed once this point of the stream is reached
+  if (inputs_consumed) AMP_HIP(hipEventRecord((hipEvent_t)inputs_consumed, st));
 
   GemmArgs g1{};
   g1.A = Xs; g1.lda = h->k1p; g1.M = rows; g1.K = h->k1p;
@@ -267,7 +274,7 @@ int amp_disc_style_reward(const AmpDisc* h, const float* x, int64_t rows, int64_
   if (rc != AMP_OK) return rc;
 
   { amp::TraceScope trace__("disc_finalize_kernel", st);
-    disc_finalize_kernel<<<(unsigned)((rows + kBlock - 1) / kBlock), kBlock, 0, st>>>(partial, g2.n_tiles, h->b3, rows, scale, task,
+    disc_finalize_kernel<<<(unsigned)((rows + kBlock - 1) / kBlock), kBlock, 0, st>>>(partial, g2.n_tiles, h->b3, rows, scale, task ? task_copy : nullptr,
                                                                                    task_w, style_w, logits, style, combined);
   }
   return launch_status("disc_finalize_kernel");

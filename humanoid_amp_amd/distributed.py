@@ -39,6 +39,11 @@ def allgather_minibatch(shard: torch.Tensor, out: torch.Tensor | None = None, gr
         raise ValueError("out has the wrong shape")
     if world == 1:
         out.copy_(shard)
+    elif shard.is_cuda and dist.get_backend(group) != "nccl":
+        # rehearsal path only (gloo has no device collectives): stage through the host
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, shard.cpu(), group=group)
+        out.copy_(host)
     else:
         dist.all_gather_into_tensor(out, shard, group=group)
     return out

@@ -255,14 +255,22 @@ class AmpDiscriminator:
                                                     nat.stream_ptr()), "amp_disc_set_scaler")
             torch.cuda.current_stream().synchronize()  # m / v are temporaries
 
-    def _workspace(self, rows: int) -> torch.Tensor:
+    def _workspace(self, rows: int, slot: int = 0) -> torch.Tensor:
         need = int(self._lib.amp_disc_workspace_bytes(self._handle, rows))
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._ws
+        if self._ws is None:
+            self._ws = {}
+        ws = self._ws.get(slot)
+        if ws is None or ws.numel() < need:
+            ws = self._ws[slot] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return ws
 
-    def style_reward(self, amp_obs: torch.Tensor, task_reward: Optional[torch.Tensor] = None, *, want_logits: bool = False):
-        """amp_obs [M, K*D] -> dict(style [M,1], combined [M,1] (if task_reward given), logits [M,1] (optional))."""
+    def style_reward(self, amp_obs: torch.Tensor, task_reward: Optional[torch.Tensor] = None, *, want_logits: bool = False,
+                     inputs_consumed: Optional[torch.cuda.Event] = None, workspace_slot: int = 0):
+        """amp_obs [M, K*D] -> dict(style [M,1], combined [M,1] (if task_reward given), logits [M,1] (optional)).
+
+        ``inputs_consumed`` (a torch.cuda.Event) is recorded on the current stream right after the last read of
+        ``amp_obs`` / ``task_reward``; ``workspace_slot`` selects one of several private workspaces so that two calls
+        may be in flight on the same stream queue (see workloads.HotPath, overlap=True)."""
         if amp_obs.dim() != 2 or amp_obs.shape[1] != self.in_dim or amp_obs.dtype != torch.float32 or amp_obs.stride(1) != 1:
             raise nat.AmpEngineError(f"amp_obs must be float32 [M, {self.in_dim}] with a contiguous last dim")
         nat.require_gpu(amp_obs.device)
@@ -276,12 +284,13 @@ class AmpDiscriminator:
             if task.numel() != M:
                 raise nat.AmpEngineError("task_reward must have one entry per row")
             combined = torch.empty((M, 1), **f32)
-        ws = self._workspace(M)
+        ws = self._workspace(M, workspace_slot)
+        ev = C.c_void_p(inputs_consumed.cuda_event) if inputs_consumed is not None else C.c_void_p(None)
         with torch.cuda.device(self.device):
             nat.check(self._lib.amp_disc_style_reward(self._handle, C.c_void_p(amp_obs.data_ptr()), M, int(amp_obs.stride(0)) if M > 1 else self.in_dim,
                                                       self.reward_scale, nat.dptr(task), self.task_reward_weight,
                                                       self.style_reward_weight, nat.dptr(logits), nat.dptr(style),
-                                                      nat.dptr(combined), nat.dptr(ws), nat.stream_ptr()),
+                                                      nat.dptr(combined), nat.dptr(ws), ev, nat.stream_ptr()),
                       "amp_disc_style_reward")
         out = {"style": style}
         if combined is not None:

@@ -84,8 +84,16 @@ def disc_flops_per_row(in_dim: int, h1: int = 1024, h2: int = 512) -> int:
 class HotPath:
     """All device state of one env shard + ``step()`` = one env-step of the hot path."""
 
-    def __init__(self, spec: WorkloadSpec, num_envs: int, device, seed: int = 0, log_reward_terms: bool = False):
+    def __init__(self, spec: WorkloadSpec, num_envs: int, device, seed: int = 0, log_reward_terms: bool = False,
+                 overlap: bool = False):
+        """``overlap``: run the discriminator on a second HIP stream so that the HBM-bound kernels of step t+1
+        (motion sample, env step, compaction) execute under the MFMA-bound GEMMs of step t.  The style reward is
+        consumed asynchronously in AMP (skrl reads it at the agent update), so nothing waits for it inside a step;
+        ``synchronize()`` / ``torch.cuda.synchronize()`` joins both streams.  Bit-identical to the serial schedule
+        (tests/test_gpu_disc.py).  Measured on MI355X it is a wash (+1.5 % at 65 536 envs, -10 % at 4 096): the GEMM
+        workgroups already hold every wave slot, so the two streams time-slice instead of overlapping -> default off."""
         self.spec, self.num_envs = spec, int(num_envs)
+        self.overlap = bool(overlap)
         self.device = nat.require_gpu(device)
         files = ",".join(os.path.join(MOTIONS_DIR, c + ".npz") for c in spec.clips)
         self.motion = MotionLoader(files, self.device)
@@ -118,14 +126,41 @@ class HotPath:
             for k in ("joint_acc", "actions", "soft_limits", "command", "last_actions"):
                 self._sim.pop(k)
         self.last = None
+        self._n = 0
+        if self.overlap:
+            self._disc_stream = torch.cuda.Stream(device=self.device)
+            self._obs_ready = torch.cuda.Event()
+            self._consumed = [torch.cuda.Event(), torch.cuda.Event()]
+            for ev in self._consumed:  # torch creates the hipEvent lazily: force it, the C ABI needs the handle
+                ev.record(self._disc_stream)
+            # warm both workspaces + output tensors on the side stream
+            with torch.cuda.stream(self._disc_stream):
+                for slot in (0, 1):
+                    self.disc._workspace(self.num_envs, slot)
 
     def step(self):
         s, k = self.state, self.kernel
+        env_stream = torch.cuda.current_stream(self.device)
+        if self.overlap and self._n > 0:
+            # the previous discriminator call must have read amp_obs / reward before this step shifts / rewrites them
+            env_stream.wait_event(self._consumed[(self._n - 1) & 1])
         self.motion.collect_reference(s["motion_times"], s["motion_ids"], self.spec.K, out=self.expert_obs)
         k.launch(nat.AMP_PHASE_ALL, key_body_indexes=[0, 1, 2, 3], **self._sim)
         k.compact_resets()
-        self.last = self.disc.style_reward(k.amp_observation_buffer.view(self.num_envs, -1), k.reward)
+        amp = k.amp_observation_buffer.view(self.num_envs, -1)
+        if not self.overlap:
+            self.last = self.disc.style_reward(amp, k.reward)
+        else:
+            slot = self._n & 1
+            self._obs_ready.record(env_stream)
+            with torch.cuda.stream(self._disc_stream):
+                self._disc_stream.wait_event(self._obs_ready)
+                self.last = self.disc.style_reward(amp, k.reward, inputs_consumed=self._consumed[slot], workspace_slot=slot)
+        self._n += 1
         return self.last
+
+    def synchronize(self):
+        torch.cuda.synchronize(self.device)
 
 
 def make_disc_weights(in_dim: int, seed: int = 0, hidden=(1024, 512)):

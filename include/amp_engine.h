@@ -28,6 +28,7 @@ extern "C" {
 #define AMP_ABI_VERSION 1
 
 typedef void* amp_stream_t; /* hipStream_t */
+typedef void* amp_event_t;  /* hipEvent_t  */
 typedef struct AmpMotion AmpMotion;
 typedef struct AmpDisc AmpDisc;
 
@@ -216,11 +217,15 @@ int amp_disc_set_scaler(AmpDisc* h, const double* running_mean_dev, const double
 int64_t amp_disc_workspace_bytes(const AmpDisc* h, int64_t rows);
 /* amp_obs_dev [rows, in_dim] (row stride in elements) -> logits [rows], style [rows] =
  * -log(max(1 - sigmoid(logit), 1e-4)) * reward_scale, combined = task_w * task + style_w * style.
- * logits / style / task / combined may be NULL. */
+ * logits / style / task / combined may be NULL.
+ * amp_obs and task_reward are read only by the first kernel (scaler pass, which also snapshots the task reward
+ * into the workspace); `inputs_consumed` (hipEvent_t, may be NULL) is recorded on `stream` right after it, so a
+ * caller running the env on another stream may overwrite both buffers (the in-place AMP history shift of the next
+ * env step) as soon as that event has completed, while the GEMMs are still running. */
 int amp_disc_style_reward(const AmpDisc* h, const float* amp_obs_dev, int64_t rows, int64_t row_stride,
                           float reward_scale, const float* task_reward_dev, float task_weight, float style_weight,
                           float* logits_dev, float* style_dev, float* combined_dev, void* workspace_dev,
-                          amp_stream_t stream);
+                          amp_event_t inputs_consumed, amp_stream_t stream);
 
 #ifdef __cplusplus
 }

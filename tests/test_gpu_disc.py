@@ -84,3 +84,27 @@ def test_disc_full_size_linearity_property():
     assert torch.equal(c, a[perm])
     sub = odisc.forward(w, x[:256].cpu())
     assert float((a[:256].cpu() - sub["logits"]).abs().max()) <= 2e-5
+
+
+def test_overlapped_hot_path_matches_serial():
+    """Two-stream pipelining (discriminator of step t under the env kernels of step t+1) must not change a bit:
+    same style / combined rewards, same buffers as the serial schedule, over several steps."""
+    import contextlib
+    import io
+
+    from humanoid_amp_amd.workloads import WORKLOADS, HotPath
+
+    outs = {}
+    for overlap in (False, True):
+        with contextlib.redirect_stdout(io.StringIO()):
+            hot = HotPath(WORKLOADS["g1_walk"], 20000, "cuda:0", seed=3, overlap=overlap)
+        rec = []
+        for _ in range(6):
+            r = hot.step()
+            rec.append((r["style"], r["combined"]))
+        hot.synchronize()
+        outs[overlap] = (rec, hot.kernel.amp_observation_buffer.clone(), hot.kernel.reward.clone(), hot.kernel.reset_ids.clone())
+    for (s0, c0), (s1, c1) in zip(outs[False][0], outs[True][0]):
+        assert torch.equal(s0, s1) and torch.equal(c0, c1)
+    for a, b in zip(outs[False][1:], outs[True][1:]):
+        assert torch.equal(a, b)
