@@ -200,6 +200,15 @@ def main():
 
     out = None
     if rank == 0:
+        # HBM traffic of the dominant kernel: PMC FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE per launch, collected
+        # in separate rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh) and committed
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            wg = {k.split("@")[0]: k for k in tj if k.endswith(f"@{(args.envs + 127) // 128 * 4}")}
+            traffic = tj[wg[DOMINANT_KERNEL.replace("<1>", "<128, 128, 16, 1, 1, 4>")]]["hbm_bytes"] if args.envs >= 16384 else None
+        except Exception:
+            traffic = None
         flops2 = 2.0 * args.envs * 1024 * 512 + 2.0 * args.envs * 512   # layer 2 + the fused 512 -> 1 dot
         achieved = flops2 / (gemm2_ms * 1e-3) / 1e12
         hbm_kernels = ("collect_reference_kernel", "env_step_kernel", "compact_scatter_kernel")
@@ -215,7 +224,7 @@ def main():
                        "collective": (f"RCCL all-gather [{args.replay_minibatch},{spec.K * spec.D}] f32 per rank x "
                                       f"{args.minibatches} every {args.rollouts} steps") if world > 1 else "none"},
             "roofline": {"bound": "mfma", "kernel": DOMINANT_KERNEL, "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
                          "avg_launch_ms": gemm2_ms, "launches_timed": len(recs), "flops_per_launch": flops2},
             "roofline_hbm": {"bound": "hbm", "kernels": list(hbm_kernels), "achieved": alg_bytes / (hbm_us * 1e-6) / 1e9 if hbm_us else None,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (alg_bytes / (hbm_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if hbm_us else None,
