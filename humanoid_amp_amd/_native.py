@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libamp_engine.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 AMP_PHASE_DONES, AMP_PHASE_REWARD, AMP_PHASE_OBS = 1, 2, 4
 AMP_PHASE_ALL = 7
@@ -67,6 +67,8 @@ class AmpEnvBuffers(C.Structure):
         ("amp_obs_buffer", C.c_void_p), ("policy_obs", C.c_void_p), ("actor_history", C.c_void_p),
         ("just_reset", C.c_void_p), ("reward", C.c_void_p), ("reward_terms", C.c_void_p), ("died", C.c_void_p),
         ("time_out", C.c_void_p), ("reset_mask", C.c_void_p), ("reset_tile_counts", C.c_void_p),
+        ("disc_input", C.c_void_p), ("disc_input_stride", C.c_int64), ("scaler_mean", C.c_void_p), ("scaler_den", C.c_void_p),
+        ("scaler_clip", C.c_float), ("reserved", C.c_int32),
     ]
 
 
@@ -100,11 +102,14 @@ SIGNATURES = {
     "amp_env_step": (C.c_int, [C.POINTER(AmpEnvCfg), C.POINTER(AmpSimState), C.POINTER(AmpEnvBuffers), _i64, C.c_uint32, _vp]),
     "amp_reset_compact_workspace_bytes": (_i64, [_i64]),
     "amp_reset_compact": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
-    "amp_reset_compact_tiles": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "amp_reset_compact_tiles": (C.c_int, [_vp, _vp, _i32, _i64, _vp, _vp, _vp]),
+    "amp_env_step_tile_envs": (_i32, [_i64]),
     "amp_disc_create": (C.c_int, [C.POINTER(AmpDiscDesc), _vp, C.POINTER(_vp)]),
     "amp_disc_destroy": (C.c_int, [_vp]),
     "amp_disc_set_scaler": (C.c_int, [_vp, _vp, _vp, _f32, _f32, _vp]),
     "amp_disc_workspace_bytes": (_i64, [_vp, _i64]),
+    "amp_disc_input_layout": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_f32)]),
+    "amp_disc_style_reward_prescaled": (C.c_int, [_vp, _vp, _i64, _f32, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "amp_disc_style_reward": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
@@ -119,12 +124,16 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP engine has not been built.  Run "
-            "`python -c \"import __graft_entry__ as g; g.build()\"` (needs hipcc, cross-compiles gfx950).  "
+            "`python humanoid_amp_amd/build.py` or `python -c \"import __graft_entry__ as g; g.build()\"` (needs hipcc, "
+            "cross-compiles gfx950).  "
             "humanoid_amp_amd has no CPU fallback."
         )
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        if not hasattr(lib, name):
+            raise ImportError(f"{LIB_PATH} does not export {name}: the library is stale, rebuild it with "
+                              "`python humanoid_amp_amd/build.py` (humanoid_amp_amd has no CPU fallback)")
+        fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
     got = lib.amp_abi_version()

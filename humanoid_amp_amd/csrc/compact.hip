@@ -23,9 +23,11 @@ __global__ __launch_bounds__(kBlock) void tile_count_kernel(const uint8_t* __res
   }
 }
 
+// counts[] holds one entry per `64 / sub` envs (sub = 1, 2 or 4 count entries per 64-env wave tile)
 __global__ __launch_bounds__(kBlock) void compact_scatter_kernel(const uint8_t* __restrict__ mask,
                                                                  const int32_t* __restrict__ counts, int64_t N,
-                                                                 int64_t n_tiles, int64_t* __restrict__ ids,
+                                                                 int64_t n_tiles, int sub, int64_t n_counts,
+                                                                 int64_t* __restrict__ ids,
                                                                  int64_t* __restrict__ count_out) {
   __shared__ long long s_part[kBlock / kWave];
   __shared__ long long s_base;
@@ -33,7 +35,7 @@ __global__ __launch_bounds__(kBlock) void compact_scatter_kernel(const uint8_t* 
   const int64_t first_tile = (int64_t)blockIdx.x * (kBlock / kTile);
   // exclusive prefix of the tile counts before this workgroup
   long long acc = 0;
-  for (int64_t t = tid; t < first_tile; t += kBlock) acc += counts[t];
+  for (int64_t t = tid; t < first_tile * sub; t += kBlock) acc += counts[t];
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   if (lane == 0) s_part[wave] = acc;
   __syncthreads();
@@ -41,10 +43,7 @@ __global__ __launch_bounds__(kBlock) void compact_scatter_kernel(const uint8_t* 
   __syncthreads();
   long long base = s_base;
   const int64_t my_tile = first_tile + wave;
-  for (int w = 0; w < wave; ++w) {
-    const int64_t t = first_tile + w;
-    if (t < n_tiles) base += counts[t];
-  }
+  for (int64_t c = first_tile * sub; c < my_tile * sub && c < n_counts; ++c) base += counts[c];
   const int64_t i = my_tile * kTile + lane;
   const int bit = (i < N) ? (mask[i] != 0) : 0;
   const unsigned long long b = __ballot(bit);
@@ -67,8 +66,8 @@ int64_t amp_reset_compact_workspace_bytes(int64_t N) {
   return (int64_t)sizeof(int32_t) * ((N + kTile - 1) / kTile + 1);
 }
 
-int amp_reset_compact_tiles(const uint8_t* mask, const int32_t* counts, int64_t N, int64_t* ids, int64_t* count,
-                            amp_stream_t stream) {
+int amp_reset_compact_tiles(const uint8_t* mask, const int32_t* counts, int32_t tile_envs, int64_t N, int64_t* ids,
+                            int64_t* count, amp_stream_t stream) {
   AMP_REQUIRE(N >= 0, "amp_reset_compact: negative num_envs");
   AMP_REQUIRE(count, "amp_reset_compact: count pointer is null");
   if (N == 0) {
@@ -76,10 +75,13 @@ int amp_reset_compact_tiles(const uint8_t* mask, const int32_t* counts, int64_t 
     return AMP_OK;
   }
   AMP_REQUIRE(mask && counts && ids, "amp_reset_compact: null buffer");
+  AMP_REQUIRE(tile_envs == 16 || tile_envs == 32 || tile_envs == 64, "amp_reset_compact: tile_envs must be 16, 32 or 64");
+  const int sub = kTile / tile_envs;
+  const int64_t n_counts = (N + tile_envs - 1) / tile_envs;
   const int64_t n_tiles = (N + kTile - 1) / kTile;
   const unsigned grid = (unsigned)((n_tiles + 3) / 4);
   { amp::TraceScope trace__("compact_scatter_kernel", (hipStream_t)stream);
-    compact_scatter_kernel<<<grid, kBlock, 0, (hipStream_t)stream>>>(mask, counts, N, n_tiles, ids, count);
+    compact_scatter_kernel<<<grid, kBlock, 0, (hipStream_t)stream>>>(mask, counts, N, n_tiles, sub, n_counts, ids, count);
   }
   return launch_status("compact_scatter_kernel");
 }
@@ -95,7 +97,7 @@ int amp_reset_compact(const uint8_t* mask, int64_t N, int64_t* ids, int64_t* cou
     int rc = launch_status("tile_count_kernel");
     if (rc != AMP_OK) return rc;
   }
-  return amp_reset_compact_tiles(mask, (const int32_t*)workspace, N, ids, count, stream);
+  return amp_reset_compact_tiles(mask, (const int32_t*)workspace, kTile, N, ids, count, stream);
 }
 
 }  // extern "C"

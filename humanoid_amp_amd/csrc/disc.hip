@@ -121,6 +121,57 @@ static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * 
 
 }  // namespace amp
 
+namespace amp {
+// layers 1-2 + finalize on a scaled, padded input Xs [rows, k1p]
+static int disc_forward(const AmpDisc* h, const float* Xs, int64_t rows, float* H1, float* partial, float scale,
+                        const float* task, float task_w, float style_w, float* logits, float* style, float* combined,
+                        hipStream_t st) {
+  // Tile choice, measured on MI355X with tools/gemm_bench.hip (interleaved rounds, profiles/r01_gemm_variants.txt):
+  // 128 x 128 x 16 with one LDS stage at 4 workgroups per CU wins whenever it yields >= 512 workgroups; smaller
+  // shards use 64 x 64 tiles so that every CU still gets several workgroups (a 4096-row layer 2 is only 128 tiles
+  // of 128 x 128: 74 us vs 40 us).
+  auto big_tiles = [&](int N) { return (rows + 127) / 128 * (N / 128) >= 512; };
+  int rc = AMP_OK;
+  GemmArgs g1{};
+  g1.A = Xs; g1.lda = h->k1p; g1.M = rows; g1.K = h->k1p;
+  g1.W = h->w1p; g1.Kp = h->k1p; g1.bias = h->b1; g1.N = h->h1;
+  g1.C = H1; g1.ldc = h->h1;
+  {
+    const bool big = big_tiles(h->h1);
+    const int bm = big ? 128 : 64;
+    g1.n_tiles = h->h1 / bm; g1.m_tiles = (int)((rows + bm - 1) / bm);
+    const unsigned grid = (unsigned)(((int64_t)g1.m_tiles * g1.n_tiles + 7) / 8 * 8);
+    amp::TraceScope trace__("disc_gemm_kernel<0>", st);
+    if (big) disc_gemm_kernel<128, 128, 16, 1, 0, 4><<<grid, kBlock, 0, st>>>(g1);
+    else disc_gemm_kernel<64, 64, 16, 1, 0, 8><<<grid, kBlock, 0, st>>>(g1);
+  }
+  rc = launch_status("disc_gemm_kernel<0>");
+  if (rc != AMP_OK) return rc;
+
+  GemmArgs g2{};
+  g2.A = H1; g2.lda = h->h1; g2.M = rows; g2.K = h->h1;
+  g2.W = h->w2; g2.Kp = h->h1; g2.bias = h->b2; g2.N = h->h2;
+  g2.w3 = h->w3; g2.partial = partial;
+  {
+    const bool big = big_tiles(h->h2);
+    const int bm = big ? 128 : 64;
+    g2.n_tiles = h->h2 / bm; g2.m_tiles = (int)((rows + bm - 1) / bm);
+    const unsigned grid = (unsigned)(((int64_t)g2.m_tiles * g2.n_tiles + 7) / 8 * 8);
+    amp::TraceScope trace__("disc_gemm_kernel<1>", st);
+    if (big) disc_gemm_kernel<128, 128, 16, 1, 1, 4><<<grid, kBlock, 0, st>>>(g2);
+    else disc_gemm_kernel<64, 64, 32, 1, 1, 4><<<grid, kBlock, 0, st>>>(g2);
+  }
+  rc = launch_status("disc_gemm_kernel<1>");
+  if (rc != AMP_OK) return rc;
+
+  { amp::TraceScope trace__("disc_finalize_kernel", st);
+    disc_finalize_kernel<<<(unsigned)((rows + kBlock - 1) / kBlock), kBlock, 0, st>>>(partial, g2.n_tiles, h->b3, rows, scale, task,
+                                                                                   task_w, style_w, logits, style, combined);
+  }
+  return launch_status("disc_finalize_kernel");
+}
+}  // namespace amp
+
 using namespace amp;
 
 extern "C" {
@@ -225,11 +276,6 @@ int amp_disc_style_reward(const AmpDisc* h, const float* x, int64_t rows, int64_
   float* H1 = (float*)((char*)Xs + round_up((int64_t)sizeof(float) * rows * h->k1p, 256));
   float* partial = (float*)((char*)H1 + round_up((int64_t)sizeof(float) * rows * h->h1, 256));
   float* task_copy = (float*)((char*)partial + round_up((int64_t)sizeof(float) * rows * (h->h2 / 64), 256));
-  // Tile choice, measured on MI355X with tools/gemm_bench.hip (interleaved rounds, profiles/r01_gemm_variants.txt):
-  // 128 x 128 x 16 with one LDS stage at 4 workgroups per CU wins whenever it yields >= 512 workgroups; smaller
-  // shards use 64 x 64 tiles so that every CU still gets several workgroups (a 4096-row layer 2 is only 128 tiles
-  // of 128 x 128: 74 us vs 40 us).
-  auto big_tiles = [&](int N) { return (rows + 127) / 128 * (N / 128) >= 512; };
   {
     const int64_t quads = rows * (h->k1p / 4);
     amp::TraceScope trace__("disc_scale_pad_kernel", st);
@@ -241,43 +287,31 @@ int amp_disc_style_reward(const AmpDisc* h, const float* x, int64_t rows, int64_
   // everything the caller handed in (amp_obs, task reward) has been consumed once this point of the stream is reached
   if (inputs_consumed) AMP_HIP(hipEventRecord((hipEvent_t)inputs_consumed, st));
 
-  GemmArgs g1{};
-  g1.A = Xs; g1.lda = h->k1p; g1.M = rows; g1.K = h->k1p;
-  g1.W = h->w1p; g1.Kp = h->k1p; g1.bias = h->b1; g1.N = h->h1;
-  g1.C = H1; g1.ldc = h->h1;
-  {
-    const bool big = big_tiles(h->h1);
-    const int bm = big ? 128 : 64;
-    g1.n_tiles = h->h1 / bm; g1.m_tiles = (int)((rows + bm - 1) / bm);
-    const unsigned grid = (unsigned)(((int64_t)g1.m_tiles * g1.n_tiles + 7) / 8 * 8);
-    amp::TraceScope trace__("disc_gemm_kernel<0>", st);
-    if (big) disc_gemm_kernel<128, 128, 16, 1, 0, 4><<<grid, kBlock, 0, st>>>(g1);
-    else disc_gemm_kernel<64, 64, 16, 1, 0, 8><<<grid, kBlock, 0, st>>>(g1);
-  }
-  rc = launch_status("disc_gemm_kernel<0>");
-  if (rc != AMP_OK) return rc;
-
-  GemmArgs g2{};
-  g2.A = H1; g2.lda = h->h1; g2.M = rows; g2.K = h->h1;
-  g2.W = h->w2; g2.Kp = h->h1; g2.bias = h->b2; g2.N = h->h2;
-  g2.w3 = h->w3; g2.partial = partial;
-  {
-    const bool big = big_tiles(h->h2);
-    const int bm = big ? 128 : 64;
-    g2.n_tiles = h->h2 / bm; g2.m_tiles = (int)((rows + bm - 1) / bm);
-    const unsigned grid = (unsigned)(((int64_t)g2.m_tiles * g2.n_tiles + 7) / 8 * 8);
-    amp::TraceScope trace__("disc_gemm_kernel<1>", st);
-    if (big) disc_gemm_kernel<128, 128, 16, 1, 1, 4><<<grid, kBlock, 0, st>>>(g2);
-    else disc_gemm_kernel<64, 64, 32, 1, 1, 4><<<grid, kBlock, 0, st>>>(g2);
-  }
-  rc = launch_status("disc_gemm_kernel<1>");
-  if (rc != AMP_OK) return rc;
-
-  { amp::TraceScope trace__("disc_finalize_kernel", st);
-    disc_finalize_kernel<<<(unsigned)((rows + kBlock - 1) / kBlock), kBlock, 0, st>>>(partial, g2.n_tiles, h->b3, rows, scale, task ? task_copy : nullptr,
-                                                                                   task_w, style_w, logits, style, combined);
-  }
-  return launch_status("disc_finalize_kernel");
+  return disc_forward(h, Xs, rows, H1, partial, scale, task ? task_copy : nullptr, task_w, style_w, logits, style, combined, st);
 }
+
+int amp_disc_input_layout(const AmpDisc* h, int32_t* padded_dim, const float** mean, const float** den, float* clip) {
+  AMP_REQUIRE(h, "amp_disc_input_layout: null handle");
+  if (padded_dim) *padded_dim = h->k1p;
+  if (mean) *mean = h->has_scaler ? h->mean : nullptr;
+  if (den) *den = h->den;
+  if (clip) *clip = h->clip;
+  return AMP_OK;
+}
+
+int amp_disc_style_reward_prescaled(const AmpDisc* h, const float* xs, int64_t rows, float scale, const float* task, float task_w,
+                                    float style_w, float* logits, float* style, float* combined, void* workspace,
+                                    amp_stream_t stream) {
+  AMP_REQUIRE(h, "amp_disc_style_reward_prescaled: null handle");
+  AMP_REQUIRE(rows >= 0, "amp_disc_style_reward_prescaled: negative rows");
+  if (rows == 0) return AMP_OK;
+  AMP_REQUIRE(xs && workspace, "amp_disc_style_reward_prescaled: null buffer");
+  AMP_REQUIRE((uintptr_t)xs % 16 == 0 && (uintptr_t)workspace % 16 == 0, "amp_disc_style_reward_prescaled: 16-byte alignment required");
+  AMP_REQUIRE(rows <= ((int64_t)1 << 30), "amp_disc_style_reward_prescaled: too many rows");
+  float* H1 = (float*)((char*)workspace + round_up((int64_t)sizeof(float) * rows * h->k1p, 256));
+  float* partial = (float*)((char*)H1 + round_up((int64_t)sizeof(float) * rows * h->h1, 256));
+  return disc_forward(h, xs, rows, H1, partial, scale, task, task_w, style_w, logits, style, combined, (hipStream_t)stream);
+}
+
 
 }  // extern "C"

@@ -13,7 +13,6 @@
 
 namespace amp {
 
-constexpr int kTileEnvs = 64;
 
 struct EnvPlan {
   int32_t n_dof, dof_pad, n_key, D, Db, K;
@@ -27,6 +26,7 @@ struct EnvPlan {
   float w_track, sigma_sq, thr, val_at_thr, slope;
 };
 
+template <int kTileEnvs>
 __global__ __launch_bounds__(kBlock) void env_step_kernel(EnvPlan p, AmpSimState st, AmpEnvBuffers bf, int64_t N) {
   extern __shared__ float smem[];
   const int D = p.D, nd = p.n_dof, ndp = p.dof_pad;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(EnvPlan p, AmpSimState
           for (int j = 0; j < nd; ++j) { const float a = s_obs[lane * D + nd + j]; acc += a * a; }
         }
       }
-      s_red[wave * kTileEnvs + lane] = acc;
+      if (lane < kTileEnvs) s_red[wave * kTileEnvs + lane] = acc;
       __syncthreads();
       if (wave == 0 && lane < n_tile) {
         const int64_t env = tile_base + lane;
@@ -190,14 +190,30 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(EnvPlan p, AmpSimState
     const int count = n_tile * D;
     const float inv_d = 1.0f / (float)D;
     constexpr int U = 4;  // independent columns per lane per trip: their loads are issued before any store
+    // optional fused discriminator input: the same values, scaled, into disc_input [N, stride]
+    float* const xs = bf.disc_input ? bf.disc_input + tile_base * bf.disc_input_stride : nullptr;
+    const float* const mu = bf.scaler_mean;
+    const float* const dn = bf.scaler_den;
+    const float clip = bf.scaler_clip;
+    auto scaled = [&](float v, int c) {
+      if (mu) {
+        v = (v - mu[c]) / dn[c];  // skrl RunningStandardScaler, exact fp32 divide
+        v = fminf(fmaxf(v, -clip), clip);
+      }
+      return v;
+    };
     for (int e0 = tid; e0 < count; e0 += U * kBlock) {
       float* col[U];
+      float* xcol[U];
+      int jc[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         int e = e0 + u * kBlock;
         e = e < count ? e : count - 1;
         const int s = (int)(((float)e + 0.5f) * inv_d);  // exact: e < 64 * D
-        col[u] = buf + s * rowK + (e - s * D);
+        jc[u] = e - s * D;
+        col[u] = buf + s * rowK + jc[u];
+        xcol[u] = xs ? xs + s * bf.disc_input_stride + jc[u] : nullptr;
       }
       for (int hi = K - 2; hi >= 0; hi -= 2) {
         float h[U][2];
@@ -210,11 +226,18 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(EnvPlan p, AmpSimState
         for (int u = 0; u < U; ++u)
 #pragma unroll
           for (int i = 0; i < 2; ++i)
-            if (hi - i >= 0 && e0 + u * kBlock < count) col[u][(int64_t)(hi - i + 1) * D] = h[u][i];
+            if (hi - i >= 0 && e0 + u * kBlock < count) {
+              col[u][(int64_t)(hi - i + 1) * D] = h[u][i];
+              if (xs) xcol[u][(hi - i + 1) * D] = scaled(h[u][i], (hi - i + 1) * D + jc[u]);
+            }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        if (e0 + u * kBlock < count) col[u][0] = s_obs[e0 + u * kBlock];
+        if (e0 + u * kBlock < count) {
+          const float v = s_obs[e0 + u * kBlock];
+          col[u][0] = v;
+          if (xs) xcol[u][0] = scaled(v, jc[u]);
+        }
     }
     // policy observation (g1_amp_env.py:195-242; humanoid_amp_env.py:126)
     const int P = p.P, Pcur = p.Pcur, Db = p.Db;
@@ -312,6 +335,14 @@ using namespace amp;
 
 extern "C" {
 
+int32_t amp_env_step_tile_envs(int64_t num_envs) {
+  // envs per workgroup: 64 when that still gives >= 1024 workgroups (4 per CU), else smaller tiles so that a small
+  // shard is spread over the whole chip (the kernel is latency-bound there: one 64-env tile takes ~25 us alone)
+  if (num_envs >= 64 * 1024) return 64;
+  if (num_envs >= 32 * 1024) return 32;
+  return 16;
+}
+
 int64_t amp_policy_obs_size(const AmpEnvCfg* cfg) {
   EnvPlan p;
   if (!cfg || make_plan(cfg, 0, &p) != AMP_OK) return -1;
@@ -355,14 +386,19 @@ int amp_env_step(const AmpEnvCfg* cfg, const AmpSimState* st, const AmpEnvBuffer
     AMP_REQUIRE(!(p.use_last_actions && p.use_command) || st->command, "amp_env_step(obs): command is null");
     AMP_REQUIRE(p.n_actor == 1 || (bf->actor_history && bf->just_reset), "amp_env_step(obs): actor history buffers are null");
     for (int k = 0; k < p.n_key; ++k) AMP_REQUIRE(st->key_body[k] >= 0, "amp_env_step(obs): negative key body index");
+    AMP_REQUIRE(!bf->disc_input || bf->disc_input_stride >= (int64_t)p.K * p.D, "amp_env_step(obs): disc_input_stride too small");
+    AMP_REQUIRE(!bf->disc_input || !bf->scaler_mean || bf->scaler_den, "amp_env_step(obs): scaler_den is null");
   }
   const bool per_env_limits = g1_rew && st->soft_limits_stride != 0;
-  const size_t lds = sizeof(float) * ((size_t)kTileEnvs * p.D + 2 * (size_t)kTileEnvs * p.dof_pad + 4 * kTileEnvs) +
-                     sizeof(int) * kTileEnvs + sizeof(float) * (size_t)(per_env_limits ? kTileEnvs : 1) * (2 * p.n_dof + 1);
+  const int tile = amp_env_step_tile_envs(N);
+  const size_t lds = sizeof(float) * ((size_t)tile * p.D + 2 * (size_t)tile * p.dof_pad + 4 * tile) + sizeof(int) * tile +
+                     sizeof(float) * (size_t)(per_env_limits ? tile : 1) * (2 * p.n_dof + 1);
   AMP_REQUIRE(lds <= 64 * 1024, "amp_env_step: observation tile needs %zu B of LDS (> 64 KiB)", lds);
-  const unsigned grid = (unsigned)((N + kTileEnvs - 1) / kTileEnvs);
+  const unsigned grid = (unsigned)((N + tile - 1) / tile);
   { amp::TraceScope trace__("env_step_kernel", (hipStream_t)stream);
-    env_step_kernel<<<grid, kBlock, lds, (hipStream_t)stream>>>(p, *st, *bf, N);
+    if (tile == 64) env_step_kernel<64><<<grid, kBlock, lds, (hipStream_t)stream>>>(p, *st, *bf, N);
+    else if (tile == 32) env_step_kernel<32><<<grid, kBlock, lds, (hipStream_t)stream>>>(p, *st, *bf, N);
+    else env_step_kernel<16><<<grid, kBlock, lds, (hipStream_t)stream>>>(p, *st, *bf, N);
   }
   return launch_status("env_step_kernel");
 }

@@ -97,7 +97,8 @@ class EnvStepKernel:
         self.died = torch.zeros(N, dtype=torch.bool, device=dev)
         self.time_out = torch.zeros(N, dtype=torch.bool, device=dev)
         self.reset_mask = torch.zeros(N, dtype=torch.bool, device=dev)
-        self.reset_tile_counts = torch.zeros((N + nat.TILE_ENVS - 1) // nat.TILE_ENVS, dtype=torch.int32, device=dev)
+        self.tile_envs = int(self._lib.amp_env_step_tile_envs(N))
+        self.reset_tile_counts = torch.zeros((N + self.tile_envs - 1) // self.tile_envs, dtype=torch.int32, device=dev)
         self.reward_terms = torch.zeros((len(REWARD_TERMS), N), device=dev) if log_reward_terms else None
         if cfg.num_actor_observations > 1:
             self.actor_obs_history_buffer = torch.zeros((N, cfg.num_actor_observations - 1, per), device=dev)
@@ -106,6 +107,19 @@ class EnvStepKernel:
             self.actor_obs_history_buffer, self.just_reset_mask = None, None
         self.reset_ids = torch.zeros(N, dtype=torch.int64, device=dev)
         self.reset_count = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.disc_input, self._scaler = None, (None, None, 0.0)
+
+    def attach_discriminator(self, disc: "AmpDiscriminator") -> torch.Tensor:
+        """Fuse ``disc``'s input scaler into the OBS phase: every OBS launch also writes the scaled, zero-padded
+        discriminator input ``disc_input [N, padded_dim]`` (feed it to ``disc.style_reward_prescaled``), which saves
+        the separate scaler pass over ``amp_obs``.  Call again after ``disc.set_scaler`` / ``set_weights``."""
+        padded, mean, den, clip = disc.input_layout()
+        if padded < self.cfg.num_amp_observations * self.cfg.amp_frame_size:
+            raise nat.AmpEngineError("discriminator input is narrower than K * D")
+        if self.disc_input is None or self.disc_input.shape[1] != padded:
+            self.disc_input = torch.zeros((self.num_envs, padded), device=self.device)  # padding columns stay zero
+        self._scaler = (mean, den, clip)
+        return self.disc_input
 
     def _buffers(self) -> nat.AmpEnvBuffers:
         b = nat.AmpEnvBuffers()
@@ -115,6 +129,9 @@ class EnvStepKernel:
         b.reward, b.reward_terms = p(self.reward), p(self.reward_terms)
         b.died, b.time_out, b.reset_mask = p(self.died), p(self.time_out), p(self.reset_mask)
         b.reset_tile_counts = p(self.reset_tile_counts)
+        if self.disc_input is not None:
+            b.disc_input, b.disc_input_stride = self.disc_input.data_ptr(), int(self.disc_input.stride(0))
+            b.scaler_mean, b.scaler_den, b.scaler_clip = self._scaler
         return b
 
     def launch(self, phases: int, *, joint_pos=None, joint_vel=None, joint_acc=None, actions=None, root_pos=None,
@@ -177,7 +194,7 @@ class EnvStepKernel:
         Returns (ids buffer [N] int64, count [1] int64), both on the device: no host sync here."""
         with torch.cuda.device(self.device):
             nat.check(self._lib.amp_reset_compact_tiles(nat.dptr(self.reset_mask), nat.dptr(self.reset_tile_counts),
-                                                        self.num_envs, nat.dptr(self.reset_ids), nat.dptr(self.reset_count),
+                                                        self.tile_envs, self.num_envs, nat.dptr(self.reset_ids), nat.dptr(self.reset_count),
                                                         nat.stream_ptr()), "amp_reset_compact_tiles")
         return self.reset_ids, self.reset_count
 
@@ -292,6 +309,45 @@ class AmpDiscriminator:
                                                       self.style_reward_weight, nat.dptr(logits), nat.dptr(style),
                                                       nat.dptr(combined), nat.dptr(ws), ev, nat.stream_ptr()),
                       "amp_disc_style_reward")
+        out = {"style": style}
+        if combined is not None:
+            out["combined"] = combined
+        if logits is not None:
+            out["logits"] = logits
+        return out
+
+    def input_layout(self):
+        """(padded_dim, mean_ptr, den_ptr, clip): layout of the scaled input the GEMMs consume (device pointers owned
+        by the handle; mean_ptr is None when no scaler is set)."""
+        padded, mean, den, clip = C.c_int32(), C.c_void_p(), C.c_void_p(), C.c_float()
+        nat.check(self._lib.amp_disc_input_layout(self._handle, C.byref(padded), C.byref(mean), C.byref(den), C.byref(clip)),
+                  "amp_disc_input_layout")
+        return int(padded.value), mean.value, den.value, float(clip.value)
+
+    def style_reward_prescaled(self, scaled: torch.Tensor, task_reward: Optional[torch.Tensor] = None, *,
+                               want_logits: bool = False):
+        """Same as :meth:`style_reward` for an already scaled + padded input (``EnvStepKernel.attach_discriminator``)."""
+        padded = self.input_layout()[0]
+        if scaled.dim() != 2 or scaled.shape[1] != padded or scaled.dtype != torch.float32 or not scaled.is_contiguous():
+            raise nat.AmpEngineError(f"scaled input must be a contiguous float32 [M, {padded}] tensor")
+        nat.require_gpu(scaled.device)
+        M = scaled.shape[0]
+        f32 = dict(dtype=torch.float32, device=self.device)
+        style = torch.empty((M, 1), **f32)
+        logits = torch.empty((M, 1), **f32) if want_logits else None
+        combined, task = None, None
+        if task_reward is not None:
+            task = task_reward.reshape(-1).to(**f32).contiguous()
+            if task.numel() != M:
+                raise nat.AmpEngineError("task_reward must have one entry per row")
+            combined = torch.empty((M, 1), **f32)
+        ws = self._workspace(M)
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.amp_disc_style_reward_prescaled(self._handle, nat.dptr(scaled), M, self.reward_scale, nat.dptr(task),
+                                                                self.task_reward_weight, self.style_reward_weight,
+                                                                nat.dptr(logits), nat.dptr(style), nat.dptr(combined),
+                                                                nat.dptr(ws), nat.stream_ptr()),
+                      "amp_disc_style_reward_prescaled")
         out = {"style": style}
         if combined is not None:
             out["combined"] = combined

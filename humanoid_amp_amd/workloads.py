@@ -85,7 +85,7 @@ class HotPath:
     """All device state of one env shard + ``step()`` = one env-step of the hot path."""
 
     def __init__(self, spec: WorkloadSpec, num_envs: int, device, seed: int = 0, log_reward_terms: bool = False,
-                 overlap: bool = False):
+                 overlap: bool = False, fused_scaler: bool = True):
         """``overlap``: run the discriminator on a second HIP stream so that the HBM-bound kernels of step t+1
         (motion sample, env step, compaction) execute under the MFMA-bound GEMMs of step t.  The style reward is
         consumed asynchronously in AMP (skrl reads it at the agent update), so nothing waits for it inside a step;
@@ -94,6 +94,7 @@ class HotPath:
         workgroups already hold every wave slot, so the two streams time-slice instead of overlapping -> default off."""
         self.spec, self.num_envs = spec, int(num_envs)
         self.overlap = bool(overlap)
+        self.fused_scaler = bool(fused_scaler) and not self.overlap  # the overlapped schedule needs the snapshot pass
         self.device = nat.require_gpu(device)
         files = ",".join(os.path.join(MOTIONS_DIR, c + ".npz") for c in spec.clips)
         self.motion = MotionLoader(files, self.device)
@@ -116,6 +117,8 @@ class HotPath:
                                      running_mean=torch.zeros(spec.K * D, dtype=torch.float64),
                                      running_variance=torch.ones(spec.K * D, dtype=torch.float64),
                                      task_reward_weight=spec.task_weight, style_reward_weight=spec.style_weight)
+        if self.fused_scaler:  # the env step emits the discriminator's scaled input directly (no separate scaler pass)
+            self.kernel.attach_discriminator(self.disc)
         # expert rows are a plausible AMP history to start from
         self.motion.collect_reference(self.state["motion_times"], self.state["motion_ids"], spec.K,
                                       out=self.kernel.amp_observation_buffer)
@@ -148,7 +151,9 @@ class HotPath:
         k.launch(nat.AMP_PHASE_ALL, key_body_indexes=[0, 1, 2, 3], **self._sim)
         k.compact_resets()
         amp = k.amp_observation_buffer.view(self.num_envs, -1)
-        if not self.overlap:
+        if self.fused_scaler:
+            self.last = self.disc.style_reward_prescaled(k.disc_input, k.reward)
+        elif not self.overlap:
             self.last = self.disc.style_reward(amp, k.reward)
         else:
             slot = self._n & 1

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define AMP_ABI_VERSION 1
+#define AMP_ABI_VERSION 2
 
 typedef void* amp_stream_t; /* hipStream_t */
 typedef void* amp_event_t;  /* hipEvent_t  */
@@ -166,11 +166,24 @@ typedef struct {
   uint8_t* died;             /* [N] bool */
   uint8_t* time_out;         /* [N] bool */
   uint8_t* reset_mask;       /* [N] died | time_out */
-  int32_t* reset_tile_counts; /* optional [ceil(N/64)]: number of reset envs per 64-env tile (feeds amp_reset_compact_tiles) */
+  int32_t* reset_tile_counts; /* optional [ceil(N / amp_env_step_tile_envs(N))]: reset envs per tile (feeds amp_reset_compact_tiles) */
+  /* Optional fusion of the discriminator's input scaler into the OBS phase (saves one pass over amp_obs):
+   * disc_input [N, disc_input_stride] receives clamp((amp_obs - mean) / den, -clip, clip) for the K*D columns (the
+   * padding columns are never written: zero them once).  mean / den / clip / stride come from amp_disc_input_layout();
+   * scaler_mean == NULL copies unscaled.  Feed the result to amp_disc_style_reward_prescaled(). */
+  float* disc_input;
+  int64_t disc_input_stride;
+  const float* scaler_mean;
+  const float* scaler_den;
+  float scaler_clip;
+  int32_t reserved;
 } AmpEnvBuffers;
 
 enum { AMP_PHASE_DONES = 1, AMP_PHASE_REWARD = 2, AMP_PHASE_OBS = 4 };
 
+/* Envs per workgroup tile amp_env_step uses for a shard of num_envs (16, 32 or 64): the granularity of
+ * reset_tile_counts. */
+int32_t amp_env_step_tile_envs(int64_t num_envs);
 /* Size of one policy observation row for a configuration (g1_amp_env_cfg.py:186-206). */
 int64_t amp_policy_obs_size(const AmpEnvCfg* cfg);
 /* Size of one actor-history frame (g1_amp_env.py:96-107); 0 when num_actor_observations == 1. */
@@ -189,8 +202,9 @@ int64_t amp_reset_compact_workspace_bytes(int64_t num_envs);
 /* mask_dev [N] (any non-zero byte = reset) -> ids_dev [<= N] ascending, count_dev [1] int64. */
 int amp_reset_compact(const uint8_t* mask_dev, int64_t num_envs, int64_t* ids_dev, int64_t* count_dev,
                       void* workspace_dev, amp_stream_t stream);
-/* Same, re-using the per-64-env tile counts amp_env_step(AMP_PHASE_DONES) already produced. */
-int amp_reset_compact_tiles(const uint8_t* mask_dev, const int32_t* tile_counts_dev, int64_t num_envs,
+/* Same, re-using the per-tile counts amp_env_step(AMP_PHASE_DONES) already produced (tile_envs =
+ * amp_env_step_tile_envs(num_envs)). */
+int amp_reset_compact_tiles(const uint8_t* mask_dev, const int32_t* tile_counts_dev, int32_t tile_envs, int64_t num_envs,
                             int64_t* ids_dev, int64_t* count_dev, amp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -215,6 +229,10 @@ int amp_disc_destroy(AmpDisc* h);
 int amp_disc_set_scaler(AmpDisc* h, const double* running_mean_dev, const double* running_variance_dev,
                         float epsilon, float clip_threshold, amp_stream_t stream);
 int64_t amp_disc_workspace_bytes(const AmpDisc* h, int64_t rows);
+/* Layout of the scaled input the GEMMs consume: padded row length (multiple of 16, rows 16-B aligned) and the
+ * handle's fp32 scaler vectors (device pointers valid until the next amp_disc_set_scaler / destroy; NULL mean when
+ * no scaler is set). */
+int amp_disc_input_layout(const AmpDisc* h, int32_t* padded_dim, const float** mean_dev, const float** den_dev, float* clip);
 /* amp_obs_dev [rows, in_dim] (row stride in elements) -> logits [rows], style [rows] =
  * -log(max(1 - sigmoid(logit), 1e-4)) * reward_scale, combined = task_w * task + style_w * style.
  * logits / style / task / combined may be NULL.
@@ -226,6 +244,13 @@ int amp_disc_style_reward(const AmpDisc* h, const float* amp_obs_dev, int64_t ro
                           float reward_scale, const float* task_reward_dev, float task_weight, float style_weight,
                           float* logits_dev, float* style_dev, float* combined_dev, void* workspace_dev,
                           amp_event_t inputs_consumed, amp_stream_t stream);
+
+/* Same as amp_disc_style_reward for an input that is already scaled and padded (amp_env_step's disc_input, or any
+ * [rows, padded_dim] fp32 matrix with 16-B aligned rows whose padding columns are zero): skips the scaler pass. */
+int amp_disc_style_reward_prescaled(const AmpDisc* h, const float* scaled_dev, int64_t rows, float reward_scale,
+                                    const float* task_reward_dev, float task_weight, float style_weight,
+                                    float* logits_dev, float* style_dev, float* combined_dev, void* workspace_dev,
+                                    amp_stream_t stream);
 
 #ifdef __cplusplus
 }

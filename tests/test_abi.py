@@ -25,10 +25,8 @@ def test_header_declares_the_path():
 
 
 def test_library_exports_every_declared_symbol():
-    from humanoid_amp_amd import _native as nat
-    from humanoid_amp_amd.build import build_library
+    from humanoid_amp_amd import _native as nat  # conftest.py rebuilt the library if it was stale
 
-    build_library()  # no-op when up to date
     lib = ctypes.CDLL(nat.LIB_PATH)
     missing = [n for n in declared_functions() if not hasattr(lib, n)]
     assert not missing, missing
@@ -54,7 +52,7 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(nat.AmpMotionDesc) == 4 * 4 + 8 + 8 + 8 + 6 * 8
     assert ctypes.sizeof(nat.AmpEnvCfg) == 10 * 4 + 8 + 6 * 4 + 3 * 8
     assert ctypes.sizeof(nat.AmpSimState) == 9 * 16 + 32 + 16 + 3 * 8
-    assert ctypes.sizeof(nat.AmpEnvBuffers) == 10 * 8
+    assert ctypes.sizeof(nat.AmpEnvBuffers) == 10 * 8 + 8 + 8 + 8 + 8 + 4 + 4
     assert ctypes.sizeof(nat.AmpDiscDesc) == 16 + 6 * 8
 
 
@@ -65,5 +63,6 @@ def test_errors_are_codes_not_exceptions_and_need_no_gpu():
     assert lib.amp_env_step(None, None, None, 0, 7, None) == -1  # AMP_ERR_INVALID
     assert b"null" in lib.amp_last_error()
     assert lib.amp_reset_compact_workspace_bytes(65536) == 4 * (1024 + 1)
+    assert [lib.amp_env_step_tile_envs(n) for n in (1, 4096, 32768, 65536, 1 << 20)] == [16, 16, 32, 64, 64]
     with pytest.raises(nat.AmpEngineError):
         nat.check(-1, "x")

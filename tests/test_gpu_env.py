@@ -170,13 +170,15 @@ def test_reset_compact_bit_exact(n, density):
     assert torch.equal(ids[: want.numel()].cpu(), want)
 
 
-def test_env_step_full_size_properties():
+@pytest.mark.parametrize("N", [65536, 40000, 4097])  # 64-, 32- and 16-env workgroup tiles (+ a ragged tail)
+def test_env_step_full_size_properties(N):
     """BASELINE size (65 536 envs, K=2): properties that need no oracle run: history shift is a pure row move,
     compaction == nonzero, reset count == sum of tile counts, fused launch == three single-phase launches."""
     from humanoid_amp_amd.engine import EnvStepConfig, EnvStepKernel
     from humanoid_amp_amd import _native as nat
 
-    N, nd, K = 65536, 29, 2
+    nd, K = 29, 2
+    assert nat.load().amp_env_step_tile_envs(N) == {65536: 64, 40000: 32, 4097: 16}[N]
     g = torch.Generator(device="cuda").manual_seed(3)
     r = lambda *s: torch.randn(*s, generator=g, device="cuda")  # noqa: E731
     cfg = EnvStepConfig(n_dof=nd, num_amp_observations=K, max_episode_length=300, rew_termination=-1.0, rew_action_l2=-0.1,
