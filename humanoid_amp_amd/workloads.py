@@ -142,6 +142,13 @@ class HotPath:
                     self.disc._workspace(self.num_envs, slot)
 
     def step(self):
+        if getattr(self, "_graph", None) is not None:
+            self._graph.replay()
+            self.last = self._graph_out
+            return self.last
+        return self._eager_step()
+
+    def _eager_step(self):
         s, k = self.state, self.kernel
         env_stream = torch.cuda.current_stream(self.device)
         if self.overlap and self._n > 0:
@@ -163,6 +170,23 @@ class HotPath:
                 self.last = self.disc.style_reward(amp, k.reward, inputs_consumed=self._consumed[slot], workspace_slot=slot)
         self._n += 1
         return self.last
+
+    def capture(self, warmup: int = 3):
+        """Capture one env-step into a hipGraph (every engine launch is asynchronous on the caller's stream and
+        allocation-free, so the whole step is capturable); later ``step()`` calls replay it.  Pays off when the
+        shard is small enough for the step to be launch-bound (a few thousand envs)."""
+        if self.overlap:
+            raise nat.AmpEngineError("graph capture and the two-stream schedule are mutually exclusive")
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._eager_step()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._graph_out = self._eager_step()
+        return self
 
     def synchronize(self):
         torch.cuda.synchronize(self.device)

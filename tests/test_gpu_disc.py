@@ -137,3 +137,28 @@ def test_fused_scaler_matches_separate_pass(workload, envs):
             assert float(xs[:, kd:].abs().max()) == 0.0 if xs.shape[1] > kd else True  # padding untouched
     for a, b in zip(res[False], res[True]):
         assert torch.equal(a, b)
+
+
+def test_graph_replay_matches_eager():
+    """The whole env-step captured as one hipGraph replays to the same bits as eager launches."""
+    import contextlib
+    import io
+
+    from humanoid_amp_amd.workloads import WORKLOADS, HotPath
+
+    res = {}
+    for graph in (False, True):
+        with contextlib.redirect_stdout(io.StringIO()):
+            hot = HotPath(WORKLOADS["g1_walk"], 4096, "cuda:0", seed=8)
+        if graph:
+            hot.capture(warmup=2)   # 2 warm-up steps + the captured one ...
+            n = 3
+        else:
+            n = 6                   # ... so eager runs 3 more to reach the same history state
+        for _ in range(n):
+            out = hot.step()
+        hot.synchronize()
+        res[graph] = (out["style"].clone(), out["combined"].clone(), hot.kernel.amp_observation_buffer.clone(),
+                      hot.kernel.reset_ids.clone(), hot.kernel.policy_obs.clone())
+    for a, b in zip(res[False], res[True]):
+        assert torch.equal(a, b)
