@@ -26,7 +26,8 @@ def global_env_ids(local_ids: torch.Tensor, num_envs: int, world_size: int, rank
     return local_ids + shard_bounds(num_envs, world_size, rank)[0]
 
 
-def allgather_minibatch(shard: torch.Tensor, out: torch.Tensor | None = None, group=None) -> torch.Tensor:
+def allgather_minibatch(shard: torch.Tensor, out: torch.Tensor | None = None, group=None,
+                        force_collective: bool = False) -> torch.Tensor:
     """[B_loc, C] per rank -> [world * B_loc, C], rank-major.  One collective, no staging copy: 2.72 MB per rank at
     B_loc = 4096, C = 166.  The 8 GPUs of a node are fully connected over xGMI, so the message is small enough
     that RCCL's direct algorithm (one link per peer) applies; nothing here is ring-specific."""
@@ -37,7 +38,7 @@ def allgather_minibatch(shard: torch.Tensor, out: torch.Tensor | None = None, gr
         out = torch.empty((world * shard.shape[0], shard.shape[1]), dtype=shard.dtype, device=shard.device)
     elif tuple(out.shape) != (world * shard.shape[0], shard.shape[1]) or not out.is_contiguous():
         raise ValueError("out has the wrong shape")
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_initialized()):
         out.copy_(shard)
     elif shard.is_cuda and dist.get_backend(group) != "nccl":
         # rehearsal path only (gloo has no device collectives): stage through the host
