@@ -43,6 +43,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=0, help="envs of the CPU sample (0 = same as --envs)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 4096-env secondary measurement")
+    ap.add_argument("--split-modes", action="store_true", help="also time the experimental split-precision (bf16x6 / bf16x3) discriminator")
     ap.add_argument("--no-graph", action="store_true", help="never use hipGraph replay (secondary measurement included)")
     return ap.parse_args()
 
@@ -248,6 +249,22 @@ def main():
                                 "ms_per_step": dts / max(args.steps, 50) * 1e3, "envs_per_gpu": 4096,
                                 "launch": "eager" if args.no_graph else "hipGraph replay of the captured step"}
         del hot_s
+
+    # ---- opt-in split-precision discriminator (NOT the headline: `value` above is native fp32 MFMA) -----------------
+    if args.split_modes:
+        extra = {}
+        for mode in ("bf16x6", "bf16x3"):
+            torch.cuda.empty_cache()
+            with contextlib.redirect_stdout(sys.stderr):
+                hot_m = HotPath(spec, args.envs, device, seed=1234 + rank, disc_precision=mode)
+            dtm = timed_steps(hot_m, args.steps, args.warmup, world, None)
+            extra[mode] = {"value": args.envs * world * args.steps / dtm, "unit": "env-steps/s", "ms_per_step": dtm / args.steps * 1e3}
+            del hot_m
+        if rank == 0:
+            out["split_precision_modes"] = {
+                "note": "experimental, opt-in (AmpDiscriminator(precision=...)): fp32 operands as 3 / 2 bf16 planes, 6 / 3 bf16 "
+                        "MFMAs per k-step, fp32 accumulate; bf16x6 error <= native fp32's, bf16x3 ~1e-5*|logit|.  Not the headline.",
+                **extra}
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -107,6 +107,7 @@ SIGNATURES = {
     "amp_disc_create": (C.c_int, [C.POINTER(AmpDiscDesc), _vp, C.POINTER(_vp)]),
     "amp_disc_destroy": (C.c_int, [_vp]),
     "amp_disc_set_scaler": (C.c_int, [_vp, _vp, _vp, _f32, _f32, _vp]),
+    "amp_disc_set_precision": (C.c_int, [_vp, _i32, _vp]),
     "amp_disc_workspace_bytes": (_i64, [_vp, _i64]),
     "amp_disc_input_layout": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_f32)]),
     "amp_disc_style_reward_prescaled": (C.c_int, [_vp, _vp, _i64, _f32, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),

@@ -16,6 +16,7 @@
 // Global->LDS staging is register-prefetched one k-tile ahead.  Workgroups are renumbered so that the
 // column tiles of one row tile run on the same XCD (they share the A tile through that XCD's L2).
 #include "disc_gemm.hpp"
+#include "disc_gemm_split.hpp"
 
 #include <cstdlib>
 
@@ -33,6 +34,10 @@ struct AmpDisc {
   float* den;  // [k1p] sqrt(var) + eps
   float clip;
   bool has_scaler;
+  // opt-in split-precision GEMMs (disc_gemm_split.hpp): 0 = native fp32 MFMA, 2 = bf16x3, 3 = bf16x6
+  int32_t planes;
+  __bf16* w1s;  // [planes][h1][k1p]
+  __bf16* w2s;  // [planes][h2][h1]
 };
 
 namespace amp {
@@ -170,6 +175,57 @@ static int disc_forward(const AmpDisc* h, const float* Xs, int64_t rows, float* 
   }
   return launch_status("disc_finalize_kernel");
 }
+// split-precision forward on bf16 planes Xp [planes][rows][k1p] (disc_gemm_split.hpp)
+static int disc_forward_split(const AmpDisc* h, const __bf16* Xp, int64_t rows, __bf16* H1p, float* partial, float scale,
+                              const float* task, float task_w, float style_w, float* logits, float* style, float* combined,
+                              hipStream_t st) {
+  auto big_tiles = [&](int N) { return (rows + 127) / 128 * (N / 128) >= 512; };
+  SplitGemmArgs g1{};
+  g1.A = Xp; g1.a_plane = rows * h->k1p; g1.lda = h->k1p; g1.M = rows;
+  g1.W = h->w1s; g1.w_plane = (int64_t)h->h1 * h->k1p; g1.Kp = h->k1p; g1.bias = h->b1; g1.N = h->h1;
+  g1.C = H1p; g1.c_plane = rows * h->h1; g1.ldc = h->h1;
+  {
+    const bool big = big_tiles(h->h1);
+    const int bm = big ? 128 : 64;
+    g1.n_tiles = h->h1 / bm; g1.m_tiles = (int)((rows + bm - 1) / bm);
+    const unsigned grid = (unsigned)(((int64_t)g1.m_tiles * g1.n_tiles + 7) / 8 * 8);
+    amp::TraceScope trace__("disc_gemm_split_kernel<0>", st);
+    if (h->planes == 3) {
+      if (big) disc_gemm_split_kernel<128, 128, 3, 0, 2><<<grid, kBlock, 0, st>>>(g1);
+      else disc_gemm_split_kernel<64, 64, 3, 0, 4><<<grid, kBlock, 0, st>>>(g1);
+    } else {
+      if (big) disc_gemm_split_kernel<128, 128, 2, 0, 2><<<grid, kBlock, 0, st>>>(g1);
+      else disc_gemm_split_kernel<64, 64, 2, 0, 4><<<grid, kBlock, 0, st>>>(g1);
+    }
+  }
+  int rc = launch_status("disc_gemm_split_kernel<0>");
+  if (rc != AMP_OK) return rc;
+  SplitGemmArgs g2{};
+  g2.A = H1p; g2.a_plane = rows * h->h1; g2.lda = h->h1; g2.M = rows;
+  g2.W = h->w2s; g2.w_plane = (int64_t)h->h2 * h->h1; g2.Kp = h->h1; g2.bias = h->b2; g2.N = h->h2;
+  g2.w3 = h->w3; g2.partial = partial;
+  {
+    const bool big = big_tiles(h->h2);
+    const int bm = big ? 128 : 64;
+    g2.n_tiles = h->h2 / bm; g2.m_tiles = (int)((rows + bm - 1) / bm);
+    const unsigned grid = (unsigned)(((int64_t)g2.m_tiles * g2.n_tiles + 7) / 8 * 8);
+    amp::TraceScope trace__("disc_gemm_split_kernel<1>", st);
+    if (h->planes == 3) {
+      if (big) disc_gemm_split_kernel<128, 128, 3, 1, 2><<<grid, kBlock, 0, st>>>(g2);
+      else disc_gemm_split_kernel<64, 64, 3, 1, 4><<<grid, kBlock, 0, st>>>(g2);
+    } else {
+      if (big) disc_gemm_split_kernel<128, 128, 2, 1, 2><<<grid, kBlock, 0, st>>>(g2);
+      else disc_gemm_split_kernel<64, 64, 2, 1, 4><<<grid, kBlock, 0, st>>>(g2);
+    }
+  }
+  rc = launch_status("disc_gemm_split_kernel<1>");
+  if (rc != AMP_OK) return rc;
+  { amp::TraceScope trace__("disc_finalize_kernel", st);
+    disc_finalize_kernel<<<(unsigned)((rows + kBlock - 1) / kBlock), kBlock, 0, st>>>(partial, g2.n_tiles, h->b3, rows, scale, task,
+                                                                                   task_w, style_w, logits, style, combined);
+  }
+  return launch_status("disc_finalize_kernel");
+}
 }  // namespace amp
 
 using namespace amp;
@@ -186,6 +242,8 @@ int amp_disc_destroy(AmpDisc* h) {
   (void)hipFree(h->b3);
   (void)hipFree(h->mean);
   (void)hipFree(h->den);
+  (void)hipFree(h->w1s);
+  (void)hipFree(h->w2s);
   delete h;
   return AMP_OK;
 }
@@ -252,10 +310,38 @@ int amp_disc_set_scaler(AmpDisc* h, const double* mean, const double* var, float
   return AMP_OK;
 }
 
+int amp_disc_set_precision(AmpDisc* h, int32_t bf16_planes, amp_stream_t stream) {
+  AMP_REQUIRE(h, "amp_disc_set_precision: null handle");
+  AMP_REQUIRE(bf16_planes == 0 || bf16_planes == 2 || bf16_planes == 3,
+              "amp_disc_set_precision: planes must be 0 (native fp32), 2 (bf16x3) or 3 (bf16x6)");
+  (void)hipFree(h->w1s);
+  (void)hipFree(h->w2s);
+  h->w1s = h->w2s = nullptr;
+  h->planes = 0;
+  if (bf16_planes == 0) return AMP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n1 = (int64_t)h->h1 * h->k1p, n2 = (int64_t)h->h2 * h->h1;
+  AMP_HIP(hipMalloc(&h->w1s, sizeof(__bf16) * n1 * bf16_planes));
+  AMP_HIP(hipMalloc(&h->w2s, sizeof(__bf16) * n2 * bf16_planes));
+  {
+    amp::TraceScope trace__("disc_split_rows_kernel", st);
+    disc_split_rows_kernel<<<(unsigned)((n1 / 4 + kBlock - 1) / kBlock), kBlock, 0, st>>>(h->w1p, h->k1p, h->h1, h->k1p, h->k1p, nullptr,
+                                                                                        nullptr, 0.0f, bf16_planes, h->w1s, n1, nullptr, nullptr);
+    disc_split_rows_kernel<<<(unsigned)((n2 / 4 + kBlock - 1) / kBlock), kBlock, 0, st>>>(h->w2, h->h1, h->h2, h->h1, h->h1, nullptr,
+                                                                                        nullptr, 0.0f, bf16_planes, h->w2s, n2, nullptr, nullptr);
+  }
+  int rc = launch_status("disc_split_rows_kernel");
+  if (rc != AMP_OK) return rc;
+  h->planes = bf16_planes;
+  return AMP_OK;
+}
+
 int64_t amp_disc_workspace_bytes(const AmpDisc* h, int64_t rows) {
   if (!h || rows < 0) return -1;
-  const int64_t xs_bytes = round_up((int64_t)sizeof(float) * rows * h->k1p, 256);
-  const int64_t h1_bytes = round_up((int64_t)sizeof(float) * rows * h->h1, 256);
+  // fp32 path: Xs, H1 as fp32; split path: 3 bf16 planes each (the same offsets are used by both)
+  const int64_t elt = h->planes ? 6 : 4;
+  const int64_t xs_bytes = round_up(elt * rows * h->k1p, 256);
+  const int64_t h1_bytes = round_up(elt * rows * h->h1, 256);
   const int64_t part_bytes = round_up((int64_t)sizeof(float) * rows * (h->h2 / 64), 256);
   const int64_t task_bytes = round_up((int64_t)sizeof(float) * rows, 256);
   return xs_bytes + h1_bytes + part_bytes + task_bytes;
@@ -272,10 +358,28 @@ int amp_disc_style_reward(const AmpDisc* h, const float* x, int64_t rows, int64_
   AMP_REQUIRE((uintptr_t)workspace % 16 == 0, "amp_disc_style_reward: workspace must be 16-byte aligned");
   AMP_REQUIRE(rows <= ((int64_t)1 << 30), "amp_disc_style_reward: too many rows");
   hipStream_t st = (hipStream_t)stream;
+  const int64_t elt = h->planes ? 6 : 4;
   float* Xs = (float*)workspace;
-  float* H1 = (float*)((char*)Xs + round_up((int64_t)sizeof(float) * rows * h->k1p, 256));
-  float* partial = (float*)((char*)H1 + round_up((int64_t)sizeof(float) * rows * h->h1, 256));
+  float* H1 = (float*)((char*)Xs + round_up(elt * rows * h->k1p, 256));
+  float* partial = (float*)((char*)H1 + round_up(elt * rows * h->h1, 256));
   float* task_copy = (float*)((char*)partial + round_up((int64_t)sizeof(float) * rows * (h->h2 / 64), 256));
+  if (h->planes) {
+    // split-precision path: scaler + split into bf16 planes in one pass (also snapshots the task reward)
+    __bf16* Xp = (__bf16*)Xs;
+    __bf16* H1p = (__bf16*)H1;
+    {
+      const int64_t quads = rows * (h->k1p / 4);
+      amp::TraceScope trace__("disc_split_rows_kernel", st);
+      disc_split_rows_kernel<<<(unsigned)((quads + kBlock - 1) / kBlock), kBlock, 0, st>>>(
+          x, row_stride, rows, h->in_dim, h->k1p, h->has_scaler ? h->mean : nullptr, h->den, h->clip, h->planes, Xp,
+          rows * h->k1p, task, task_copy);
+    }
+    int rcs = launch_status("disc_split_rows_kernel");
+    if (rcs != AMP_OK) return rcs;
+    if (inputs_consumed) AMP_HIP(hipEventRecord((hipEvent_t)inputs_consumed, st));
+    return disc_forward_split(h, Xp, rows, H1p, partial, scale, task ? task_copy : nullptr, task_w, style_w, logits, style,
+                              combined, st);
+  }
   {
     const int64_t quads = rows * (h->k1p / 4);
     amp::TraceScope trace__("disc_scale_pad_kernel", st);
@@ -308,9 +412,23 @@ int amp_disc_style_reward_prescaled(const AmpDisc* h, const float* xs, int64_t r
   AMP_REQUIRE(xs && workspace, "amp_disc_style_reward_prescaled: null buffer");
   AMP_REQUIRE((uintptr_t)xs % 16 == 0 && (uintptr_t)workspace % 16 == 0, "amp_disc_style_reward_prescaled: 16-byte alignment required");
   AMP_REQUIRE(rows <= ((int64_t)1 << 30), "amp_disc_style_reward_prescaled: too many rows");
-  float* H1 = (float*)((char*)workspace + round_up((int64_t)sizeof(float) * rows * h->k1p, 256));
-  float* partial = (float*)((char*)H1 + round_up((int64_t)sizeof(float) * rows * h->h1, 256));
-  return disc_forward(h, xs, rows, H1, partial, scale, task, task_w, style_w, logits, style, combined, (hipStream_t)stream);
+  const int64_t elt = h->planes ? 6 : 4;
+  float* H1 = (float*)((char*)workspace + round_up(elt * rows * h->k1p, 256));
+  float* partial = (float*)((char*)H1 + round_up(elt * rows * h->h1, 256));
+  hipStream_t st = (hipStream_t)stream;
+  if (h->planes) {
+    __bf16* Xp = (__bf16*)workspace;
+    {
+      const int64_t quads = rows * (h->k1p / 4);
+      amp::TraceScope trace__("disc_split_rows_kernel", st);
+      disc_split_rows_kernel<<<(unsigned)((quads + kBlock - 1) / kBlock), kBlock, 0, st>>>(
+          xs, h->k1p, rows, h->k1p, h->k1p, nullptr, nullptr, 0.0f, h->planes, Xp, rows * h->k1p, nullptr, nullptr);
+    }
+    int rcs = launch_status("disc_split_rows_kernel");
+    if (rcs != AMP_OK) return rcs;
+    return disc_forward_split(h, Xp, rows, (__bf16*)H1, partial, scale, task, task_w, style_w, logits, style, combined, st);
+  }
+  return disc_forward(h, xs, rows, H1, partial, scale, task, task_w, style_w, logits, style, combined, st);
 }
 
 

@@ -85,7 +85,7 @@ class HotPath:
     """All device state of one env shard + ``step()`` = one env-step of the hot path."""
 
     def __init__(self, spec: WorkloadSpec, num_envs: int, device, seed: int = 0, log_reward_terms: bool = False,
-                 overlap: bool = False, fused_scaler: bool = True):
+                 overlap: bool = False, fused_scaler: bool = True, disc_precision: str = "f32"):
         """``overlap``: run the discriminator on a second HIP stream so that the HBM-bound kernels of step t+1
         (motion sample, env step, compaction) execute under the MFMA-bound GEMMs of step t.  The style reward is
         consumed asynchronously in AMP (skrl reads it at the agent update), so nothing waits for it inside a step;
@@ -116,7 +116,8 @@ class HotPath:
         self.disc = AmpDiscriminator(self.disc_weights, self.device,
                                      running_mean=torch.zeros(spec.K * D, dtype=torch.float64),
                                      running_variance=torch.ones(spec.K * D, dtype=torch.float64),
-                                     task_reward_weight=spec.task_weight, style_reward_weight=spec.style_weight)
+                                     task_reward_weight=spec.task_weight, style_reward_weight=spec.style_weight,
+                                     precision=disc_precision)
         if self.fused_scaler:  # the env step emits the discriminator's scaled input directly (no separate scaler pass)
             self.kernel.attach_discriminator(self.disc)
         # expert rows are a plausible AMP history to start from

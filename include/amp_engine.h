@@ -228,6 +228,11 @@ int amp_disc_destroy(AmpDisc* h);
 /* RunningStandardScaler statistics (fp64 on device, as skrl keeps them); NULL mean disables scaling. */
 int amp_disc_set_scaler(AmpDisc* h, const double* running_mean_dev, const double* running_variance_dev,
                         float epsilon, float clip_threshold, amp_stream_t stream);
+/* OPT-IN split-precision GEMMs: 0 = native fp32 MFMA (default), 3 = "bf16x6" (fp32 operands carried as three bf16
+ * planes, six bf16 MFMAs per k-step: fp32-level accuracy, ~2.7x the fp32-MFMA rate), 2 = "bf16x3" (two planes, three
+ * MFMAs: ~1e-5 * |logit| accuracy, ~5x).  Re-splits the weights; call again after amp_disc_create.  The workspace
+ * size depends on it. */
+int amp_disc_set_precision(AmpDisc* h, int32_t bf16_planes, amp_stream_t stream);
 int64_t amp_disc_workspace_bytes(const AmpDisc* h, int64_t rows);
 /* Layout of the scaled input the GEMMs consume: padded row length (multiple of 16, rows 16-B aligned) and the
  * handle's fp32 scaler vectors (device pointers valid until the next amp_disc_set_scaler / destroy; NULL mean when

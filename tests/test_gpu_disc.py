@@ -162,3 +162,34 @@ def test_graph_replay_matches_eager():
                       hot.kernel.reset_ids.clone(), hot.kernel.policy_obs.clone())
     for a, b in zip(res[False], res[True]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("precision,bar", [("bf16x6", 1e-6), ("bf16x3", 1e-5)])
+@pytest.mark.parametrize("in_dim,rows", [(166, 4096), (830, 777), (162, 70000)])
+def test_split_precision_modes(precision, bar, in_dim, rows):
+    """Opt-in split-precision GEMMs: bf16x6 must be as accurate as native fp32 (<= 1e-6 vs fp64 on O(1) logits),
+    bf16x3 must stay inside the 1e-5 budget on O(1) logits."""
+    from humanoid_amp_amd.engine import AmpDiscriminator
+
+    g = torch.Generator().manual_seed(in_dim + rows)
+    w = odisc.make_weights(in_dim, seed=3)
+    x = torch.randn(rows, in_dim, generator=g) * 1.5
+    mean = torch.randn(in_dim, generator=g, dtype=torch.float64) * 0.2
+    var = torch.rand(in_dim, generator=g, dtype=torch.float64) + 0.1
+    task = torch.randn(rows, 1, generator=g)
+    d = AmpDiscriminator([(p.cuda(), q.cuda()) for p, q in w], "cuda:0", running_mean=mean, running_variance=var,
+                         task_reward_weight=0.5, style_reward_weight=0.5, precision=precision)
+    out = d.style_reward(x.cuda(), task.cuda(), want_logits=True)
+    sub = slice(0, min(rows, 4096))
+    ref = odisc.forward(w, x[sub], mean, var, task=task[sub], task_w=0.5, style_w=0.5)
+    with torch.no_grad():
+        lg64 = odisc.logits(w, ref["scaled"], dtype=torch.float64)
+    scale = max(1.0, float(lg64.abs().max()))
+    assert float((out["logits"][sub].cpu().double() - lg64).abs().max()) <= bar * scale
+    assert float((out["style"][sub].cpu() - ref["style"]).abs().max()) <= 2.5 * bar * scale + 1e-6
+    assert float((out["combined"][sub].cpu() - ref["combined"]).abs().max()) <= 2.5 * bar * scale + 1e-6
+    # prescaled entry point == generic entry point in the same mode
+    xs = torch.zeros(rows, d.input_layout()[0], device="cuda")
+    xs[:, :in_dim] = odisc.scale_states(x, mean, var).cuda()
+    pre = d.style_reward_prescaled(xs, task.cuda(), want_logits=True)
+    assert float((pre["logits"] - out["logits"]).abs().max()) <= bar * scale  # host-scaled vs device-scaled input
