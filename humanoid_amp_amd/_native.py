@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libamp_engine.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 AMP_PHASE_DONES, AMP_PHASE_REWARD, AMP_PHASE_OBS = 1, 2, 4
 AMP_PHASE_ALL = 7
@@ -30,6 +30,15 @@ class AmpMotionDesc(C.Structure):
         ("n_frames", C.c_int64), ("dt", C.c_double), ("clip_frames", C.POINTER(C.c_int64)),
         ("dof_positions", C.c_void_p), ("dof_velocities", C.c_void_p), ("body_positions", C.c_void_p),
         ("body_rotations", C.c_void_p), ("body_linear_velocities", C.c_void_p), ("body_angular_velocities", C.c_void_p),
+    ]
+
+
+class AmpResetArgs(C.Structure):
+    _fields_ = [
+        ("env_ids", C.c_void_p), ("count", C.c_void_p), ("max_n", C.c_int64), ("seed", C.c_uint64), ("step", C.c_uint64),
+        ("start", C.c_int32), ("K", C.c_int32), ("env_origins", C.c_void_p), ("z_lift", C.c_float), ("reserved", C.c_int32),
+        ("root_state", C.c_void_p), ("dof_pos", C.c_void_p), ("dof_vel", C.c_void_p), ("amp_obs_buffer", C.c_void_p),
+        ("motion_ids", C.c_void_p), ("motion_times", C.c_void_p),
     ]
 
 
@@ -97,6 +106,8 @@ SIGNATURES = {
     "amp_motion_sample": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "amp_collect_reference": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "amp_reset_reference_state": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _vp, _vp, _vp, _vp]),
+    "amp_motion_sample_times": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _i32, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "amp_reset_apply": (C.c_int, [_vp, C.POINTER(AmpResetArgs), _vp]),
     "amp_policy_obs_size": (_i64, [C.POINTER(AmpEnvCfg)]),
     "amp_actor_history_frame_size": (_i64, [C.POINTER(AmpEnvCfg)]),
     "amp_env_step": (C.c_int, [C.POINTER(AmpEnvCfg), C.POINTER(AmpSimState), C.POINTER(AmpEnvBuffers), _i64, C.c_uint32, _vp]),

@@ -202,11 +202,14 @@ constexpr int kExpertUnroll = 4; // independent (gather, gather) pairs in flight
 __global__ __launch_bounds__(kBlock) void collect_reference_kernel(MotionView v, const double* __restrict__ times,
                                                                    const int64_t* __restrict__ ids, int64_t n, int K,
                                                                    float* __restrict__ out,
-                                                                   const int64_t* __restrict__ dst_rows) {
+                                                                   const int64_t* __restrict__ dst_rows,
+                                                                   const int64_t* __restrict__ n_dev) {
   __shared__ ExpertSlot slots[kExpertTile];
   const int D = v.D, nd2 = 2 * v.n_dof;
+  if (n_dev) n = *n_dev < n ? *n_dev : n;  // device-side sample count (reset path without a host read-back)
   const int64_t total = n * K;
   const int64_t tile_base = (int64_t)blockIdx.x * kExpertTile;
+  if (tile_base >= total) return;  // uniform for the whole workgroup
   const int n_tile = (int)((total - tile_base) < kExpertTile ? (total - tile_base) : kExpertTile);
   const float* __restrict__ hot = v.hot;
   if (threadIdx.x < n_tile) {
@@ -278,10 +281,12 @@ __global__ __launch_bounds__(kBlock) void reset_state_kernel(MotionView v, const
                                                              const int64_t* __restrict__ env_ids, int64_t n,
                                                              const float* __restrict__ origins, float z_lift,
                                                              float* __restrict__ root, float* __restrict__ o_dp,
-                                                             float* __restrict__ o_dv) {
+                                                             float* __restrict__ o_dv, const int64_t* __restrict__ n_dev) {
   __shared__ SampleSlot slots[kBlock];
   const int D = v.D, nd = v.n_dof;
+  if (n_dev) n = *n_dev < n ? *n_dev : n;
   const int64_t tile_base = (int64_t)blockIdx.x * kBlock;
+  if (tile_base >= n) return;
   const int n_tile = (int)((n - tile_base) < kBlock ? (n - tile_base) : kBlock);
   const float* __restrict__ hot = v.hot;
   if (threadIdx.x < n_tile) {
@@ -326,6 +331,43 @@ __global__ __launch_bounds__(kBlock) void reset_state_kernel(MotionView v, const
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// device-side sample_times (replaces the host numpy RNG of motion_loader.py:309-329 on the reset path).
+// Counter-based: Philox4x32-10, key = seed, counter = (index, step), so the draw of an env does not depend on
+// how many other envs reset in the same step.  Parity with the reference is distributional only (it uses numpy's
+// global MT19937); bit-exactness is defined against oracle/rng.py.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t out[4]) {
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ __launch_bounds__(kBlock) void sample_times_kernel(ClipMeta m, uint64_t seed, uint64_t step, int start,
+                                                              const int64_t* __restrict__ index, int64_t n,
+                                                              const int64_t* __restrict__ n_dev,
+                                                              int64_t* __restrict__ o_ids, double* __restrict__ o_t) {
+  if (n_dev) n = *n_dev < n ? *n_dev : n;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t idx = (uint64_t)(index ? index[i] : i);
+  uint32_t r[4];
+  philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)seed,
+                (uint32_t)(seed >> 32), r);
+  const int64_t clip = (int64_t)(((uint64_t)r[0] * (uint64_t)m.n_clips) >> 32);  // uniform in [0, n_clips)
+  // 53-bit uniform in [0, 1) from two words, numpy's random_sample construction
+  const double u = ((double)(r[1] >> 5) * 67108864.0 + (double)(r[2] >> 6)) / 9007199254740992.0;
+  o_ids[i] = clip;
+  o_t[i] = start ? 0.0 : u * m.dur[clip];
 }
 
 static inline unsigned grid_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
@@ -482,7 +524,49 @@ int amp_collect_reference(const AmpMotion* h, const double* times, const int64_t
   if (n == 0) return AMP_OK;
   AMP_REQUIRE(times && out, "amp_collect_reference: null buffer");
   { amp::TraceScope trace__("collect_reference_kernel", (hipStream_t)stream);
-    collect_reference_kernel<<<grid_for(n * K, kExpertTile), kBlock, 0, (hipStream_t)stream>>>(h->v, times, ids, n, K, out, dst_rows);
+    collect_reference_kernel<<<grid_for(n * K, kExpertTile), kBlock, 0, (hipStream_t)stream>>>(h->v, times, ids, n, K, out, dst_rows, nullptr);
+  }
+  return launch_status("collect_reference_kernel");
+}
+
+int amp_motion_sample_times(const AmpMotion* h, uint64_t seed, uint64_t step, int32_t start, const int64_t* index,
+                            const int64_t* n_dev, int64_t n, int64_t* motion_ids, double* times, amp_stream_t stream) {
+  AMP_REQUIRE(h, "amp_motion_sample_times: null handle");
+  AMP_REQUIRE(n >= 0, "amp_motion_sample_times: negative n");
+  if (n == 0) return AMP_OK;
+  AMP_REQUIRE(motion_ids && times, "amp_motion_sample_times: null buffer");
+  { amp::TraceScope trace__("sample_times_kernel", (hipStream_t)stream);
+    sample_times_kernel<<<grid_for(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(h->v.clips, seed, step, start, index, n, n_dev,
+                                                                              motion_ids, times);
+  }
+  return launch_status("sample_times_kernel");
+}
+
+int amp_reset_apply(const AmpMotion* h, const AmpResetArgs* a, amp_stream_t stream) {
+  AMP_REQUIRE(h && a, "amp_reset_apply: null argument");
+  AMP_REQUIRE(h->has_layout, "amp_reset_apply: call amp_motion_set_obs_layout first");
+  AMP_REQUIRE(a->max_n >= 0 && a->K >= 1, "amp_reset_apply: need max_n >= 0 and K >= 1");
+  if (a->max_n == 0) return AMP_OK;
+  AMP_REQUIRE(a->env_ids && a->count && a->motion_ids && a->motion_times, "amp_reset_apply: null buffer");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n = a->max_n;
+  { amp::TraceScope trace__("sample_times_kernel", st);
+    sample_times_kernel<<<grid_for(n, kBlock), kBlock, 0, st>>>(h->v.clips, a->seed, a->step, a->start, a->env_ids, n, a->count,
+                                                             a->motion_ids, a->motion_times);
+  }
+  int rc = launch_status("sample_times_kernel");
+  if (rc != AMP_OK) return rc;
+  if (a->root_state || a->dof_pos || a->dof_vel) {
+    amp::TraceScope trace__("reset_state_kernel", st);
+    reset_state_kernel<<<grid_for(n, kBlock), kBlock, 0, st>>>(h->v, a->motion_times, a->motion_ids, a->env_ids, n, a->env_origins,
+                                                            a->z_lift, a->root_state, a->dof_pos, a->dof_vel, a->count);
+  }
+  rc = launch_status("reset_state_kernel");
+  if (rc != AMP_OK) return rc;
+  if (a->amp_obs_buffer) {
+    amp::TraceScope trace__("collect_reference_kernel", st);
+    collect_reference_kernel<<<grid_for(n * a->K, kExpertTile), kBlock, 0, st>>>(h->v, a->motion_times, a->motion_ids, n, a->K,
+                                                                              a->amp_obs_buffer, a->env_ids, a->count);
   }
   return launch_status("collect_reference_kernel");
 }
@@ -496,7 +580,7 @@ int amp_reset_reference_state(const AmpMotion* h, const double* times, const int
   AMP_REQUIRE(times, "amp_reset_reference_state: times is null");
   { amp::TraceScope trace__("reset_state_kernel", (hipStream_t)stream);
     reset_state_kernel<<<grid_for(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(h->v, times, ids, env_ids, n, origins, z_lift,
-                                                                             root, dp, dv);
+                                                                             root, dp, dv, nullptr);
   }
   return launch_status("reset_state_kernel");
 }

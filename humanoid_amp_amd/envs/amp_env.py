@@ -44,8 +44,14 @@ class _AmpEnv(DirectRLEnv):
     Z_LIFT = 0.05
     IS_G1 = True
 
-    def __init__(self, cfg, render_mode: str | None = None, robot=None, log_rewards: bool = True, **kwargs):
+    def __init__(self, cfg, render_mode: str | None = None, robot=None, log_rewards: bool = True,
+                 device_reset: bool = False, reset_seed: int = 0, **kwargs):
+        """``device_reset=True`` keeps the whole reset on the device (ids + count from the compaction kernel feed
+        ``amp_reset_apply``; clip / time come from the engine's counter-based RNG keyed by ``reset_seed``): no host
+        sync and no numpy RNG inside ``step()``.  Needs a state provider with ``write_reset_compact`` (the synthetic
+        articulation has one); the reference's exact host-RNG sequence is then not reproduced (distribution is)."""
         self._log_rewards = bool(log_rewards)
+        self.device_reset, self._reset_seed, self._reset_out = bool(device_reset), int(reset_seed), None
         super().__init__(cfg, render_mode, robot=robot, **kwargs)
         nat.require_gpu(self.device)
         data = self.robot.data
@@ -161,6 +167,22 @@ class _AmpEnv(DirectRLEnv):
     def _after_reset(self, env_ids):
         pass
 
+    def _reset_on_device(self):
+        if not self.cfg.reset_strategy.startswith("random"):
+            raise ValueError("device_reset supports the random / random-start strategies")
+        ids, count = self._kernel.compact_resets()
+        self._reset_out = self._motion_loader.reset_apply(
+            ids, count, self.cfg.num_amp_observations, seed=self._reset_seed, step=self.common_step_counter,
+            start="start" in self.cfg.reset_strategy, env_origins=self.scene.env_origins, z_lift=self.Z_LIFT,
+            amp_observation_buffer=self.amp_observation_buffer, out=self._reset_out)
+        o, mask = self._reset_out, self._kernel.reset_mask
+        self.robot.write_reset_compact(ids, count, o["root_state"], o["dof_pos"], o["dof_vel"])
+        self.episode_length_buf.masked_fill_(mask, 0)
+        self._after_reset_masked(mask)
+
+    def _after_reset_masked(self, mask):
+        pass
+
     def _reset_strategy_default(self, env_ids):
         d = self.robot.data
         root_state = d.default_root_state[env_ids].clone()
@@ -252,6 +274,22 @@ class G1AmpEnv(_AmpEnv):
         self.last_actions[env_ids] = 0.0
         if getattr(self.cfg, "num_actor_observations", 1) > 1:
             self._just_reset_mask[env_ids] = True
+
+    def _after_reset_masked(self, mask):
+        self.last_actions.masked_fill_(mask[:, None], 0.0)
+        if getattr(self.cfg, "num_actor_observations", 1) > 1:
+            self._just_reset_mask |= mask
+        lo, hi = self.cfg.track_vel_range
+        t_lo, t_hi = self.cfg.command_resampling_time_range
+        if hi > lo:  # same distribution as _resample_commands, drawn for every env and kept where the mask is set
+            cmd = torch.rand((self.num_envs, 2), device=self.device) * (hi - lo) + lo
+            left = torch.rand(self.num_envs, device=self.device) * (t_hi - t_lo) + t_lo
+            self.command_target_speed.copy_(torch.where(mask[:, None], cmd, self.command_target_speed))
+            self.command_time_left.copy_(torch.where(mask, left, self.command_time_left))
+        else:
+            fixed = torch.tensor([lo, 0.0], device=self.device)
+            self.command_target_speed.copy_(torch.where(mask[:, None], fixed, self.command_target_speed))
+            self.command_time_left.masked_fill_(mask, float("inf"))
 
 
 class HumanoidAmpEnv(_AmpEnv):

@@ -58,6 +58,9 @@ class DirectRLEnv:
     def _reset_idx(self, env_ids):
         self.episode_length_buf[env_ids] = 0
 
+    def _reset_on_device(self):
+        raise NotImplementedError
+
     def _compact_reset_ids(self) -> torch.Tensor:
         """Ascending int64 ids of ``reset_buf``; tasks on the engine override this with the fused tile counts."""
         from ..engine import reset_compact
@@ -86,9 +89,12 @@ class DirectRLEnv:
         self.reset_terminated, self.reset_time_outs = self._get_dones()
         self.reset_buf = self.reset_terminated | self.reset_time_outs
         self.reward_buf = self._get_rewards()
-        reset_env_ids = self._compact_reset_ids()
-        if len(reset_env_ids) > 0:
-            self._reset_idx(reset_env_ids)
+        if getattr(self, "device_reset", False):
+            self._reset_on_device()   # engine path: no count read-back, no host RNG
+        else:
+            reset_env_ids = self._compact_reset_ids()
+            if len(reset_env_ids) > 0:
+                self._reset_idx(reset_env_ids)
         self.obs_buf = self._get_observations()
         return self.obs_buf, self.reward_buf, self.reset_terminated, self.reset_time_outs, self.extras
 

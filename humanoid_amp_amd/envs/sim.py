@@ -68,6 +68,28 @@ class SyntheticArticulation:
         self.data.joint_pos[env_ids] = joint_pos
         self.data.joint_vel[env_ids] = joint_vel
 
+    def write_reset_compact(self, env_ids: torch.Tensor, count: torch.Tensor, root_state: torch.Tensor, joint_pos: torch.Tensor,
+                            joint_vel: torch.Tensor):
+        """Device-only counterpart of the three write_*_to_sim calls: rows i < count of the compact arrays go to env
+        ``env_ids[i]``; nothing is read back to the host (rows >= count are routed to a scratch row)."""
+        d, N = self.data, self.num_envs
+        valid = torch.arange(env_ids.numel(), device=self.device) < count
+        tgt = torch.where(valid, env_ids, torch.full_like(env_ids, N))  # N = scratch row
+        def scatter(dst, src):
+            pad = torch.cat([dst, dst[:1]], dim=0)
+            pad.index_copy_(0, tgt, src)
+            dst.copy_(pad[:N])
+        nb = d.body_pos_w.shape[1]
+        scatter(d.joint_pos, joint_pos)
+        scatter(d.joint_vel, joint_vel)
+        scatter(d.body_pos_w, root_state[:, None, 0:3] + self._offsets[None])
+        scatter(d.body_quat_w, root_state[:, None, 3:7].expand(-1, nb, -1))
+        scatter(d.body_lin_vel_w, root_state[:, None, 7:10].expand(-1, nb, -1))
+        scatter(d.body_ang_vel_w, root_state[:, None, 10:13].expand(-1, nb, -1))
+        mask = torch.zeros(N + 1, dtype=torch.bool, device=self.device)
+        mask[tgt] = True
+        d.joint_acc.masked_fill_(mask[:N, None], 0.0)
+
     # ---- toy physics ------------------------------------------------------------------------------------
     def step(self):
         d, dt = self.data, self.dt

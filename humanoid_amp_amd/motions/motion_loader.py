@@ -291,6 +291,49 @@ class MotionLoader:
                                                       nat.stream_ptr()), "amp_collect_reference")
         return out
 
+    def sample_times_device(self, num_samples: int, start: bool = False, *, seed: int = 0, step: int = 0,
+                            index: torch.Tensor | None = None, count: torch.Tensor | None = None):
+        """Device-side :meth:`sample_times`: (motion_ids int64 [n], times float64 [n]) drawn with the counter-based
+        Philox generator keyed by ``(seed, step, index[i] or i)`` -- no host RNG, no H2D copy.  ``count`` (device int64
+        [1]) caps the draws without a read-back.  Distribution as the reference; the random stream is the engine's own."""
+        h = self._need_handle()
+        n = int(num_samples)
+        ids = torch.zeros(n, dtype=torch.int64, device=self._tdev)
+        times = torch.zeros(n, dtype=torch.float64, device=self._tdev)
+        with torch.cuda.device(self._tdev):
+            nat.check(self._lib.amp_motion_sample_times(h, int(seed) & (2**64 - 1), int(step) & (2**64 - 1), int(bool(start)),
+                                                        nat.dptr(index, torch.int64, "index"), nat.dptr(count, torch.int64, "count"),
+                                                        n, nat.dptr(ids), nat.dptr(times), nat.stream_ptr()),
+                      "amp_motion_sample_times")
+        return ids, times
+
+    def reset_apply(self, env_ids: torch.Tensor, count: torch.Tensor, num_amp_observations: int, *, seed: int, step: int,
+                    start: bool, env_origins: torch.Tensor | None, z_lift: float, amp_observation_buffer: torch.Tensor,
+                    out: dict | None = None) -> dict:
+        """The whole reference-state reset (g1_amp_env.py:371-419) on the device-side output of the reset compaction:
+        for i < count, env = env_ids[i]: draw (clip, t), write root_state[i] / dof_pos[i] / dof_vel[i] and the K expert
+        frames into ``amp_observation_buffer[env]``.  Returns the (reusable) compact output tensors."""
+        h = self._need_handle()
+        if self._layout is None:
+            raise nat.AmpEngineError("call set_obs_layout first")
+        n = env_ids.numel()
+        if out is None:
+            f32 = dict(dtype=torch.float32, device=self._tdev)
+            out = dict(root_state=torch.zeros((n, 13), **f32), dof_pos=torch.zeros((n, self.num_dofs), **f32),
+                       dof_vel=torch.zeros((n, self.num_dofs), **f32), motion_ids=torch.zeros(n, dtype=torch.int64, device=self._tdev),
+                       motion_times=torch.zeros(n, dtype=torch.float64, device=self._tdev))
+        a = nat.AmpResetArgs()
+        a.env_ids, a.count, a.max_n = nat.dptr(env_ids, torch.int64, "env_ids").value, nat.dptr(count, torch.int64, "count").value, n
+        a.seed, a.step, a.start, a.K = int(seed) & (2**64 - 1), int(step) & (2**64 - 1), int(bool(start)), int(num_amp_observations)
+        a.env_origins = nat.dptr(env_origins, torch.float32, "env_origins").value
+        a.z_lift = float(z_lift)
+        a.root_state, a.dof_pos, a.dof_vel = (out[k].data_ptr() for k in ("root_state", "dof_pos", "dof_vel"))
+        a.amp_obs_buffer = nat.dptr(amp_observation_buffer, torch.float32, "amp_observation_buffer").value
+        a.motion_ids, a.motion_times = out["motion_ids"].data_ptr(), out["motion_times"].data_ptr()
+        with torch.cuda.device(self._tdev):
+            nat.check(self._lib.amp_reset_apply(h, C.byref(a), nat.stream_ptr()), "amp_reset_apply")
+        return out
+
     def reset_reference_state(self, times, motion_ids, env_ids=None, env_origins: torch.Tensor | None = None,
                               z_lift: float = 0.0):
         """(root_state [n,13], dof_pos [n,Dof], dof_vel [n,Dof]) of the reference body for reset envs

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define AMP_ABI_VERSION 2
+#define AMP_ABI_VERSION 3
 
 typedef void* amp_stream_t; /* hipStream_t */
 typedef void* amp_event_t;  /* hipEvent_t  */
@@ -112,6 +112,35 @@ int amp_collect_reference(const AmpMotion* h, const double* times_dev, const int
 int amp_reset_reference_state(const AmpMotion* h, const double* times_dev, const int64_t* motion_ids_dev,
                               const int64_t* env_ids_dev, int64_t n, const float* env_origins_dev, float z_lift,
                               float* root_state_dev, float* dof_pos_dev, float* dof_vel_dev, amp_stream_t stream);
+
+/* Device-side MotionLoader.sample_times (motion_loader.py:309-329) for the reset path: counter-based Philox4x32-10,
+ * key = seed, counter = (index_dev[i] or i, step).  clip ~ U{0..n_clips-1}, t = 0 (start != 0) or U[0,1) * duration.
+ * n_dev (device int64, may be NULL) caps the number of draws at min(n, *n_dev) without a host read-back.
+ * Parity with the reference's host numpy RNG is distributional only; bit-exact against oracle/rng.py. */
+int amp_motion_sample_times(const AmpMotion* h, uint64_t seed, uint64_t step, int32_t start, const int64_t* index_dev,
+                            const int64_t* n_dev, int64_t n, int64_t* motion_ids_dev, double* times_dev, amp_stream_t stream);
+
+/* The whole reference-state reset of G1AmpEnv._reset_strategy_random (g1_amp_env.py:371-419) driven by the DEVICE-side
+ * output of amp_reset_compact* -- no count read-back, no host RNG: for i < *count, env = env_ids[i]:
+ * (clip, t) drawn with (seed, step, env); root_state / dof rows i; amp_obs_buffer[env] = K expert frames. */
+typedef struct {
+  const int64_t* env_ids;   /* dev [max_n] ascending reset ids */
+  const int64_t* count;     /* dev [1] */
+  int64_t max_n;            /* capacity of the compact outputs (num_envs) */
+  uint64_t seed, step;
+  int32_t start;            /* reset_strategy "random-start" */
+  int32_t K;
+  const float* env_origins; /* dev [num_envs, 3] or NULL */
+  float z_lift;
+  int32_t reserved;
+  float* root_state;        /* dev [max_n, 13] compact, may be NULL */
+  float* dof_pos;           /* dev [max_n, n_dof] compact, may be NULL */
+  float* dof_vel;
+  float* amp_obs_buffer;    /* dev [num_envs, K, D], rows env_ids[i] overwritten; may be NULL */
+  int64_t* motion_ids;      /* dev [max_n] compact out */
+  double* motion_times;     /* dev [max_n] compact out */
+} AmpResetArgs;
+int amp_reset_apply(const AmpMotion* h, const AmpResetArgs* args, amp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Per-step env kernels  (replace G1AmpEnv._get_dones / _get_rewards / _get_observations,

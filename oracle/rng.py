@@ -1,0 +1,43 @@
+"""Oracle: Philox4x32-10 + the device-side sample_times draw (TEST INFRASTRUCTURE ONLY).
+
+The reference samples reset times with the host's global numpy RNG (motions/motion_loader.py:321-327), which cannot be
+reproduced on a device; the engine's device reset path uses a counter-based generator instead (parity with the
+reference: distributional only).  This numpy restatement of the published Philox4x32-10 algorithm (Salmon et al.,
+"Parallel Random Numbers: As Easy as 1, 2, 3", SC'11; constants as in Random123) pins the HIP kernel bit for bit, and
+is itself pinned by the Random123 known-answer vectors in tests/test_oracle_rng.py.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+W0, W1 = 0x9E3779B9, 0xBB67AE85
+MASK = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Vectorised over numpy uint64 arrays holding 32-bit words; returns four uint64 arrays of 32-bit words."""
+    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint64) & MASK for c in (c0, c1, c2, c3))
+    k0, k1 = int(k0) & 0xFFFFFFFF, int(k1) & 0xFFFFFFFF
+    for _ in range(10):
+        p0, p1 = M0 * c0, M1 * c2
+        n0 = (p1 >> np.uint64(32)) ^ c1 ^ np.uint64(k0)
+        n1 = p1 & MASK
+        n2 = (p0 >> np.uint64(32)) ^ c3 ^ np.uint64(k1)
+        n3 = p0 & MASK
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0, k1 = (k0 + W0) & 0xFFFFFFFF, (k1 + W1) & 0xFFFFFFFF
+    return c0, c1, c2, c3
+
+
+def sample_times(durations: np.ndarray, seed: int, step: int, index: np.ndarray, start: bool = False):
+    """(motion_ids int64, times float64) exactly as csrc/motion.hip::sample_times_kernel draws them."""
+    index = np.asarray(index, dtype=np.uint64)
+    n_clips = len(durations)
+    r0, r1, r2, _ = philox4x32_10(index & MASK, index >> np.uint64(32), step & 0xFFFFFFFF, (step >> 32) & 0xFFFFFFFF,
+                                  seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    ids = ((r0 * np.uint64(n_clips)) >> np.uint64(32)).astype(np.int64)
+    u = ((r1 >> np.uint64(5)).astype(np.float64) * 67108864.0 + (r2 >> np.uint64(6)).astype(np.float64)) / 9007199254740992.0
+    times = np.zeros(len(index)) if start else u * np.asarray(durations, dtype=np.float64)[ids]
+    return ids, times

@@ -1,0 +1,94 @@
+"""GPU: the device-side reset path: counter-based sample_times bit-exact vs the Philox oracle,
+amp_reset_apply == the host-driven calls on the same draws, and an env stepped with device_reset=True against the
+oracle (no host sync inside step)."""
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from oracle import env as oenv
+from oracle import motion as om
+from oracle import rng as orng
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def test_sample_times_device_bit_exact_vs_oracle():
+    from humanoid_amp_amd.motions import MotionLoader
+
+    ml = MotionLoader(",".join(gu.clip_files("humanoid3")), "cuda:0")
+    idx = torch.randperm(100000, generator=torch.Generator().manual_seed(0))[:5000].cuda()
+    for seed, step, start in ((0, 0, False), (2**40 + 17, 2**33 + 5, False), (9, 3, True)):
+        ids, t = ml.sample_times_device(5000, start, seed=seed, step=step, index=idx)
+        want_ids, want_t = orng.sample_times(ml.durations, seed, step, idx.cpu().numpy(), start)
+        assert np.array_equal(ids.cpu().numpy(), want_ids) and np.array_equal(t.cpu().numpy(), want_t)
+    # count caps the draws on the device
+    count = torch.tensor([123], device="cuda")
+    ids, t = ml.sample_times_device(5000, seed=1, step=2, index=idx, count=count)
+    assert float(t[123:].abs().max()) == 0.0 and float(t[:123].max()) > 0.0
+    ids0, t0 = ml.sample_times_device(7, seed=1, step=2)  # index defaults to arange
+    w_ids, w_t = orng.sample_times(ml.durations, 1, 2, np.arange(7))
+    assert np.array_equal(t0.cpu().numpy(), w_t) and np.array_equal(ids0.cpu().numpy(), w_ids)
+
+
+def test_reset_apply_equals_host_driven_reset():
+    from humanoid_amp_amd.engine import reset_compact
+    from humanoid_amp_amd.motions import MotionLoader
+    from humanoid_amp_amd.robots import G1_JOINT_NAMES, G1_KEY_BODY_NAMES
+
+    ml = MotionLoader(gu.clip_files("g1_dance")[0], "cuda:0")
+    ml.set_obs_layout(ml.get_dof_index(G1_JOINT_NAMES), 0, ml.get_body_index(G1_KEY_BODY_NAMES))
+    N, K, D = 3000, 10, 83
+    mask = torch.rand(N, generator=torch.Generator().manual_seed(1)) < 0.2
+    ids, count = reset_compact(mask.cuda())
+    origins = torch.randn(N, 3, device="cuda")
+    buf = torch.randn(N, K, D, device="cuda")
+    ref_buf = buf.clone()
+    out = ml.reset_apply(ids, count, K, seed=5, step=77, start=False, env_origins=origins, z_lift=0.05, amp_observation_buffer=buf)
+    n = int(count)
+    m_ids, m_t = orng.sample_times(ml.durations, 5, 77, ids[:n].cpu().numpy())
+    assert np.array_equal(out["motion_ids"][:n].cpu().numpy(), m_ids) and np.array_equal(out["motion_times"][:n].cpu().numpy(), m_t)
+    root, dpos, dvel = ml.reset_reference_state(m_t, m_ids, env_ids=ids[:n], env_origins=origins, z_lift=0.05)
+    assert torch.equal(out["root_state"][:n], root) and torch.equal(out["dof_pos"][:n], dpos) and torch.equal(out["dof_vel"][:n], dvel)
+    ml.collect_reference(m_t, m_ids, K, out=ref_buf, dst_rows=ids[:n])
+    assert torch.equal(buf, ref_buf)  # reset rows overwritten, every other row untouched
+
+
+@pytest.mark.parametrize("strategy", ["random", "random-start"])
+def test_env_device_reset_loop(strategy):
+    from humanoid_amp_amd.envs import G1AmpDanceEnvCfg, G1AmpEnv
+    from humanoid_amp_amd.robots import G1_KEY_BODY_NAMES
+
+    cfg = G1AmpDanceEnvCfg(reset_strategy=strategy, num_amp_observations=2)
+    cfg.scene.num_envs = 300
+    cfg.episode_length_s = 0.15
+    env = G1AmpEnv(cfg, device_reset=True, reset_seed=11)
+    mt = om.load_tables([cfg.motion_file])
+    keys = [mt.body_names.index(n) for n in G1_KEY_BODY_NAMES]
+    torch.manual_seed(0)
+    env.reset()
+    shadow = env.amp_observation_buffer.clone().cpu()
+    r, total_resets = env.ref_body_index, 0
+    for step in range(20):
+        obs, rew, term, tout, extras = env.step(torch.randn(300, 29, device="cuda") * 0.3)
+        mask = (term | tout).cpu()
+        ids = mask.nonzero().squeeze(-1)
+        total_resets += len(ids)
+        if len(ids):
+            m_ids, m_t = orng.sample_times(mt.durations, 11, env.common_step_counter, ids.numpy(), "start" in strategy)
+            rows = oenv.collect_reference(mt, m_t, m_ids, 2, env.motion_dof_indexes, 0, keys).view(len(ids), 2, -1)
+            shadow[ids] = rows
+            root, dpos, _ = oenv.reset_reference_state(mt, m_t, m_ids, env.motion_dof_indexes, 0, env.scene.env_origins.cpu()[ids], 0.05)
+            d = env.robot.data
+            assert float((d.joint_pos.cpu()[ids] - dpos).abs().max()) == 0.0
+            assert float((d.body_pos_w.cpu()[ids, r] - root[:, :3]).abs().max()) == 0.0
+            assert int(env.episode_length_buf.cpu()[ids].max()) == 0
+            assert float(env.last_actions.cpu()[ids].abs().max()) == 0.0
+        d = env.robot.data
+        ob = oenv.compute_obs(d.joint_pos.cpu(), d.joint_vel.cpu(), d.body_pos_w[:, r].cpu(), d.body_quat_w[:, r].cpu(),
+                              d.body_lin_vel_w[:, r].cpu(), d.body_ang_vel_w[:, r].cpu(), d.body_pos_w[:, env.key_body_indexes].cpu())
+        amp = oenv.shift_history(shadow, ob)
+        assert float((extras["amp_obs"].cpu() - amp).abs().max()) <= TOL
+    assert total_resets > 300
