@@ -336,6 +336,7 @@ using namespace amp;
 extern "C" {
 
 int32_t amp_env_step_tile_envs(int64_t num_envs) {
+  // measured (MI355X, G1 K=2): 65 536 envs 72 / 78 / 91 us with 64 / 32 / 16-env tiles; 16 384 envs 39 / 27 / 23 us
   // envs per workgroup: 64 when that still gives >= 1024 workgroups (4 per CU), else smaller tiles so that a small
   // shard is spread over the whole chip (the kernel is latency-bound there: one 64-env tile takes ~25 us alone)
   if (num_envs >= 64 * 1024) return 64;

@@ -31,6 +31,7 @@ struct MotionView {
   const float* body_ang;
   const float* hot;  // [F, D] private hot-subset table
   int32_t n_dof, n_bodies, n_key, D;
+  int32_t HP;  // floats per hot row: D rounded up to a multiple of 4 (16-B aligned rows for dwordx4 gathers)
 };
 
 }  // namespace amp
@@ -88,10 +89,14 @@ __global__ __launch_bounds__(kBlock) void build_hot_kernel(MotionView v, int64_t
                                                            int32_t ref, const int32_t* __restrict__ keys,
                                                            float* __restrict__ hot) {
   const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const int D = v.D;
-  if (e >= n_frames * D) return;
-  const int64_t f = e / D;
-  const int j = (int)(e - f * D);
+  const int D = v.D, HP = v.HP;
+  if (e >= n_frames * HP) return;
+  const int64_t f = e / HP;
+  const int j = (int)(e - f * HP);
+  if (j >= D) {
+    hot[e] = 0.0f;  // row padding
+    return;
+  }
   const int nd = v.n_dof, B = v.n_bodies;
   float val;
   if (j < nd) {
@@ -197,15 +202,20 @@ struct ExpertSlot {
 };
 
 constexpr int kExpertTile = 64;  // samples per workgroup: many short workgroups hide the L2 gather latency
-constexpr int kExpertUnroll = 4; // independent (gather, gather) pairs in flight per lane
 
+// Phase A: one sample per lane (fp64 frame/blend, SLERP of the reference quaternion, tangent/normal).
+// Phase B: a lane LERPs FOUR consecutive columns of one sample from two 16-B gathers (hot rows are padded to a
+//          16-B pitch) and drops them into an LDS image of the tile's output, which is contiguous in HBM
+//          ([64 samples][D floats], 16-B aligned) unless rows are scattered (dst_rows).
+// Phase C: the image is streamed out with 16-B stores, 1 KiB per wave instruction.
 __global__ __launch_bounds__(kBlock) void collect_reference_kernel(MotionView v, const double* __restrict__ times,
                                                                    const int64_t* __restrict__ ids, int64_t n, int K,
                                                                    float* __restrict__ out,
                                                                    const int64_t* __restrict__ dst_rows,
                                                                    const int64_t* __restrict__ n_dev) {
-  __shared__ ExpertSlot slots[kExpertTile];
-  const int D = v.D, nd2 = 2 * v.n_dof;
+  extern __shared__ __attribute__((aligned(16))) float s_img[];  // [64][D] output image, then the slots
+  const int D = v.D, HP = v.HP, nd2 = 2 * v.n_dof;
+  ExpertSlot* slots = reinterpret_cast<ExpertSlot*>(s_img + ((kExpertTile * D + 3) & ~3));
   if (n_dev) n = *n_dev < n ? *n_dev : n;  // device-side sample count (reset path without a host read-back)
   const int64_t total = n * K;
   const int64_t tile_base = (int64_t)blockIdx.x * kExpertTile;
@@ -225,8 +235,8 @@ __global__ __launch_bounds__(kBlock) void collect_reference_kernel(MotionView v,
     sl.i0 = (int32_t)a;
     sl.i1 = (int32_t)b;
     sl.blend = (float)w;
-    const float* r0 = hot + a * D + nd2;
-    const float* r1 = hot + b * D + nd2;
+    const float* r0 = hot + a * HP + nd2;
+    const float* r1 = hot + b * HP + nd2;
     sl.rp[0] = lerp_ref(r0[0], r1[0], sl.blend);
     sl.rp[1] = lerp_ref(r0[1], r1[1], sl.blend);
     sl.rp[2] = lerp_ref(r0[2], r1[2], sl.blend);
@@ -240,35 +250,49 @@ __global__ __launch_bounds__(kBlock) void collect_reference_kernel(MotionView v,
     slots[threadIdx.x] = sl;
   }
   __syncthreads();
-  // flat walk over the tile's n_tile*D output floats, kExpertUnroll independent elements per lane per trip:
-  // all gathers of a trip are issued before the first LERP / store
-  const int count = n_tile * D;
-  const float inv_d = 1.0f / (float)D;
-  for (int e0 = threadIdx.x; e0 < count; e0 += kExpertUnroll * kBlock) {
-    int sv[kExpertUnroll], jv[kExpertUnroll];
-    float av[kExpertUnroll], bv[kExpertUnroll];
+  // ---- phase B: (sample, quad) items; both gathers of an item are 16-B loads --------------------------
+  const int QP = HP >> 2;  // quads per row
+  const f4* __restrict__ hot4 = reinterpret_cast<const f4*>(hot);
+  for (int it = threadIdx.x; it < n_tile * QP; it += kBlock) {
+    const int s = it / QP, q = it - s * QP;
+    const ExpertSlot& sl = slots[s];
+    const f4 a = hot4[(int64_t)sl.i0 * QP + q];
+    const f4 b = hot4[(int64_t)sl.i1 * QP + q];
+    float* img = s_img + s * D;
 #pragma unroll
-    for (int u = 0; u < kExpertUnroll; ++u) {
-      int e = e0 + u * kBlock;
-      e = e < count ? e : count - 1;
-      const int s = (int)(((float)e + 0.5f) * inv_d);  // exact for e < 2^16 (|error| << 0.5 / D)
-      const int j = e - s * D;
-      sv[u] = s;
-      jv[u] = j;
-      const int col = (j >= nd2 && j <= nd2 + 6) ? nd2 + 2 : j;  // root height reads the z column; tangent|normal come from LDS
-      av[u] = hot[(int64_t)slots[s].i0 * D + col];
-      bv[u] = hot[(int64_t)slots[s].i1 * D + col];
-    }
-#pragma unroll
-    for (int u = 0; u < kExpertUnroll; ++u) {
-      if (e0 + u * kBlock < count) {
-        const ExpertSlot& sl = slots[sv[u]];
-        const int j = jv[u];
-        float val = lerp_ref(av[u], bv[u], sl.blend);
-        if (j > nd2 && j <= nd2 + 6) val = sl.tn[j - nd2 - 1];
+    for (int c = 0; c < 4; ++c) {
+      const int j = 4 * q + c;
+      if (j >= D) break;
+      float val;
+      if (j == nd2) {
+        val = sl.rp[2];                       // root height = lerped z (bit-identical to lerp of the z column)
+      } else if (j <= nd2 + 6 && j > nd2) {
+        val = sl.tn[j - nd2 - 1];             // tangent | normal
+      } else {
+        val = lerp_ref(a[c], b[c], sl.blend);
         if (j >= nd2 + 13) val = val - sl.rp[(j - nd2 - 13) % 3];  // key body relative to the reference body (:552)
-        out[sl.obase + j] = val;
       }
+      img[j] = val;
+    }
+  }
+  __syncthreads();
+  // ---- phase C: stream the image out -------------------------------------------------------------------
+  if (!dst_rows) {
+    // rows of consecutive samples are contiguous: the whole tile is one 16-B aligned run (64 * D floats)
+    float* dst = out + tile_base * D;
+    const int count = n_tile * D;
+    if ((count & 3) == 0 && (((uintptr_t)dst) & 15) == 0) {
+      const f4* src4 = reinterpret_cast<const f4*>(s_img);
+      f4* dst4 = reinterpret_cast<f4*>(dst);
+      for (int e = threadIdx.x; e < (count >> 2); e += kBlock) dst4[e] = src4[e];
+    } else {
+      for (int e = threadIdx.x; e < count; e += kBlock) dst[e] = s_img[e];
+    }
+  } else {
+    // scattered rows (reset path): every K-run of samples of one env is contiguous; store per sample
+    for (int e = threadIdx.x; e < n_tile * D; e += kBlock) {
+      const int s = e / D, j = e - s * D;
+      out[slots[s].obase + j] = s_img[e];
     }
   }
 }
@@ -283,7 +307,7 @@ __global__ __launch_bounds__(kBlock) void reset_state_kernel(MotionView v, const
                                                              float* __restrict__ root, float* __restrict__ o_dp,
                                                              float* __restrict__ o_dv, const int64_t* __restrict__ n_dev) {
   __shared__ SampleSlot slots[kBlock];
-  const int D = v.D, nd = v.n_dof;
+  const int nd = v.n_dof;
   if (n_dev) n = *n_dev < n ? *n_dev : n;
   const int64_t tile_base = (int64_t)blockIdx.x * kBlock;
   if (tile_base >= n) return;
@@ -297,8 +321,8 @@ __global__ __launch_bounds__(kBlock) void reset_state_kernel(MotionView v, const
     const float bl = (float)w;
     slots[threadIdx.x] = SampleSlot{(int32_t)a, (int32_t)b, bl};
     if (root) {
-      const float* r0 = hot + a * D + 2 * nd;
-      const float* r1 = hot + b * D + 2 * nd;
+      const float* r0 = hot + a * v.HP + 2 * nd;
+      const float* r1 = hot + b * v.HP + 2 * nd;
       const int64_t env = env_ids ? env_ids[i] : i;
       float* o = root + i * 13;
       const float* og = origins ? origins + env * 3 : nullptr;
@@ -322,7 +346,7 @@ __global__ __launch_bounds__(kBlock) void reset_state_kernel(MotionView v, const
     float* o = out + tile_base * nd;
     for (int e = threadIdx.x; e < n_tile * nd; e += kBlock) {
       const SampleSlot sl = slots[s];
-      o[e] = lerp_ref(hot[(int64_t)sl.i0 * D + off + j], hot[(int64_t)sl.i1 * D + off + j], sl.blend);
+      o[e] = lerp_ref(hot[(int64_t)sl.i0 * v.HP + off + j], hot[(int64_t)sl.i1 * v.HP + off + j], sl.blend);
       s += step_s;
       j += step_j;
       if (j >= nd) {
@@ -371,6 +395,7 @@ __global__ __launch_bounds__(kBlock) void sample_times_kernel(ClipMeta m, uint64
 }
 
 static inline unsigned grid_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+static inline size_t expert_lds(int D) { return sizeof(float) * (size_t)((kExpertTile * D + 3) & ~3) + sizeof(ExpertSlot) * kExpertTile; }
 
 }  // namespace amp
 
@@ -436,6 +461,7 @@ int amp_motion_create(const AmpMotionDesc* d, AmpMotion** out) {
   v.n_bodies = d->n_bodies;
   v.n_key = 0;
   v.D = 0;
+  v.HP = 0;
   *out = h;
   return AMP_OK;
 }
@@ -467,7 +493,8 @@ int amp_motion_set_obs_layout(AmpMotion* h, const int32_t* dof_perm, int32_t ref
   (void)hipFree(h->d_perm);
   h->d_hot = nullptr;
   h->d_perm = nullptr;
-  AMP_HIP(hipMalloc(&h->d_hot, sizeof(float) * h->n_frames * D));
+  const int HP = (D + 3) / 4 * 4;
+  AMP_HIP(hipMalloc(&h->d_hot, sizeof(float) * h->n_frames * HP));
   AMP_HIP(hipMalloc(&h->d_perm, sizeof(int32_t) * (h->v.n_dof + kMaxKey)));
   hipStream_t st = (hipStream_t)stream;
   AMP_HIP(hipMemcpyAsync(h->d_perm, dof_perm, sizeof(int32_t) * h->v.n_dof, hipMemcpyHostToDevice, st));
@@ -477,8 +504,9 @@ int amp_motion_set_obs_layout(AmpMotion* h, const int32_t* dof_perm, int32_t ref
   for (int i = 0; i < n_key; ++i) h->key_bodies[i] = key_bodies[i];
   h->v.n_key = n_key;
   h->v.D = D;
+  h->v.HP = HP;
   h->v.hot = h->d_hot;
-  const int64_t total = h->n_frames * D;
+  const int64_t total = h->n_frames * h->v.HP;
   { amp::TraceScope trace__("build_hot_kernel", st);
     build_hot_kernel<<<grid_for(total, kBlock), kBlock, 0, st>>>(h->v, h->n_frames, h->d_perm, ref_body, h->d_perm + h->v.n_dof,
                                                               h->d_hot);
@@ -524,7 +552,7 @@ int amp_collect_reference(const AmpMotion* h, const double* times, const int64_t
   if (n == 0) return AMP_OK;
   AMP_REQUIRE(times && out, "amp_collect_reference: null buffer");
   { amp::TraceScope trace__("collect_reference_kernel", (hipStream_t)stream);
-    collect_reference_kernel<<<grid_for(n * K, kExpertTile), kBlock, 0, (hipStream_t)stream>>>(h->v, times, ids, n, K, out, dst_rows, nullptr);
+    collect_reference_kernel<<<grid_for(n * K, kExpertTile), kBlock, expert_lds(h->v.D), (hipStream_t)stream>>>(h->v, times, ids, n, K, out, dst_rows, nullptr);
   }
   return launch_status("collect_reference_kernel");
 }
@@ -565,7 +593,7 @@ int amp_reset_apply(const AmpMotion* h, const AmpResetArgs* a, amp_stream_t stre
   if (rc != AMP_OK) return rc;
   if (a->amp_obs_buffer) {
     amp::TraceScope trace__("collect_reference_kernel", st);
-    collect_reference_kernel<<<grid_for(n * a->K, kExpertTile), kBlock, 0, st>>>(h->v, a->motion_times, a->motion_ids, n, a->K,
+    collect_reference_kernel<<<grid_for(n * a->K, kExpertTile), kBlock, expert_lds(h->v.D), st>>>(h->v, a->motion_times, a->motion_ids, n, a->K,
                                                                               a->amp_obs_buffer, a->env_ids, a->count);
   }
   return launch_status("collect_reference_kernel");
