@@ -64,6 +64,8 @@ def timed_steps(hot, steps, warmup, world, collective):
         hot.step()
         if collective and (i + 1) % collective["every"] == 0:
             collective["fn"]()
+    if collective and "join" in collective:
+        collective["join"]()  # every all-gather issued inside the timed region completes inside it
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -184,8 +186,11 @@ def main():
         hot = HotPath(spec, args.envs, device, seed=1234 + rank)
     collective = None
     if world > 1:
-        ag = ReplayAllGather(hot.kernel.amp_observation_buffer.view(args.envs, -1), args.replay_minibatch, seed=rank)
-        collective = {"every": args.rollouts, "fn": lambda: [ag() for _ in range(args.minibatches)]}
+        # the gathered minibatches feed the (out-of-scope) discriminator update, so nothing in the env path waits for
+        # them: they are launched asynchronously (RCCL stream) and joined before the timed region ends
+        ag = ReplayAllGather(hot.kernel.amp_observation_buffer.view(args.envs, -1), args.replay_minibatch, seed=rank,
+                             slots=args.minibatches)
+        collective = {"every": args.rollouts, "fn": lambda: [ag.start() for _ in range(args.minibatches)], "join": ag.wait_all}
 
     # ---- timed region: exactly --steps steps, the dominant kernel bracketed by HIP events on its stream --------
     with nat.KernelTrace(capacity=args.steps + args.warmup + 8, kernel_filter=DOMINANT_KERNEL) as tr:
@@ -224,7 +229,8 @@ def main():
                                    f"[{spec.K * spec.D},1024,512,1] seed-0 init", "envs_per_gpu": args.envs,
                        "global_envs": args.envs * world, "parallelism": f"env-shard x{world}",
                        "collective": (f"RCCL all-gather [{args.replay_minibatch},{spec.K * spec.D}] f32 per rank x "
-                                      f"{args.minibatches} every {args.rollouts} steps") if world > 1 else "none"},
+                                      f"{args.minibatches} every {args.rollouts} steps, async on the RCCL stream, joined inside "
+                                      "the timed region") if world > 1 else "none"},
             "roofline": {"bound": "mfma", "kernel": DOMINANT_KERNEL, "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
                          "avg_launch_ms": gemm2_ms, "launches_timed": len(recs), "flops_per_launch": flops2},

@@ -51,16 +51,54 @@ def allgather_minibatch(shard: torch.Tensor, out: torch.Tensor | None = None, gr
 
 
 class ReplayAllGather:
-    """Draw ``rows`` random rows of this rank's AMP observations and all-gather them (one discriminator minibatch)."""
+    """Draw ``rows`` random rows of this rank's AMP observations and all-gather them (one discriminator minibatch).
 
-    def __init__(self, amp_obs: torch.Tensor, rows: int, seed: int = 0, group=None):
+    ``slots`` independent (shard, output) buffer pairs let that many gathers be in flight: ``start()`` enqueues the
+    row draw on the current stream and launches the collective asynchronously on RCCL's stream, so it runs under the
+    following env steps / GEMMs; ``wait_all()`` (or the next ``start()`` on a busy slot) joins them.  ``__call__`` is
+    the blocking form."""
+
+    def __init__(self, amp_obs: torch.Tensor, rows: int, seed: int = 0, group=None, slots: int = 1):
         self.amp_obs, self.rows, self.group = amp_obs, int(rows), group
         self.gen = torch.Generator(device=amp_obs.device).manual_seed(seed)
         world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.shard = torch.empty((self.rows, amp_obs.shape[1]), dtype=amp_obs.dtype, device=amp_obs.device)
-        self.out = torch.empty((world * self.rows, amp_obs.shape[1]), dtype=amp_obs.dtype, device=amp_obs.device)
+        mk = lambda n: torch.empty((n, amp_obs.shape[1]), dtype=amp_obs.dtype, device=amp_obs.device)  # noqa: E731
+        self.shards = [mk(self.rows) for _ in range(slots)]
+        self.outs = [mk(world * self.rows) for _ in range(slots)]
+        self.works = [None] * slots
+        self._next = 0
+        self._async = dist.is_initialized() and world > 1 and (not amp_obs.is_cuda or dist.get_backend(group) == "nccl")
+
+    def _draw(self, slot: int):
+        idx = torch.randint(0, self.amp_obs.shape[0], (self.rows,), generator=self.gen, device=self.amp_obs.device)
+        torch.index_select(self.amp_obs, 0, idx, out=self.shards[slot])
 
     def __call__(self) -> torch.Tensor:
-        idx = torch.randint(0, self.amp_obs.shape[0], (self.rows,), generator=self.gen, device=self.amp_obs.device)
-        torch.index_select(self.amp_obs, 0, idx, out=self.shard)
-        return allgather_minibatch(self.shard, self.out, self.group)
+        self._draw(0)
+        return allgather_minibatch(self.shards[0], self.outs[0], self.group)
+
+    def start(self) -> int:
+        """Begin one gather in the next slot (waits first if that slot is still in flight); returns the slot."""
+        slot = self._next
+        self._next = (self._next + 1) % len(self.shards)
+        if self.works[slot] is not None:
+            self.works[slot].wait()
+            self.works[slot] = None
+        self._draw(slot)
+        if self._async:
+            self.works[slot] = dist.all_gather_into_tensor(self.outs[slot], self.shards[slot], group=self.group, async_op=True)
+        else:
+            allgather_minibatch(self.shards[slot], self.outs[slot], self.group)
+        return slot
+
+    def wait_all(self):
+        for i, w in enumerate(self.works):
+            if w is not None:
+                w.wait()
+                self.works[i] = None
+
+    def result(self, slot: int) -> torch.Tensor:
+        if self.works[slot] is not None:
+            self.works[slot].wait()
+            self.works[slot] = None
+        return self.outs[slot]

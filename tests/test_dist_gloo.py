@@ -39,6 +39,12 @@ def _worker(rank, world, port, out_dir):
     assert got.shape == (world * 8, 6)
     for r in range(world):  # every block comes from rank r's table
         assert bool(((got[r * 8:(r + 1) * 8] // 1000).long() == r).all())
+    rg3 = ReplayAllGather(table, rows=4, seed=rank, slots=2)  # async slots, wrap-around
+    for _ in range(5):
+        s = rg3.start()
+    rg3.wait_all()
+    last = rg3.result(s)
+    assert last.shape == (world * 4, 6) and bool(((last[:4] // 1000).long() == 0).all()) and bool(((last[4:] // 1000).long() == 1).all())
 
     # (2) env sharding: each rank computes its contiguous env block of the oracle path; rank 0 checks the concatenation
     clips = [os.path.join(ROOT, "humanoid_amp_amd", "motions", "G1_walk.npz")]

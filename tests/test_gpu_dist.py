@@ -35,6 +35,13 @@ def test_rccl_world1_allgather_and_bench_collective():
         assert out.shape == (4096, 166)
         # every gathered row is a row of the table
         assert bool((out[:8].unsqueeze(1) == table.unsqueeze(0)).all(dim=2).any(dim=1).all())
+        # asynchronous slots (the bench's schedule)
+        rg2 = ReplayAllGather(table, rows=512, seed=1, slots=3)
+        rg2._async = True  # world size 1 would short-circuit: force the real async collective
+        slots = [rg2.start() for _ in range(5)]  # wraps around: slots 0 and 1 are waited and reused
+        rg2.wait_all()
+        assert slots == [0, 1, 2, 0, 1] and all(w is None for w in rg2.works)
+        assert bool((rg2.result(2)[:4].unsqueeze(1) == table.unsqueeze(0)).all(dim=2).any(dim=1).all())
         t = torch.tensor([1.5], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the max-over-ranks timing reduction of bench.py
         dist.barrier()
