@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libamp_engine.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 AMP_PHASE_DONES, AMP_PHASE_REWARD, AMP_PHASE_OBS = 1, 2, 4
 AMP_PHASE_ALL = 7
@@ -39,6 +39,15 @@ class AmpResetArgs(C.Structure):
         ("start", C.c_int32), ("K", C.c_int32), ("env_origins", C.c_void_p), ("z_lift", C.c_float), ("reserved", C.c_int32),
         ("root_state", C.c_void_p), ("dof_pos", C.c_void_p), ("dof_vel", C.c_void_p), ("amp_obs_buffer", C.c_void_p),
         ("motion_ids", C.c_void_p), ("motion_times", C.c_void_p),
+    ]
+
+
+class AmpDiscTrainCfg(C.Structure):
+    _fields_ = [
+        ("max_rows_per_group", C.c_int64), ("learning_rate", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
+        ("adam_epsilon", C.c_float), ("loss_scale", C.c_float), ("logit_reg_scale", C.c_float), ("grad_penalty_scale", C.c_float),
+        ("weight_decay_scale", C.c_float), ("scaler_epsilon", C.c_float), ("scaler_clip", C.c_float), ("use_scaler", C.c_int32),
+        ("update_scaler", C.c_int32), ("apply_update", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -121,6 +130,11 @@ SIGNATURES = {
     "amp_disc_set_precision": (C.c_int, [_vp, _i32, _vp]),
     "amp_disc_workspace_bytes": (_i64, [_vp, _i64]),
     "amp_disc_input_layout": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_f32)]),
+    "amp_disc_get_weights": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "amp_disc_trainer_create": (C.c_int, [_vp, C.POINTER(AmpDiscTrainCfg), _vp, _vp, C.c_double, _vp, C.POINTER(_vp)]),
+    "amp_disc_trainer_destroy": (C.c_int, [_vp]),
+    "amp_disc_trainer_scaler": (C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_double), _vp]),
+    "amp_disc_train_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "amp_disc_style_reward_prescaled": (C.c_int, [_vp, _vp, _i64, _f32, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "amp_disc_style_reward": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
 }

@@ -228,6 +228,19 @@ static int disc_forward_split(const AmpDisc* h, const __bf16* Xp, int64_t rows, 
 }
 }  // namespace amp
 
+namespace amp {
+// accessors for disc_train.hip
+struct DiscParams {
+  int32_t in_dim, h1, h2, k1p;
+  float *w1p, *b1, *w2, *b2, *w3, *b3;
+};
+DiscParams disc_params(AmpDisc* h) { return DiscParams{h->in_dim, h->h1, h->h2, h->k1p, h->w1p, h->b1, h->w2, h->b2, h->w3, h->b3}; }
+int disc_refresh_derived(AmpDisc* h, hipStream_t st) {
+  // the fp32 weights changed in place: re-split the bf16 planes of the opt-in split-precision mode
+  return h->planes ? amp_disc_set_precision(h, h->planes, (amp_stream_t)st) : AMP_OK;
+}
+}  // namespace amp
+
 using namespace amp;
 
 extern "C" {
@@ -333,6 +346,20 @@ int amp_disc_set_precision(AmpDisc* h, int32_t bf16_planes, amp_stream_t stream)
   int rc = launch_status("disc_split_rows_kernel");
   if (rc != AMP_OK) return rc;
   h->planes = bf16_planes;
+  return AMP_OK;
+}
+
+int amp_disc_get_weights(const AmpDisc* h, float* w1, float* b1, float* w2, float* b2, float* w3, float* b3, amp_stream_t stream) {
+  AMP_REQUIRE(h && w1 && b1 && w2 && b2 && w3 && b3, "amp_disc_get_weights: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  // W1 is stored zero-padded to k1p columns: copy the logical [h1, in_dim] block
+  AMP_HIP(hipMemcpy2DAsync(w1, sizeof(float) * h->in_dim, h->w1p, sizeof(float) * h->k1p, sizeof(float) * h->in_dim, h->h1,
+                           hipMemcpyDeviceToDevice, st));
+  AMP_HIP(hipMemcpyAsync(b1, h->b1, sizeof(float) * h->h1, hipMemcpyDeviceToDevice, st));
+  AMP_HIP(hipMemcpyAsync(w2, h->w2, sizeof(float) * (size_t)h->h2 * h->h1, hipMemcpyDeviceToDevice, st));
+  AMP_HIP(hipMemcpyAsync(b2, h->b2, sizeof(float) * h->h2, hipMemcpyDeviceToDevice, st));
+  AMP_HIP(hipMemcpyAsync(w3, h->w3, sizeof(float) * h->h2, hipMemcpyDeviceToDevice, st));
+  AMP_HIP(hipMemcpyAsync(b3, h->b3, sizeof(float), hipMemcpyDeviceToDevice, st));
   return AMP_OK;
 }
 

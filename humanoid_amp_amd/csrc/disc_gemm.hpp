@@ -1,6 +1,7 @@
 // fp32-MFMA GEMM building block of the discriminator (included by disc.hip and tools/gemm_bench.hip).
 //   MODE 0: C = relu(A W^T + bias) stored [M, N]
 //   MODE 1: partial[m, nt] = sum over the tile's columns of relu(A W^T + bias)[m, n] * w3[n]
+//   MODE 2: C = (A W^T) [* (mask > 0)] [+ C]   plain product for the training step's backward GEMMs
 // A [M, lda] and W [N, Kp] are row-major fp32 with 16-B aligned rows, Kp % BK == 0.
 //
 // Tile: BM x BN x BK_, 4 waves as 2 x 2, each wave (BM/2) x (BN/2) = TM x TN accumulators of
@@ -22,7 +23,8 @@ struct GemmArgs {
   const float* A; int64_t lda; int64_t M; int32_t K;
   const float* W; int32_t Kp;
   const float* bias; int32_t N;
-  float* C; int64_t ldc;                               // mode 0 output
+  float* C; int64_t ldc;                               // mode 0 / 2 output
+  const float* mask; int64_t ldmask; int32_t accumulate; // mode 2: optional elementwise gate (mask > 0) and C += 
   const float* w3; float* partial; int32_t n_tiles;    // mode 1 output [M, n_tiles]
   int32_t m_tiles;
 };
@@ -153,29 +155,41 @@ __global__ __launch_bounds__(kBlock, MINW_) void disc_gemm_kernel(GemmArgs g) {
   __syncthreads();
 
   // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) --------
-  if (MODE == 0) {
-    // bias + ReLU, then transpose each wave's 32 x (TN*32) slab through its own LDS region (the staging tiles are
+  if (MODE == 0 || MODE == 2) {
+    // bias + ReLU (mode 0) / optional gate + accumulate (mode 2), then transpose each wave's 32 x (TN*32) slab through its own LDS region (the staging tiles are
     // dead) so that a lane stores 16 B and consecutive lanes cover contiguous bytes of one output row
     constexpr int W = TN * 32, EPL = W + 4, QPR = W / 4;  // row width, padded row, 16-B pieces per row
     float* ep = smem + wave * (32 * EPL);
     float bias[TN];
 #pragma unroll
-    for (int b = 0; b < TN; ++b) bias[b] = g.bias[n0 + wn * W + b * 32 + li];
+    for (int b = 0; b < TN; ++b) bias[b] = MODE == 0 ? g.bias[n0 + wn * W + b * 32 + li] : 0.0f;
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
 #pragma unroll
-        for (int b = 0; b < TN; ++b) ep[row * EPL + b * 32 + li] = fmaxf(acc[a][b][r] + bias[b], 0.0f);
+        for (int b = 0; b < TN; ++b)
+          ep[row * EPL + b * 32 + li] = MODE == 0 ? fmaxf(acc[a][b][r] + bias[b], 0.0f) : acc[a][b][r];
       }
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < (32 * QPR) / 64; ++i) {
         const int idx = lane + 64 * i, row = idx / QPR, q = idx % QPR;
-        const f4 v = *reinterpret_cast<const f4*>(&ep[row * EPL + 4 * q]);
+        f4 v = *reinterpret_cast<const f4*>(&ep[row * EPL + 4 * q]);
         const int64_t grow = m0 + wm * (TM * 32) + a * 32 + row;
-        if (grow < g.M) *reinterpret_cast<f4*>(&g.C[grow * g.ldc + n0 + wn * W + 4 * q]) = v;
+        if (grow < g.M) {
+          const int col = n0 + wn * W + 4 * q;
+          if (MODE == 2) {
+            if (g.mask) {
+              const f4 mk = *reinterpret_cast<const f4*>(&g.mask[grow * g.ldmask + col]);
+#pragma unroll
+              for (int c = 0; c < 4; ++c) v[c] = mk[c] > 0.0f ? v[c] : 0.0f;
+            }
+            if (g.accumulate) v += *reinterpret_cast<const f4*>(&g.C[grow * g.ldc + col]);
+          }
+          *reinterpret_cast<f4*>(&g.C[grow * g.ldc + col]) = v;
+        }
       }
       __syncthreads();
     }

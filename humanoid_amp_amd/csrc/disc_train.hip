@@ -1,0 +1,553 @@
+// Discriminator TRAINING step: the discriminator part of skrl's AMP._update, restated
+// [skrl is third-party and absent: parity unpinned; oracle = torch autograd, oracle/disc_train.py].
+//
+//   loss = loss_scale * ( 0.5 * [BCE(D(policy U replay), 0) + BCE(D(motion), 1)]
+//                         + logit_reg * |w3|^2 + grad_penalty * mean_rows |dD/dx (motion)|^2 + weight_decay * sum |W|^2 )
+//   followed by one Adam step on (W1, b1, W2, b2, w3, b3).
+//
+// Everything is fp32 on the fp32 MFMA GEMM of disc_gemm.hpp.  That kernel is "NT" (both operands K-contiguous), so
+// products that reduce over the batch dimension (dW = dY^T X) run on explicitly transposed copies; the batches are
+// small (3 x 4096 rows), the transposes are noise.  ReLU masks are read back from the stored activations (H > 0).
+// The gradient penalty's second-order term is analytic: with the masks m1, m2 fixed,
+//   a2 = m2 * w3,  a1 = m1 * (a2 W2),  g = a1 W1,  P = mean |g|^2,  dg = 2 g / B
+//   dW1 += a1^T dg,  e1 = m1 * (dg W1^T),  dW2 += a2^T e1,  dw3 += colsum(m2 * (e1 W2^T)).
+#include "disc_gemm.hpp"
+
+struct AmpDisc;  // defined in disc.hip; accessed through the accessors below
+extern "C" int amp_disc_input_layout(const AmpDisc* h, int32_t* padded_dim, const float** mean, const float** den, float* clip);
+
+namespace amp {
+// accessors implemented in disc.hip
+struct DiscParams {
+  int32_t in_dim, h1, h2, k1p;
+  float *w1p, *b1, *w2, *b2, *w3, *b3;
+};
+DiscParams disc_params(AmpDisc* h);
+int disc_refresh_derived(AmpDisc* h, hipStream_t st);  // after the weights changed (split planes, ...)
+
+static inline int64_t up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ---- small kernels ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void transpose_pad_kernel(const float* __restrict__ in, int64_t rows, int cols, int64_t ld_in,
+                                                               float* __restrict__ out, int64_t ld_out, int out_rows) {
+  // out[c][r] = in[r][c] for c < cols, r < rows; zero for c in [cols, out_rows) and r in [rows, ld_out)
+  __shared__ float tile[32][33];
+  const int64_t r0 = (int64_t)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int64_t r = r0 + i;
+    const int c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? in[r * ld_in + c] : 0.0f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i;
+    const int64_t r = r0 + tx;
+    if (c < out_rows && r < ld_out) out[(int64_t)c * ld_out + r] = tile[tx][i];
+  }
+}
+
+// out[n] (+)= sum_i A[i][n] * (rowscale ? rowscale[i] : 1) * (mask ? mask[i][n] > 0 : 1); one block per 64 columns
+__global__ __launch_bounds__(kBlock) void colsum_kernel(const float* __restrict__ A, int64_t rows, int cols, int64_t lda,
+                                                        const float* __restrict__ rowscale, const float* __restrict__ mask,
+                                                        int64_t ldmask, float* __restrict__ out, int accumulate) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), p = threadIdx.x >> 6;
+  float s = 0.0f;
+  if (c < cols)
+    for (int64_t i = p; i < rows; i += 4) {
+      float v = A[i * lda + c];
+      if (rowscale) v *= rowscale[i];
+      if (mask) v = mask[i * ldmask + c] > 0.0f ? v : 0.0f;
+      s += v;
+    }
+  part[p][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (p == 0 && c < cols) {
+    const float t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    out[c] = accumulate ? out[c] + t : t;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void rowdot_kernel(const float* __restrict__ A, int64_t rows, int cols, int64_t lda,
+                                                        const float* __restrict__ w, const float* __restrict__ b,
+                                                        float* __restrict__ out) {
+  // one wave per row: out[i] = A[i] . w + b
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float s = 0.0f;
+  for (int c = lane; c < cols; c += 64) s += A[row * lda + c] * w[c];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (lane == 0) out[row] = s + b[0];
+}
+
+// BCE-with-logits forward + backward for the two groups; one block, deterministic.
+// loss[0] = 0.5 * (mean softplus(l | fake rows) + mean softplus(-l | motion rows)); dlogit includes loss_scale.
+__global__ __launch_bounds__(1024) void bce_kernel(const float* __restrict__ logit, int64_t n_fake, int64_t n_real,
+                                                   float loss_scale, float* __restrict__ dlogit, float* __restrict__ loss) {
+  __shared__ float red[2][1024];
+  float lf = 0.0f, lr = 0.0f;
+  const int64_t n = n_fake + n_real;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const float x = logit[i];
+    const bool real = i >= n_fake;
+    const float y = real ? 1.0f : 0.0f;
+    // torch BCEWithLogits: (1 - y) x + max(-x, 0) + log(exp(-max(-x,0)) + exp(-x - max(-x,0)))
+    const float mx = fmaxf(-x, 0.0f);
+    const float l = (1.0f - y) * x + mx + logf(expf(-mx) + expf(-x - mx));
+    const float sg = 1.0f / (1.0f + expf(-x));
+    if (real) lr += l; else lf += l;
+    dlogit[i] = loss_scale * 0.5f * (sg - y) / (float)(real ? n_real : n_fake);
+  }
+  red[0][threadIdx.x] = lf;
+  red[1][threadIdx.x] = lr;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if (threadIdx.x < off) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + off];
+      red[1][threadIdx.x] += red[1][threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = 0.5f * (red[0][0] / (float)n_fake + red[1][0] / (float)n_real);
+}
+
+// dH2[i][n] = dlogit[i] * w3[n] * (H2[i][n] > 0)
+__global__ __launch_bounds__(kBlock) void dh2_kernel(const float* __restrict__ dlogit, const float* __restrict__ w3,
+                                                     const float* __restrict__ H2, int64_t rows, int cols,
+                                                     float* __restrict__ dH2) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= rows * cols) return;
+  const int64_t i = e / cols;
+  const int n = (int)(e - i * cols);
+  dH2[e] = H2[e] > 0.0f ? dlogit[i] * w3[n] : 0.0f;
+}
+
+// a2[i][n] = w3[n] * (H2m[i][n] > 0)
+__global__ __launch_bounds__(kBlock) void a2_kernel(const float* __restrict__ w3, const float* __restrict__ H2, int64_t rows, int cols,
+                                                    float* __restrict__ a2) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= rows * cols) return;
+  a2[e] = H2[e] > 0.0f ? w3[e % cols] : 0.0f;
+}
+
+// penalty value + dg = coef * g in place (one block, deterministic): loss[1] = gp_scale * mean_rows |g|^2
+__global__ __launch_bounds__(1024) void gp_kernel(float* __restrict__ g, int64_t rows, int cols, int64_t ld, float gp_scale,
+                                                  float loss_scale, float* __restrict__ loss) {
+  __shared__ float red[1024];
+  float s = 0.0f;
+  const float coef = 2.0f * gp_scale * loss_scale / (float)rows;
+  for (int64_t e = threadIdx.x; e < rows * cols; e += 1024) {
+    const int64_t i = e / cols;
+    const int c = (int)(e - i * cols);
+    const float v = g[i * ld + c];
+    s += v * v;
+    g[i * ld + c] = coef * v;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[1] = gp_scale * red[0] / (float)rows;
+}
+
+// sum of squares of a parameter tensor -> loss[slot] (+)= scale * sum; one block
+__global__ __launch_bounds__(1024) void sumsq_kernel(const float* __restrict__ p, int64_t rows, int cols, int64_t ld, float scale,
+                                                     float* __restrict__ loss, int slot, int accumulate) {
+  __shared__ float red[1024];
+  float s = 0.0f;
+  for (int64_t e = threadIdx.x; e < rows * cols; e += 1024) {
+    const float v = p[(e / cols) * ld + (e % cols)];
+    s += v * v;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[slot] = (accumulate ? loss[slot] : 0.0f) + scale * red[0];
+}
+
+// Adam on one tensor; the L2-type regularisers enter as grad += reg2 * p  (reg2 = 2 * loss_scale * coefficient)
+__global__ __launch_bounds__(kBlock) void adam_kernel(float* __restrict__ p, int64_t ld_p, const float* __restrict__ g, int64_t ld_g,
+                                                      float* __restrict__ m, float* __restrict__ v, int64_t rows, int cols,
+                                                      float reg2, float lr, float b1, float b2, float eps, float bc1, float bc2,
+                                                      float* __restrict__ grad_out) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= rows * cols) return;
+  const int64_t r = e / cols;
+  const int c = (int)(e - r * cols);
+  const float pv = p[r * ld_p + c];
+  const float gr = g[r * ld_g + c] + reg2 * pv;
+  if (grad_out) grad_out[e] = gr;
+  const float mi = b1 * m[e] + (1.0f - b1) * gr;
+  const float vi = b2 * v[e] + (1.0f - b2) * gr * gr;
+  m[e] = mi;
+  v[e] = vi;
+  p[r * ld_p + c] = pv - lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+}
+
+// RunningStandardScaler update (train=True): batch mean / unbiased variance per column in fp64, merged into the
+// running statistics (skrl _parallel_variance); one block per column.
+__global__ __launch_bounds__(kBlock) void scaler_update_kernel(const float* __restrict__ x, int64_t rows, int cols, int64_t ld,
+                                                               double* __restrict__ mean, double* __restrict__ var,
+                                                               double count) {
+  __shared__ double red[kBlock];
+  const int c = blockIdx.x;
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < rows; i += kBlock) s += (double)x[i * ld + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = kBlock / 2; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  const double bm = red[0] / (double)rows;
+  __syncthreads();
+  double q = 0.0;
+  for (int64_t i = threadIdx.x; i < rows; i += kBlock) {
+    const double d = (double)x[i * ld + c] - bm;
+    q += d * d;
+  }
+  red[threadIdx.x] = q;
+  __syncthreads();
+  for (int off = kBlock / 2; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double bv = red[0] / (double)(rows - 1);
+    const double n = (double)rows, total = count + n, delta = bm - mean[c];
+    const double m2 = var[c] * count + bv * n + delta * delta * count * n / total;
+    mean[c] = mean[c] + delta * n / total;
+    var[c] = m2 / total;
+  }
+}
+
+__global__ void scaler_to_f32_kernel(const double* __restrict__ mean64, const double* __restrict__ var64, int n, int np, float eps,
+                                     float* __restrict__ mean, float* __restrict__ den) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= np) return;
+  mean[i] = i < n ? (float)mean64[i] : 0.0f;
+  den[i] = i < n ? sqrtf((float)var64[i]) + eps : 1.0f;
+}
+
+__global__ __launch_bounds__(kBlock) void scale_rows_kernel(const float* __restrict__ x, int64_t row_stride, int64_t rows, int k,
+                                                            int kp, const float* __restrict__ mean, const float* __restrict__ den,
+                                                            float clip, float* __restrict__ xs) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= rows * kp) return;
+  const int64_t m = e / kp;
+  const int c = (int)(e - m * kp);
+  float v = 0.0f;
+  if (c < k) {
+    v = x[m * row_stride + c];
+    if (mean) {
+      v = (v - mean[c]) / den[c];
+      v = fminf(fmaxf(v, -clip), clip);
+    }
+  }
+  xs[e] = v;
+}
+
+}  // namespace amp
+
+using namespace amp;
+
+struct AmpDiscTrainer {
+  AmpDisc* disc;
+  AmpDiscTrainCfg cfg;
+  DiscParams p;
+  int64_t max_rows;   // capacity per group
+  int64_t step;
+  // persistent device state
+  float *w2t, *w1t;              // W2^T [h1, h2], W1^T [kN, h1] (kN = k1p rounded to 64)
+  float *mom[6], *vel[6];        // Adam moments for W1 (logical [h1, in_dim]), b1, W2, b2, w3, b3
+  double *mean64, *var64;        // running scaler statistics (owned here when update_scaler)
+  double count;
+  float* ws;                     // workspace
+  int64_t ws_floats;
+  int kN;
+};
+
+namespace {
+
+int gemm_nt(hipStream_t st, const float* A, int64_t lda, int64_t M, const float* W, int Kp, int N, float* C, int64_t ldc,
+            const float* mask, int64_t ldmask, int accumulate) {
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.M = M; g.K = Kp; g.W = W; g.Kp = Kp; g.N = N; g.C = C; g.ldc = ldc;
+  g.mask = mask; g.ldmask = ldmask; g.accumulate = accumulate;
+  g.n_tiles = N / 64; g.m_tiles = (int)((M + 63) / 64);
+  const unsigned grid = (unsigned)(((int64_t)g.m_tiles * g.n_tiles + 7) / 8 * 8);
+  amp::TraceScope trace__("disc_gemm_kernel<2>", st);
+  disc_gemm_kernel<64, 64, 16, 1, 2, 4><<<grid, kBlock, 0, st>>>(g);
+  return launch_status("disc_gemm_kernel<2>");
+}
+
+int gemm_fwd(hipStream_t st, const float* A, int64_t lda, int64_t M, const float* W, int Kp, int N, const float* bias, float* C) {
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.M = M; g.K = Kp; g.W = W; g.Kp = Kp; g.bias = bias; g.N = N; g.C = C; g.ldc = N;
+  g.n_tiles = N / 64; g.m_tiles = (int)((M + 63) / 64);
+  const unsigned grid = (unsigned)(((int64_t)g.m_tiles * g.n_tiles + 7) / 8 * 8);
+  amp::TraceScope trace__("disc_gemm_kernel<0>", st);
+  disc_gemm_kernel<64, 64, 16, 1, 0, 8><<<grid, kBlock, 0, st>>>(g);
+  return launch_status("disc_gemm_kernel<0>");
+}
+
+void transpose(hipStream_t st, const float* in, int64_t rows, int cols, int64_t ld_in, float* out, int64_t ld_out, int out_rows) {
+  dim3 grid((unsigned)((ld_out + 31) / 32), (unsigned)((out_rows + 31) / 32));
+  transpose_pad_kernel<<<grid, kBlock, 0, st>>>(in, rows, cols, ld_in, out, ld_out, out_rows);
+}
+
+unsigned blocks(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+}  // namespace
+
+extern "C" {
+
+int amp_disc_trainer_destroy(AmpDiscTrainer* t) {
+  if (!t) return AMP_OK;
+  (void)hipFree(t->w2t);
+  (void)hipFree(t->w1t);
+  for (int i = 0; i < 6; ++i) {
+    (void)hipFree(t->mom[i]);
+    (void)hipFree(t->vel[i]);
+  }
+  (void)hipFree(t->mean64);
+  (void)hipFree(t->var64);
+  (void)hipFree(t->ws);
+  delete t;
+  return AMP_OK;
+}
+
+int amp_disc_trainer_create(AmpDisc* disc, const AmpDiscTrainCfg* cfg, const double* running_mean_dev,
+                            const double* running_variance_dev, double current_count, amp_stream_t stream,
+                            AmpDiscTrainer** out) {
+  AMP_REQUIRE(disc && cfg && out, "amp_disc_trainer_create: null argument");
+  AMP_REQUIRE(cfg->max_rows_per_group >= 16, "amp_disc_trainer_create: max_rows_per_group must be >= 16");
+  AmpDiscTrainer* t = new (std::nothrow) AmpDiscTrainer();
+  AMP_REQUIRE(t, "amp_disc_trainer_create: out of host memory");
+  *t = AmpDiscTrainer{};
+  t->disc = disc;
+  t->cfg = *cfg;
+  t->p = disc_params(disc);
+  t->max_rows = up(cfg->max_rows_per_group, 16);
+  t->kN = (int)up(t->p.k1p, 64);
+  t->count = current_count;
+  const DiscParams& p = t->p;
+  const int64_t sizes[6] = {(int64_t)p.h1 * p.in_dim, p.h1, (int64_t)p.h2 * p.h1, p.h2, p.h2, 1};
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMalloc(&t->w2t, sizeof(float) * (size_t)p.h1 * p.h2);
+  if (e == hipSuccess) e = hipMalloc(&t->w1t, sizeof(float) * (size_t)t->kN * p.h1);
+  for (int i = 0; i < 6 && e == hipSuccess; ++i) {
+    e = hipMalloc(&t->mom[i], sizeof(float) * sizes[i]);
+    if (e == hipSuccess) e = hipMalloc(&t->vel[i], sizeof(float) * sizes[i]);
+    if (e == hipSuccess) e = hipMemsetAsync(t->mom[i], 0, sizeof(float) * sizes[i], st);
+    if (e == hipSuccess) e = hipMemsetAsync(t->vel[i], 0, sizeof(float) * sizes[i], st);
+  }
+  if (e == hipSuccess) e = hipMalloc(&t->mean64, sizeof(double) * p.in_dim);
+  if (e == hipSuccess) e = hipMalloc(&t->var64, sizeof(double) * p.in_dim);
+  if (e == hipSuccess && running_mean_dev)
+    e = hipMemcpyAsync(t->mean64, running_mean_dev, sizeof(double) * p.in_dim, hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess && running_variance_dev)
+    e = hipMemcpyAsync(t->var64, running_variance_dev, sizeof(double) * p.in_dim, hipMemcpyDeviceToDevice, st);
+  // workspace: see the carve-up in amp_disc_train_step
+  const int64_t B = t->max_rows, M = 3 * B, Mp = up(M, 16), Bp = up(B, 16);
+  const int64_t f = M * p.k1p + M * p.h1 + M * p.h2 + 2 * M + M * p.h2 + M * p.h1 +              // Xs H1 H2 logit dlogit dH2 dH1
+                    (int64_t)p.h2 * Mp + 2 * (int64_t)p.h1 * Mp + (int64_t)t->kN * Mp +            // dH2T H1T dH1T XsT
+                    B * p.h2 + B * p.h1 + B * t->kN + B * p.h1 + B * p.h2 +                        // a2 a1 g e1 da2
+                    (int64_t)p.h1 * Bp + (int64_t)t->kN * Bp + (int64_t)p.h2 * Bp + (int64_t)p.h1 * Bp +  // a1T dgT a2T e1T
+                    (int64_t)p.h1 * t->kN + p.h1 + (int64_t)p.h2 * p.h1 + p.h2 + p.h2 + 1 + 64;    // grads + loss
+  t->ws_floats = f + 16 * 32;
+  if (e == hipSuccess) e = hipMalloc(&t->ws, sizeof(float) * t->ws_floats);
+  if (e != hipSuccess) {
+    amp_disc_trainer_destroy(t);
+    return fail(AMP_ERR_HIP, "amp_disc_trainer_create: %s", hipGetErrorString(e));
+  }
+  if (!running_mean_dev) {
+    AMP_HIP(hipMemsetAsync(t->mean64, 0, sizeof(double) * p.in_dim, st));
+    // variance 1: fill through a tiny host copy
+    double* ones = new double[p.in_dim];
+    for (int i = 0; i < p.in_dim; ++i) ones[i] = 1.0;
+    hipError_t e2 = hipMemcpy(t->var64, ones, sizeof(double) * p.in_dim, hipMemcpyHostToDevice);
+    delete[] ones;
+    if (e2 != hipSuccess) {
+      amp_disc_trainer_destroy(t);
+      return fail(AMP_ERR_HIP, "amp_disc_trainer_create: %s", hipGetErrorString(e2));
+    }
+  }
+  *out = t;
+  return AMP_OK;
+}
+
+int amp_disc_trainer_scaler(const AmpDiscTrainer* t, double* mean_out, double* var_out, double* count, amp_stream_t stream) {
+  AMP_REQUIRE(t, "amp_disc_trainer_scaler: null handle");
+  hipStream_t st = (hipStream_t)stream;
+  if (mean_out) AMP_HIP(hipMemcpyAsync(mean_out, t->mean64, sizeof(double) * t->p.in_dim, hipMemcpyDeviceToDevice, st));
+  if (var_out) AMP_HIP(hipMemcpyAsync(var_out, t->var64, sizeof(double) * t->p.in_dim, hipMemcpyDeviceToDevice, st));
+  if (count) *count = t->count;
+  return AMP_OK;
+}
+
+int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* replay, const float* motion, int64_t rows,
+                        int64_t row_stride, float* loss_dev, float* grads_dev, amp_stream_t stream) {
+  AMP_REQUIRE(t && policy && replay && motion, "amp_disc_train_step: null argument");
+  AMP_REQUIRE(rows >= 2 && rows <= t->max_rows, "amp_disc_train_step: rows per group must be in [2, %lld]", (long long)t->max_rows);
+  const DiscParams p = t->p;
+  AMP_REQUIRE(row_stride >= p.in_dim, "amp_disc_train_step: row_stride too small");
+  hipStream_t st = (hipStream_t)stream;
+  const AmpDiscTrainCfg& c = t->cfg;
+  const int64_t B = rows, M = 3 * B, Mp = up(M, 16), Bp = up(B, 16);
+  const int kN = t->kN, k1p = p.k1p, H1n = p.h1, H2n = p.h2;
+  // ---- workspace carve-up (every region 16-float aligned) ------------------------------------------------------
+  float* w = t->ws;
+  auto take = [&](int64_t n) { float* r = w; w += up(n, 16); return r; };
+  float* Xs = take(M * k1p);
+  float* H1 = take(M * H1n);
+  float* H2 = take(M * H2n);
+  float* logit = take(M);
+  float* dlogit = take(M);
+  float* dH2 = take(M * H2n);
+  float* dH1 = take(M * H1n);
+  float* dH2T = take((int64_t)H2n * Mp);
+  float* H1T = take((int64_t)H1n * Mp);
+  float* dH1T = take((int64_t)H1n * Mp);
+  float* XsT = take((int64_t)kN * Mp);
+  float* a2 = take(B * H2n);
+  float* a1 = take(B * H1n);
+  float* g = take(B * kN);
+  float* e1 = take(B * H1n);
+  float* da2 = take(B * H2n);
+  float* a1T = take((int64_t)H1n * Bp);
+  float* dgT = take((int64_t)kN * Bp);
+  float* a2T = take((int64_t)H2n * Bp);
+  float* e1T = take((int64_t)H1n * Bp);
+  float* gW1 = take((int64_t)H1n * kN);
+  float* gb1 = take(H1n);
+  float* gW2 = take((int64_t)H2n * H1n);
+  float* gb2 = take(H2n);
+  float* gw3 = take(H2n);
+  float* gb3 = take(1);
+  float* loss = take(16);  // [0] prediction, [1] gradient penalty, [2] logit reg, [3] weight decay
+  AMP_REQUIRE(w - t->ws <= t->ws_floats, "amp_disc_train_step: internal workspace overflow");
+  int rc;
+
+  // ---- 1. scaler (train=True): update the running statistics with each batch, then scale it --------------------
+  const float* mean32 = nullptr;
+  const float* den32 = nullptr;
+  float clip = 0.0f;
+  const float* groups[3] = {policy, replay, motion};
+  for (int gi = 0; gi < 3; ++gi) {
+    if (c.update_scaler) {
+      scaler_update_kernel<<<p.in_dim, kBlock, 0, st>>>(groups[gi], B, p.in_dim, row_stride, t->mean64, t->var64, t->count);
+      t->count += (double)B;
+    }
+    if (c.use_scaler) {
+      // the fp32 vectors live in the discriminator handle: refresh them there so inference sees the same scaler
+      rc = amp_disc_set_scaler(t->disc, t->mean64, t->var64, c.scaler_epsilon, c.scaler_clip, stream);
+      if (rc != AMP_OK) return rc;
+      int32_t kp;
+      amp_disc_input_layout(t->disc, &kp, &mean32, &den32, &clip);
+    }
+    scale_rows_kernel<<<blocks(B * k1p), kBlock, 0, st>>>(groups[gi], row_stride, B, p.in_dim, k1p, mean32, den32, clip,
+                                                         Xs + gi * B * k1p);
+  }
+  rc = launch_status("scale_rows_kernel");
+  if (rc != AMP_OK) return rc;
+
+  // ---- 2. forward, keeping H1 / H2 -----------------------------------------------------------------------------
+  rc = gemm_fwd(st, Xs, k1p, M, p.w1p, k1p, H1n, p.b1, H1);
+  if (rc != AMP_OK) return rc;
+  rc = gemm_fwd(st, H1, H1n, M, p.w2, H1n, H2n, p.b2, H2);
+  if (rc != AMP_OK) return rc;
+  rowdot_kernel<<<(unsigned)((M + 3) / 4), kBlock, 0, st>>>(H2, M, H2n, H2n, p.w3, p.b3, logit);
+  bce_kernel<<<1, 1024, 0, st>>>(logit, 2 * B, B, c.loss_scale, dlogit, loss);
+
+  // ---- 3. backward of the prediction loss ----------------------------------------------------------------------
+  colsum_kernel<<<(H2n + 63) / 64, kBlock, 0, st>>>(H2, M, H2n, H2n, dlogit, nullptr, 0, gw3, 0);   // gw3 = H2^T dlogit
+  colsum_kernel<<<1, kBlock, 0, st>>>(dlogit, M, 1, 1, nullptr, nullptr, 0, gb3, 0);
+  dh2_kernel<<<blocks(M * H2n), kBlock, 0, st>>>(dlogit, p.w3, H2, M, H2n, dH2);
+  colsum_kernel<<<(H2n + 63) / 64, kBlock, 0, st>>>(dH2, M, H2n, H2n, nullptr, nullptr, 0, gb2, 0);
+  transpose(st, p.w2, H2n, H1n, H1n, t->w2t, H2n, H1n);               // W2^T [h1, h2]
+  transpose(st, p.w1p, H1n, k1p, k1p, t->w1t, H1n, kN);               // W1^T [kN, h1] (zero rows >= k1p)
+  rc = gemm_nt(st, dH2, H2n, M, t->w2t, H2n, H1n, dH1, H1n, H1, H1n, 0);   // dH1 = (dH2 W2) * (H1 > 0)
+  if (rc != AMP_OK) return rc;
+  colsum_kernel<<<(H1n + 63) / 64, kBlock, 0, st>>>(dH1, M, H1n, H1n, nullptr, nullptr, 0, gb1, 0);
+  transpose(st, dH2, M, H2n, H2n, dH2T, Mp, H2n);
+  transpose(st, H1, M, H1n, H1n, H1T, Mp, H1n);
+  rc = gemm_nt(st, dH2T, Mp, H2n, H1T, (int)Mp, H1n, gW2, H1n, nullptr, 0, 0);   // gW2 = dH2^T H1
+  if (rc != AMP_OK) return rc;
+  transpose(st, dH1, M, H1n, H1n, dH1T, Mp, H1n);
+  transpose(st, Xs, M, k1p, k1p, XsT, Mp, kN);
+  rc = gemm_nt(st, dH1T, Mp, H1n, XsT, (int)Mp, kN, gW1, kN, nullptr, 0, 0);     // gW1 = dH1^T Xs
+  if (rc != AMP_OK) return rc;
+
+  // ---- 4. gradient penalty on the motion rows ------------------------------------------------------------------
+  if (c.grad_penalty_scale != 0.0f) {
+    const float* H1m = H1 + 2 * B * H1n;
+    const float* H2m = H2 + 2 * B * H2n;
+    a2_kernel<<<blocks(B * H2n), kBlock, 0, st>>>(p.w3, H2m, B, H2n, a2);
+    rc = gemm_nt(st, a2, H2n, B, t->w2t, H2n, H1n, a1, H1n, H1m, H1n, 0);        // a1 = (a2 W2) * m1
+    if (rc != AMP_OK) return rc;
+    rc = gemm_nt(st, a1, H1n, B, t->w1t, H1n, kN, g, kN, nullptr, 0, 0);         // g = a1 W1      [B, kN]
+    if (rc != AMP_OK) return rc;
+    gp_kernel<<<1, 1024, 0, st>>>(g, B, p.in_dim, kN, c.grad_penalty_scale, c.loss_scale, loss);  // g <- dL/dg
+    transpose(st, a1, B, H1n, H1n, a1T, Bp, H1n);
+    transpose(st, g, B, kN, kN, dgT, Bp, kN);
+    rc = gemm_nt(st, a1T, Bp, H1n, dgT, (int)Bp, kN, gW1, kN, nullptr, 0, 1);    // gW1 += a1^T dg
+    if (rc != AMP_OK) return rc;
+    rc = gemm_nt(st, g, kN, B, p.w1p, k1p, H1n, e1, H1n, H1m, H1n, 0);           // e1 = (dg W1^T) * m1   (K = k1p <= kN)
+    if (rc != AMP_OK) return rc;
+    transpose(st, a2, B, H2n, H2n, a2T, Bp, H2n);
+    transpose(st, e1, B, H1n, H1n, e1T, Bp, H1n);
+    rc = gemm_nt(st, a2T, Bp, H2n, e1T, (int)Bp, H1n, gW2, H1n, nullptr, 0, 1);  // gW2 += a2^T e1
+    if (rc != AMP_OK) return rc;
+    rc = gemm_nt(st, e1, H1n, B, p.w2, H1n, H2n, da2, H2n, nullptr, 0, 0);       // da2 = e1 W2^T
+    if (rc != AMP_OK) return rc;
+    colsum_kernel<<<(H2n + 63) / 64, kBlock, 0, st>>>(da2, B, H2n, H2n, nullptr, H2m, H2n, gw3, 1);  // gw3 += colsum(m2 * da2)
+  } else {
+    AMP_HIP(hipMemsetAsync(loss + 1, 0, sizeof(float), st));
+  }
+
+  // ---- 5. regularisers (values for the report; their gradients are folded into the Adam kernel) ----------------
+  sumsq_kernel<<<1, 1024, 0, st>>>(p.w3, 1, H2n, H2n, c.logit_reg_scale, loss, 2, 0);
+  sumsq_kernel<<<1, 1024, 0, st>>>(p.w1p, H1n, p.in_dim, k1p, c.weight_decay_scale, loss, 3, 0);
+  sumsq_kernel<<<1, 1024, 0, st>>>(p.w2, H2n, H1n, H1n, c.weight_decay_scale, loss, 3, 1);
+  sumsq_kernel<<<1, 1024, 0, st>>>(p.w3, 1, H2n, H2n, c.weight_decay_scale, loss, 3, 1);
+  if (loss_dev) AMP_HIP(hipMemcpyAsync(loss_dev, loss, 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
+
+  // ---- 6. Adam -------------------------------------------------------------------------------------------------
+  t->step += 1;
+  const float bc1 = 1.0f - powf(c.beta1, (float)t->step), bc2 = 1.0f - powf(c.beta2, (float)t->step);
+  const float wd2 = 2.0f * c.loss_scale * c.weight_decay_scale, lr2 = 2.0f * c.loss_scale * c.logit_reg_scale;
+  float* go = grads_dev;  // optional export, in parameter order, logical shapes
+  const int64_t n1 = (int64_t)H1n * p.in_dim, n2 = (int64_t)H2n * H1n;
+  const float lr = c.apply_update ? c.learning_rate : 0.0f;
+  adam_kernel<<<blocks(n1), kBlock, 0, st>>>(p.w1p, k1p, gW1, kN, t->mom[0], t->vel[0], H1n, p.in_dim, wd2, lr, c.beta1, c.beta2,
+                                            c.adam_epsilon, bc1, bc2, go);
+  if (go) go += n1;
+  adam_kernel<<<blocks(H1n), kBlock, 0, st>>>(p.b1, H1n, gb1, H1n, t->mom[1], t->vel[1], 1, H1n, 0.0f, lr, c.beta1, c.beta2,
+                                             c.adam_epsilon, bc1, bc2, go);
+  if (go) go += H1n;
+  adam_kernel<<<blocks(n2), kBlock, 0, st>>>(p.w2, H1n, gW2, H1n, t->mom[2], t->vel[2], H2n, H1n, wd2, lr, c.beta1, c.beta2,
+                                            c.adam_epsilon, bc1, bc2, go);
+  if (go) go += n2;
+  adam_kernel<<<blocks(H2n), kBlock, 0, st>>>(p.b2, H2n, gb2, H2n, t->mom[3], t->vel[3], 1, H2n, 0.0f, lr, c.beta1, c.beta2,
+                                             c.adam_epsilon, bc1, bc2, go);
+  if (go) go += H2n;
+  adam_kernel<<<blocks(H2n), kBlock, 0, st>>>(p.w3, H2n, gw3, H2n, t->mom[4], t->vel[4], 1, H2n, wd2 + lr2, lr, c.beta1, c.beta2,
+                                             c.adam_epsilon, bc1, bc2, go);
+  if (go) go += H2n;
+  adam_kernel<<<1, kBlock, 0, st>>>(p.b3, 1, gb3, 1, t->mom[5], t->vel[5], 1, 1, 0.0f, lr, c.beta1, c.beta2, c.adam_epsilon, bc1, bc2,
+                                   go);
+  rc = launch_status("adam_kernel");
+  if (rc != AMP_OK) return rc;
+  return c.apply_update ? disc_refresh_derived(t->disc, st) : AMP_OK;
+}
+
+}  // extern "C"

@@ -264,7 +264,7 @@ class AmpDiscriminator:
             nat.check(self._lib.amp_disc_create(C.byref(d), nat.stream_ptr(), C.byref(h)), "amp_disc_create")
         self._destroy()
         self._handle = h
-        self.in_dim = d.in_dim
+        self.in_dim, self._h1, self._h2 = d.in_dim, d.h1, d.h2
         if self._planes:
             with torch.cuda.device(self.device):
                 nat.check(self._lib.amp_disc_set_precision(h, self._planes, nat.stream_ptr()), "amp_disc_set_precision")
@@ -374,3 +374,92 @@ class AmpDiscriminator:
             self._destroy()
         except Exception:
             pass
+
+
+class AmpDiscriminatorTrainer:
+    """Discriminator training step of skrl's AMP agent on the engine: BCE on
+    (policy U replay) vs motion batches + logit regularisation + gradient penalty + weight decay, Adam.  Updates the
+    attached :class:`AmpDiscriminator` in place (weights and, with ``use_scaler``, its running scaler).
+    Hyper-parameter names / defaults: agents/skrl_g1_walk_amp_cfg.yaml:70,87-95."""
+
+    LOSS_TERMS = ("prediction", "grad_penalty", "logit_reg", "weight_decay")
+
+    def __init__(self, disc: AmpDiscriminator, *, batch_size: int = 4096, learning_rate: float = 5e-5,
+                 discriminator_loss_scale: float = 5.0, discriminator_logit_regularization_scale: float = 0.05,
+                 discriminator_gradient_penalty_scale: float = 5.0, discriminator_weight_decay_scale: float = 1e-4,
+                 betas=(0.9, 0.999), adam_epsilon: float = 1e-8, use_scaler: bool = True, update_scaler: bool = True,
+                 running_mean: Optional[torch.Tensor] = None, running_variance: Optional[torch.Tensor] = None,
+                 current_count: float = 1.0, apply_update: bool = True):
+        self.disc, self.device, self._lib = disc, disc.device, nat.load()
+        self.batch_size = int(batch_size)
+        c = nat.AmpDiscTrainCfg()
+        c.max_rows_per_group = self.batch_size
+        c.learning_rate, c.beta1, c.beta2, c.adam_epsilon = learning_rate, betas[0], betas[1], adam_epsilon
+        c.loss_scale, c.logit_reg_scale = discriminator_loss_scale, discriminator_logit_regularization_scale
+        c.grad_penalty_scale, c.weight_decay_scale = discriminator_gradient_penalty_scale, discriminator_weight_decay_scale
+        c.scaler_epsilon, c.scaler_clip = disc.epsilon, disc.clip_threshold
+        c.use_scaler, c.update_scaler, c.apply_update = int(use_scaler), int(update_scaler), int(apply_update)
+        self.loss_scale = float(discriminator_loss_scale)
+        m = None if running_mean is None else running_mean.detach().to(device=self.device, dtype=torch.float64).contiguous()
+        v = None if running_variance is None else running_variance.detach().to(device=self.device, dtype=torch.float64).contiguous()
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.amp_disc_trainer_create(disc._handle, C.byref(c), nat.dptr(m), nat.dptr(v), float(current_count),
+                                                        nat.stream_ptr(), C.byref(h)), "amp_disc_trainer_create")
+            torch.cuda.current_stream().synchronize()
+        self._handle = h
+        self._n_params = sum(int(w.numel() + b.numel()) for w, b in self.weights())
+
+    def weights(self):
+        """Current [(W1, b1), (W2, b2), (W3, b3)] of the attached discriminator (device copies, Linear layout)."""
+        d = self.disc
+        f32 = dict(dtype=torch.float32, device=self.device)
+        w1 = torch.empty((d._h1, d.in_dim), **f32); b1 = torch.empty(d._h1, **f32)
+        w2 = torch.empty((d._h2, d._h1), **f32); b2 = torch.empty(d._h2, **f32)
+        w3 = torch.empty((1, d._h2), **f32); b3 = torch.empty(1, **f32)
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.amp_disc_get_weights(d._handle, *[nat.dptr(t) for t in (w1, b1, w2, b2, w3, b3)], nat.stream_ptr()),
+                      "amp_disc_get_weights")
+        return [(w1, b1), (w2, b2), (w3, b3)]
+
+    def step(self, policy_states: torch.Tensor, replay_states: torch.Tensor, motion_states: torch.Tensor, *,
+             want_grads: bool = False):
+        """One update on three [B, K*D] batches of raw AMP observations.  Returns {"loss": total, terms..., "grads"?}
+        as device tensors (no host sync)."""
+        B = policy_states.shape[0]
+        for name, t in (("policy", policy_states), ("replay", replay_states), ("motion", motion_states)):
+            if t.dim() != 2 or t.shape != (B, self.disc.in_dim) or t.dtype != torch.float32 or t.stride(1) != 1 \
+                    or t.stride(0) != policy_states.stride(0):
+                raise nat.AmpEngineError(f"{name}_states must be float32 [B, {self.disc.in_dim}] with the same row stride")
+            nat.require_gpu(t.device)
+        loss = torch.empty(4, dtype=torch.float32, device=self.device)
+        grads = torch.empty(self._n_params, dtype=torch.float32, device=self.device) if want_grads else None
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.amp_disc_train_step(self._handle, C.c_void_p(policy_states.data_ptr()),
+                                                    C.c_void_p(replay_states.data_ptr()), C.c_void_p(motion_states.data_ptr()), B,
+                                                    int(policy_states.stride(0)), nat.dptr(loss), nat.dptr(grads), nat.stream_ptr()),
+                      "amp_disc_train_step")
+        out = dict(zip(self.LOSS_TERMS, loss.unbind(0)))
+        out["loss"] = self.loss_scale * loss.sum()
+        if want_grads:
+            out["grads"] = grads
+        return out
+
+    def scaler_state(self):
+        """(running_mean, running_variance, current_count): fp64 device copies of the trainer's statistics."""
+        n = self.disc.in_dim
+        mean = torch.empty(n, dtype=torch.float64, device=self.device)
+        var = torch.empty(n, dtype=torch.float64, device=self.device)
+        cnt = C.c_double()
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.amp_disc_trainer_scaler(self._handle, nat.dptr(mean), nat.dptr(var), C.byref(cnt), nat.stream_ptr()),
+                      "amp_disc_trainer_scaler")
+        return mean, var, float(cnt.value)
+
+    def __del__(self):
+        h, self._handle = getattr(self, "_handle", None), None
+        if h is not None:
+            try:
+                self._lib.amp_disc_trainer_destroy(h)
+            except Exception:
+                pass

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define AMP_ABI_VERSION 3
+#define AMP_ABI_VERSION 4
 
 typedef void* amp_stream_t; /* hipStream_t */
 typedef void* amp_event_t;  /* hipEvent_t  */
@@ -285,6 +285,47 @@ int amp_disc_style_reward_prescaled(const AmpDisc* h, const float* scaled_dev, i
                                     const float* task_reward_dev, float task_weight, float style_weight,
                                     float* logits_dev, float* style_dev, float* combined_dev, void* workspace_dev,
                                     amp_stream_t stream);
+
+/* Current weights in torch.nn.Linear layout (W1 [h1, in_dim], ... , W3 [1, h2]) into caller-owned device buffers. */
+int amp_disc_get_weights(const AmpDisc* h, float* w1_dev, float* b1_dev, float* w2_dev, float* b2_dev, float* w3_dev,
+                         float* b3_dev, amp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Discriminator TRAINING step (skrl AMP._update, discriminator part -- third-party,
+ * parity unpinned; hyper-parameters agents/skrl_g1_walk_amp_cfg.yaml:70,87-95):
+ *   scaler update (train=True) per batch -> BCE(policy U replay -> 0, motion -> 1) + logit regularisation +
+ *   gradient penalty w.r.t. the scaled motion states + weight decay, x loss scale -> Adam on the handle's weights.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct AmpDiscTrainer AmpDiscTrainer;
+typedef struct {
+  int64_t max_rows_per_group;   /* capacity: rows of each of the three batches (discriminator_batch_size 4096) */
+  float learning_rate;          /* 5e-5 */
+  float beta1, beta2, adam_epsilon; /* torch.optim.Adam defaults 0.9, 0.999, 1e-8 */
+  float loss_scale;             /* discriminator_loss_scale 5.0 */
+  float logit_reg_scale;        /* discriminator_logit_regularization_scale 0.05 */
+  float grad_penalty_scale;     /* discriminator_gradient_penalty_scale 5.0 */
+  float weight_decay_scale;     /* discriminator_weight_decay_scale 1e-4 */
+  float scaler_epsilon, scaler_clip; /* RunningStandardScaler 1e-8, 5.0 */
+  int32_t use_scaler;           /* 0: feed raw observations */
+  int32_t update_scaler;        /* 1: train=True statistics update with every batch (fp64) */
+  int32_t apply_update;         /* 0: compute loss / gradients only (Adam moments still advance with lr = 0) */
+  int32_t reserved;
+} AmpDiscTrainCfg;
+
+/* The trainer updates `disc`'s weights (and, with use_scaler, its scaler) in place; `disc` must outlive it.
+ * running_mean / running_variance (device fp64 [in_dim], may be NULL = 0 / 1) and current_count seed the statistics. */
+int amp_disc_trainer_create(AmpDisc* disc, const AmpDiscTrainCfg* cfg, const double* running_mean_dev,
+                            const double* running_variance_dev, double current_count, amp_stream_t stream,
+                            AmpDiscTrainer** out);
+int amp_disc_trainer_destroy(AmpDiscTrainer* t);
+/* Copies the running statistics (fp64 [in_dim]) into caller-owned device buffers; *count (host) = samples seen. */
+int amp_disc_trainer_scaler(const AmpDiscTrainer* t, double* mean_out_dev, double* var_out_dev, double* count,
+                            amp_stream_t stream);
+/* One step on three batches of `rows` raw AMP observations each ([rows, in_dim], row stride in elements).
+ * loss_dev (may be NULL): [4] = prediction, gradient penalty, logit regularisation, weight decay (unscaled terms;
+ * total = loss_scale * sum).  grads_dev (may be NULL): dL/d(W1, b1, W2, b2, W3, b3) concatenated, logical shapes. */
+int amp_disc_train_step(AmpDiscTrainer* t, const float* policy_dev, const float* replay_dev, const float* motion_dev,
+                        int64_t rows, int64_t row_stride, float* loss_dev, float* grads_dev, amp_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,102 @@
+"""GPU: the discriminator training step vs the torch-autograd oracle.  PARITY UNPINNED (skrl absent): the oracle
+restates skrl's AMP._update discriminator part (oracle/disc_train.py).
+
+Bars: loss terms <= 1e-5 relative; every gradient <= 2e-5 * max|grad| of its tensor (fp32 GEMM reductions over
+12 288 rows are ordered differently); Adam-updated weights <= 1e-6 absolute after one step; scaler statistics
+<= 1e-9 relative (fp64)."""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import disc as odisc
+from oracle import disc_train as odt
+
+pytestmark = pytest.mark.gpu
+
+
+def _batches(in_dim, B, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(B, in_dim, generator=g) * s + o for s, o in ((1.0, 0.0), (1.2, 0.1), (0.8, -0.2))]
+
+
+def _split(flat, weights):
+    out, i = [], 0
+    for w, b in weights:
+        for t in (w, b):
+            out.append(flat[i:i + t.numel()].view_as(t))
+            i += t.numel()
+    return out
+
+
+@pytest.mark.parametrize("in_dim,B", [(166, 512), (830, 256), (162, 1000)])
+def test_gradients_and_loss_no_scaler(in_dim, B):
+    from humanoid_amp_amd.engine import AmpDiscriminator, AmpDiscriminatorTrainer
+
+    w = odisc.make_weights(in_dim, seed=in_dim)
+    p, r, m = _batches(in_dim, B, seed=B)
+    disc = AmpDiscriminator([(a.cuda(), b.cuda()) for a, b in w], "cuda:0")
+    tr = AmpDiscriminatorTrainer(disc, batch_size=B, use_scaler=False, update_scaler=False, apply_update=False)
+    out = tr.step(p.cuda(), r.cuda(), m.cuda(), want_grads=True)
+    L, G = odt.loss_and_grads(w, p, r, m, None, None)
+    L64, G64 = odt.loss_and_grads(w, p, r, m, None, None, dtype=torch.float64)
+    for name, key in (("prediction", "prediction"), ("grad_penalty", "grad_penalty"), ("logit_reg", "logit_reg"),
+                      ("weight_decay", "weight_decay")):
+        assert abs(float(out[name]) - float(L64[key])) <= 1e-5 * max(1.0, abs(float(L64[key]))), name
+    assert abs(float(out["loss"]) - float(L64["total"])) <= 2e-5 * abs(float(L64["total"]))
+    got = _split(out["grads"].cpu(), w)
+    for i, (g_gpu, g_ref, g_64) in enumerate(zip(got, G, G64)):
+        scale = float(g_64.abs().max())
+        err_gpu = float((g_gpu.double() - g_64).abs().max())
+        err_cpu = float((g_ref.double() - g_64).abs().max())
+        assert err_gpu <= err_cpu + 2e-5 * scale, (i, err_gpu, err_cpu, scale)
+    # apply_update=False: the weights did not move
+    for (a, b), (c, d) in zip(tr.weights(), w):
+        assert torch.equal(a.cpu(), c) and torch.equal(b.cpu(), d)
+
+
+def test_full_step_with_scaler_and_adam():
+    from humanoid_amp_amd.engine import AmpDiscriminator, AmpDiscriminatorTrainer
+
+    in_dim, B = 166, 768
+    w = odisc.make_weights(in_dim, seed=1)
+    g = torch.Generator().manual_seed(5)
+    mean0 = torch.randn(in_dim, generator=g, dtype=torch.float64) * 0.1
+    var0 = torch.rand(in_dim, generator=g, dtype=torch.float64) + 0.5
+    count0 = 1000.0
+    disc = AmpDiscriminator([(a.cuda(), b.cuda()) for a, b in w], "cuda:0", running_mean=mean0, running_variance=var0)
+    tr = AmpDiscriminatorTrainer(disc, batch_size=B, running_mean=mean0, running_variance=var0, current_count=count0,
+                                 learning_rate=1e-3)
+    # oracle state
+    params = [t.clone() for wb in w for t in wb]
+    mo = [torch.zeros_like(t) for t in params]
+    ve = [torch.zeros_like(t) for t in params]
+    mean, var, count = mean0.clone(), var0.clone(), count0
+    for step in range(1, 4):
+        p, r, m = _batches(in_dim, B, seed=100 + step)
+        out = tr.step(p.cuda(), r.cuda(), m.cuda(), want_grads=True)
+        # skrl order: each batch updates the running statistics, then is scaled with them
+        scaled = []
+        for x in (p, r, m):
+            mean, var, count = odt.scaler_update(mean, var, count, x)
+            scaled.append(odisc.scale_states(x, mean, var))
+        cur = [(params[0], params[1]), (params[2], params[3]), (params[4], params[5])]
+        L, G = odt.loss_and_grads(cur, *scaled, None, None)
+        assert abs(float(out["loss"]) - float(L["total"])) <= 5e-5 * abs(float(L["total"])), step
+        g_gpu = _split(out["grads"].cpu(), w)
+        for a, b in zip(g_gpu, G):
+            assert float((a - b).abs().max()) <= 3e-5 * float(b.abs().max())
+        # Adam's m / (sqrt(v) + eps) is sign-like for near-zero gradients, so feeding each side its own (1e-5-close)
+        # gradients would compare noise; the Adam arithmetic is checked on the engine's gradients instead
+        params, mo, ve = odt.adam_step(params, g_gpu, mo, ve, step, lr=1e-3)
+    gm, gv, gc = tr.scaler_state()
+    assert gc == count
+    assert float(((gm.cpu() - mean) / (mean.abs() + 1e-6)).abs().max()) <= 1e-9
+    assert float(((gv.cpu() - var) / var).abs().max()) <= 1e-9
+    for (a, b), (c, d) in zip(tr.weights(), [(params[0], params[1]), (params[2], params[3]), (params[4], params[5])]):
+        assert float((a.cpu() - c).abs().max()) <= 1e-6 and float((b.cpu() - d).abs().max()) <= 1e-6
+    # the discriminator handle serves inference with the trained weights and the updated scaler
+    x = _batches(in_dim, 300, seed=9)[0]
+    ref = odisc.forward([(params[0], params[1]), (params[2], params[3]), (params[4], params[5])], x, mean, var)
+    got = disc.style_reward(x.cuda(), want_logits=True)
+    assert float((got["logits"].cpu() - ref["logits"]).abs().max()) <= 5e-5
