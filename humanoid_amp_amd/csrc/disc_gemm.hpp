@@ -24,18 +24,22 @@ struct GemmArgs {
   const float* W; int32_t Kp;
   const float* bias; int32_t N;
   float* C; int64_t ldc;                               // mode 0 / 2 output
-  const float* mask; int64_t ldmask; int32_t accumulate; // mode 2: optional elementwise gate (mask > 0) and C += 
+  const float* mask; int64_t ldmask; int32_t accumulate; // mode 2: optional elementwise gate (mask > 0) and C +=
+  int32_t k_slices; int64_t slice_stride;              // mode 2: split-K, slice s writes its partial product to C + s * slice_stride
   const float* w3; float* partial; int32_t n_tiles;    // mode 1 output [M, n_tiles]
   int32_t m_tiles;
 };
 
 // XCD-aware renumbering: hardware deals workgroups round-robin over the 8 XCDs; give each XCD a contiguous
 // run of (row tile, column tile) pairs with the column tile fastest (speed only, never correctness).
-__device__ __forceinline__ bool tile_of_block(const GemmArgs& g, int& mt, int& nt) {
-  const int total = g.m_tiles * g.n_tiles;
+__device__ __forceinline__ bool tile_of_block(const GemmArgs& g, int& mt, int& nt, int* slice = nullptr) {
+  const int tiles = g.m_tiles * g.n_tiles;
+  const int total = tiles * (g.k_slices > 1 ? g.k_slices : 1);
   const int per_xcd = (total + 7) / 8;
-  const int v = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  int v = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (v >= total) return false;
+  if (slice) *slice = v / tiles;
+  v %= tiles;
   mt = v / g.n_tiles;
   nt = v - mt * g.n_tiles;
   return true;
@@ -106,14 +110,19 @@ __global__ __launch_bounds__(kBlock, MINW_) void disc_gemm_kernel(GemmArgs g) {
   constexpr int EP_F = 4 * 32 * (TN * 32 + 4);  // epilogue transpose region (mode 0)
   constexpr int SMEM_F = STAGES_ * STAGE_F > EP_F ? STAGES_ * STAGE_F : EP_F;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_F];
-  int mt, nt;
-  if (!tile_of_block(g, mt, nt)) return;
+  int mt, nt, slice = 0;
+  if (!tile_of_block(g, mt, nt, &slice)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
   const int64_t m0 = (int64_t)mt * BM_;
   const int n0 = nt * BN_;
-  const int nk = g.Kp / BK_;
+  // k-tile range of this workgroup (split-K: slice s owns a contiguous run of k-tiles)
+  const int nk_all = g.Kp / BK_;
+  const int per_slice = (MODE == 2 && g.k_slices > 1) ? (nk_all + g.k_slices - 1) / g.k_slices : nk_all;
+  const int k0 = slice * per_slice;
+  const int nk = k0 + per_slice < nk_all ? k0 + per_slice : nk_all;  // one past the last k-tile
+  if (MODE == 2 && g.k_slices > 1) g.C += (int64_t)slice * g.slice_stride;
 
   floatx16 acc[TM][TN];
 #pragma unroll
@@ -125,14 +134,16 @@ __global__ __launch_bounds__(kBlock, MINW_) void disc_gemm_kernel(GemmArgs g) {
 
   const int arow = wm * (TM * 32) + li, brow = wn * (TN * 32) + li;
   Stage<BM_, BN_, BK_> stg;
-  stg.load(g, m0, n0, 0, tid);
-  stg.store(smem, smem + BM_ * LDT, tid);
+  if (k0 < nk) {
+    stg.load(g, m0, n0, k0, tid);
+    stg.store(smem, smem + BM_ * LDT, tid);
+  }
   if (STAGES_ == 2) {
-    if (nk > 1) stg.load(g, m0, n0, 1, tid);
+    if (k0 + 1 < nk) stg.load(g, m0, n0, k0 + 1, tid);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-      float* cur = smem + (kt & 1) * STAGE_F;
-      float* nxt = smem + ((kt + 1) & 1) * STAGE_F;
+    for (int kt = k0; kt < nk; ++kt) {
+      float* cur = smem + ((kt - k0) & 1) * STAGE_F;
+      float* nxt = smem + ((kt - k0 + 1) & 1) * STAGE_F;
       if (kt + 1 < nk) stg.store(nxt, nxt + BM_ * LDT, tid);   // k-tile kt+1 (in registers since kt-1)
       if (kt + 2 < nk) stg.load(g, m0, n0, kt + 2, tid);        // in flight under this tile's MFMAs
       __builtin_amdgcn_sched_barrier(0);
@@ -141,7 +152,7 @@ __global__ __launch_bounds__(kBlock, MINW_) void disc_gemm_kernel(GemmArgs g) {
     }
   } else {
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = k0; kt < nk; ++kt) {
       if (kt + 1 < nk) stg.load(g, m0, n0, kt + 1, tid);        // in flight under this tile's MFMAs
       __builtin_amdgcn_sched_barrier(0);
       compute_tile<TM, TN, BK_, MODE == 1>(smem, smem + BM_ * LDT, arow, brow, lh, acc);

@@ -48,26 +48,62 @@ __global__ __launch_bounds__(kBlock) void transpose_pad_kernel(const float* __re
   }
 }
 
-// out[n] (+)= sum_i A[i][n] * (rowscale ? rowscale[i] : 1) * (mask ? mask[i][n] > 0 : 1); one block per 64 columns
-__global__ __launch_bounds__(kBlock) void colsum_kernel(const float* __restrict__ A, int64_t rows, int cols, int64_t lda,
-                                                        const float* __restrict__ rowscale, const float* __restrict__ mask,
-                                                        int64_t ldmask, float* __restrict__ out, int accumulate) {
-  __shared__ float part[4][64];
+// Column sums in two deterministic stages.  Stage 1: grid (ceil(cols/64), kChunks); block (x, ch) sums its row chunk of
+// 64 columns -> part[ch][c].  Stage 2: out[c] (+)= sum over ch in order.
+// value(i, c) = A[i][c] * (rowscale ? rowscale[i] : 1) * (mask ? mask[i][c] > 0 : 1)
+constexpr int kChunks = 64;
+__global__ __launch_bounds__(kBlock) void colsum_part_kernel(const float* __restrict__ A, int64_t rows, int cols, int64_t lda,
+                                                             const float* __restrict__ rowscale, const float* __restrict__ mask,
+                                                             int64_t ldmask, float* __restrict__ part) {
+  __shared__ float red[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), p = threadIdx.x >> 6;
+  const int64_t per = (rows + kChunks - 1) / kChunks;
+  const int64_t lo = (int64_t)blockIdx.y * per, hi = lo + per < rows ? lo + per : rows;
   float s = 0.0f;
   if (c < cols)
-    for (int64_t i = p; i < rows; i += 4) {
+    for (int64_t i = lo + p; i < hi; i += 4) {
       float v = A[i * lda + c];
       if (rowscale) v *= rowscale[i];
       if (mask) v = mask[i * ldmask + c] > 0.0f ? v : 0.0f;
       s += v;
     }
-  part[p][threadIdx.x & 63] = s;
+  red[p][threadIdx.x & 63] = s;
   __syncthreads();
-  if (p == 0 && c < cols) {
-    const float t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
-    out[c] = accumulate ? out[c] + t : t;
+  if (p == 0 && c < cols)
+    part[(int64_t)blockIdx.y * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(kBlock) void colsum_final_kernel(const float* __restrict__ part, int cols, float* __restrict__ out,
+                                                              int accumulate) {
+  const int c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.0f;
+  for (int ch = 0; ch < kChunks; ++ch) s += part[(int64_t)ch * cols + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+// out[e] (+)= sum over the split-K slices, in slice order (deterministic)
+__global__ __launch_bounds__(kBlock) void sum_slices_kernel(const float* __restrict__ part, int slices, int64_t n, int64_t stride,
+                                                            float* __restrict__ out, int accumulate) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= n) return;
+  float s = accumulate ? out[e] : 0.0f;
+  for (int k = 0; k < slices; ++k) s += part[(int64_t)k * stride + e];
+  out[e] = s;
+}
+
+// deterministic scalar reduction tail: out[slot] (+)= scale * sum(part[0..n))
+__global__ void scalar_final_kernel(const float* __restrict__ part, int n, float scale, float* __restrict__ out, int slot,
+                                    int accumulate) {
+  __shared__ float red[256];
+  float s = 0.0f;
+  for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
   }
+  if (threadIdx.x == 0) out[slot] = (accumulate ? out[slot] : 0.0f) + scale * red[0];
 }
 
 __global__ __launch_bounds__(kBlock) void rowdot_kernel(const float* __restrict__ A, int64_t rows, int cols, int64_t lda,
@@ -133,44 +169,26 @@ __global__ __launch_bounds__(kBlock) void a2_kernel(const float* __restrict__ w3
   a2[e] = H2[e] > 0.0f ? w3[e % cols] : 0.0f;
 }
 
-// penalty value + dg = coef * g in place (one block, deterministic): loss[1] = gp_scale * mean_rows |g|^2
-__global__ __launch_bounds__(1024) void gp_kernel(float* __restrict__ g, int64_t rows, int cols, int64_t ld, float gp_scale,
-                                                  float loss_scale, float* __restrict__ loss) {
-  __shared__ float red[1024];
+// sum of squares of an [rows, cols] view (optionally scaling it in place by coef afterwards) -> per-block partials
+__global__ __launch_bounds__(kBlock) void sumsq_part_kernel(float* __restrict__ x, int64_t rows, int cols, int64_t ld, float coef,
+                                                            int scale_in_place, float* __restrict__ part) {
+  __shared__ float red[kBlock];
   float s = 0.0f;
-  const float coef = 2.0f * gp_scale * loss_scale / (float)rows;
-  for (int64_t e = threadIdx.x; e < rows * cols; e += 1024) {
+  const int64_t n = rows * cols;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (int64_t)gridDim.x * kBlock) {
     const int64_t i = e / cols;
     const int c = (int)(e - i * cols);
-    const float v = g[i * ld + c];
+    const float v = x[i * ld + c];
     s += v * v;
-    g[i * ld + c] = coef * v;
+    if (scale_in_place) x[i * ld + c] = coef * v;
   }
   red[threadIdx.x] = s;
   __syncthreads();
-  for (int off = 512; off > 0; off >>= 1) {
+  for (int off = kBlock / 2; off > 0; off >>= 1) {
     if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
     __syncthreads();
   }
-  if (threadIdx.x == 0) loss[1] = gp_scale * red[0] / (float)rows;
-}
-
-// sum of squares of a parameter tensor -> loss[slot] (+)= scale * sum; one block
-__global__ __launch_bounds__(1024) void sumsq_kernel(const float* __restrict__ p, int64_t rows, int cols, int64_t ld, float scale,
-                                                     float* __restrict__ loss, int slot, int accumulate) {
-  __shared__ float red[1024];
-  float s = 0.0f;
-  for (int64_t e = threadIdx.x; e < rows * cols; e += 1024) {
-    const float v = p[(e / cols) * ld + (e % cols)];
-    s += v * v;
-  }
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int off = 512; off > 0; off >>= 1) {
-    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) loss[slot] = (accumulate ? loss[slot] : 0.0f) + scale * red[0];
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
 }
 
 // Adam on one tensor; the L2-type regularisers enter as grad += reg2 * p  (reg2 = 2 * loss_scale * coefficient)
@@ -192,41 +210,46 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(float* __restrict__ p, int
   p[r * ld_p + c] = pv - lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
 }
 
-// RunningStandardScaler update (train=True): batch mean / unbiased variance per column in fp64, merged into the
-// running statistics (skrl _parallel_variance); one block per column.
-__global__ __launch_bounds__(kBlock) void scaler_update_kernel(const float* __restrict__ x, int64_t rows, int cols, int64_t ld,
-                                                               double* __restrict__ mean, double* __restrict__ var,
-                                                               double count) {
-  __shared__ double red[kBlock];
-  const int c = blockIdx.x;
-  double s = 0.0;
-  for (int64_t i = threadIdx.x; i < rows; i += kBlock) s += (double)x[i * ld + c];
-  red[threadIdx.x] = s;
+// RunningStandardScaler update (train=True), two stages.  Stage 1: grid (ceil(cols/64), kChunks): per-chunk column sums
+// of x and x^2 in fp64 (lanes = consecutive columns: coalesced).  Stage 2: batch mean / unbiased variance per column,
+// merged into the running statistics (skrl _parallel_variance).
+__global__ __launch_bounds__(kBlock) void scaler_part_kernel(const float* __restrict__ x, int64_t rows, int cols, int64_t ld,
+                                                             double* __restrict__ part) {
+  __shared__ double red[2][4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), p = threadIdx.x >> 6;
+  const int64_t per = (rows + kChunks - 1) / kChunks;
+  const int64_t lo = (int64_t)blockIdx.y * per, hi = lo + per < rows ? lo + per : rows;
+  double s = 0.0, q = 0.0;
+  if (c < cols)
+    for (int64_t i = lo + p; i < hi; i += 4) {
+      const double v = (double)x[i * ld + c];
+      s += v;
+      q += v * v;
+    }
+  red[0][p][threadIdx.x & 63] = s;
+  red[1][p][threadIdx.x & 63] = q;
   __syncthreads();
-  for (int off = kBlock / 2; off > 0; off >>= 1) {
-    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-    __syncthreads();
+  if (p == 0 && c < cols) {
+    const int l = threadIdx.x;
+    part[((int64_t)blockIdx.y * cols + c) * 2 + 0] = (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]);
+    part[((int64_t)blockIdx.y * cols + c) * 2 + 1] = (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
   }
-  const double bm = red[0] / (double)rows;
-  __syncthreads();
-  double q = 0.0;
-  for (int64_t i = threadIdx.x; i < rows; i += kBlock) {
-    const double d = (double)x[i * ld + c] - bm;
-    q += d * d;
+}
+__global__ __launch_bounds__(kBlock) void scaler_merge_kernel(const double* __restrict__ part, int64_t rows, int cols,
+                                                              double* __restrict__ mean, double* __restrict__ var, double count) {
+  const int c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= cols) return;
+  double s = 0.0, q = 0.0;
+  for (int ch = 0; ch < kChunks; ++ch) {
+    s += part[((int64_t)ch * cols + c) * 2 + 0];
+    q += part[((int64_t)ch * cols + c) * 2 + 1];
   }
-  red[threadIdx.x] = q;
-  __syncthreads();
-  for (int off = kBlock / 2; off > 0; off >>= 1) {
-    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    const double bv = red[0] / (double)(rows - 1);
-    const double n = (double)rows, total = count + n, delta = bm - mean[c];
-    const double m2 = var[c] * count + bv * n + delta * delta * count * n / total;
-    mean[c] = mean[c] + delta * n / total;
-    var[c] = m2 / total;
-  }
+  const double n = (double)rows, bm = s / n;
+  const double bv = (q - n * bm * bm) / (n - 1.0);  // fp64 sums of fp32 data: the cancellation is harmless
+  const double total = count + n, delta = bm - mean[c];
+  const double m2 = var[c] * count + bv * n + delta * delta * count * n / total;
+  mean[c] = mean[c] + delta * n / total;
+  var[c] = m2 / total;
 }
 
 __global__ void scaler_to_f32_kernel(const double* __restrict__ mean64, const double* __restrict__ var64, int n, int np, float eps,
@@ -277,16 +300,33 @@ struct AmpDiscTrainer {
 
 namespace {
 
+// C[M, N] (ld = ldc) = A W^T, optionally gated / accumulated.  `split` (scratch of k_slices * M * ldc floats) enables
+// split-K for the weight-gradient products whose reduction runs over the 4096..12288 batch rows while the output is
+// only a few hundred tiles: the slices' partial products land in `split` and are summed in slice order.
 int gemm_nt(hipStream_t st, const float* A, int64_t lda, int64_t M, const float* W, int Kp, int N, float* C, int64_t ldc,
-            const float* mask, int64_t ldmask, int accumulate) {
+            const float* mask, int64_t ldmask, int accumulate, float* split = nullptr) {
   GemmArgs g{};
   g.A = A; g.lda = lda; g.M = M; g.K = Kp; g.W = W; g.Kp = Kp; g.N = N; g.C = C; g.ldc = ldc;
   g.mask = mask; g.ldmask = ldmask; g.accumulate = accumulate;
   g.n_tiles = N / 64; g.m_tiles = (int)((M + 63) / 64);
-  const unsigned grid = (unsigned)(((int64_t)g.m_tiles * g.n_tiles + 7) / 8 * 8);
-  amp::TraceScope trace__("disc_gemm_kernel<2>", st);
-  disc_gemm_kernel<64, 64, 16, 1, 2, 4><<<grid, kBlock, 0, st>>>(g);
-  return launch_status("disc_gemm_kernel<2>");
+  const int tiles = g.m_tiles * g.n_tiles, nk = Kp / 16;
+  int slices = 1;
+  if (split && !mask) {
+    while (slices < 16 && tiles * slices < 1024 && nk / (slices * 2) >= 16) slices *= 2;
+  }
+  if (slices > 1) {
+    g.k_slices = slices; g.slice_stride = M * ldc; g.C = split; g.accumulate = 0;
+  }
+  const unsigned grid = (unsigned)(((int64_t)tiles * slices + 7) / 8 * 8);
+  {
+    amp::TraceScope trace__("disc_gemm_kernel<2>", st);
+    disc_gemm_kernel<64, 64, 16, 1, 2, 4><<<grid, kBlock, 0, st>>>(g);
+  }
+  int rc = launch_status("disc_gemm_kernel<2>");
+  if (rc != AMP_OK || slices == 1) return rc;
+  const int64_t n = M * ldc;
+  sum_slices_kernel<<<(unsigned)((n + kBlock - 1) / kBlock), kBlock, 0, st>>>(split, slices, n, n, C, accumulate);
+  return launch_status("sum_slices_kernel");
 }
 
 int gemm_fwd(hipStream_t st, const float* A, int64_t lda, int64_t M, const float* W, int Kp, int N, const float* bias, float* C) {
@@ -363,7 +403,7 @@ int amp_disc_trainer_create(AmpDisc* disc, const AmpDiscTrainCfg* cfg, const dou
                     B * p.h2 + B * p.h1 + B * t->kN + B * p.h1 + B * p.h2 +                        // a2 a1 g e1 da2
                     (int64_t)p.h1 * Bp + (int64_t)t->kN * Bp + (int64_t)p.h2 * Bp + (int64_t)p.h1 * Bp +  // a1T dgT a2T e1T
                     (int64_t)p.h1 * t->kN + p.h1 + (int64_t)p.h2 * p.h1 + p.h2 + p.h2 + 1 + 64;    // grads + loss
-  t->ws_floats = f + 16 * 32;
+  t->ws_floats = f + (int64_t)16 * p.h2 * p.h1 + (int64_t)kChunks * 1024 + 1024 + (int64_t)kChunks * p.in_dim * 4 + 16 + 16 * 40;
   if (e == hipSuccess) e = hipMalloc(&t->ws, sizeof(float) * t->ws_floats);
   if (e != hipSuccess) {
     amp_disc_trainer_destroy(t);
@@ -434,7 +474,21 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
   float* gw3 = take(H2n);
   float* gb3 = take(1);
   float* loss = take(16);  // [0] prediction, [1] gradient penalty, [2] logit reg, [3] weight decay
+  float* split = take((int64_t)16 * H2n * H1n);                  // split-K partial products (largest: gW2)
+  float* part = take((int64_t)kChunks * 1024 + 1024);          // column-sum / scalar partials
+  double* dpart = reinterpret_cast<double*>(take((int64_t)kChunks * p.in_dim * 4 + 16));
   AMP_REQUIRE(w - t->ws <= t->ws_floats, "amp_disc_train_step: internal workspace overflow");
+  AMP_REQUIRE(H1n <= 1024 && H2n <= 1024, "amp_disc_train_step: hidden sizes above 1024 are not supported");
+  auto colsum = [&](const float* A, int64_t rows_, int cols_, int64_t lda_, const float* rowscale, const float* mask, int64_t ldm,
+                    float* out, int accumulate) {
+    colsum_part_kernel<<<dim3((cols_ + 63) / 64, kChunks), kBlock, 0, st>>>(A, rows_, cols_, lda_, rowscale, mask, ldm, part);
+    colsum_final_kernel<<<(cols_ + kBlock - 1) / kBlock, kBlock, 0, st>>>(part, cols_, out, accumulate);
+  };
+  auto sumsq = [&](float* x, int64_t rows_, int cols_, int64_t ld_, float coef, int in_place, float scale, int slot, int accumulate) {
+    const int nb = 256;
+    sumsq_part_kernel<<<nb, kBlock, 0, st>>>(x, rows_, cols_, ld_, coef, in_place, part);
+    scalar_final_kernel<<<1, 256, 0, st>>>(part, nb, scale, loss, slot, accumulate);
+  };
   int rc;
 
   // ---- 1. scaler (train=True): update the running statistics with each batch, then scale it --------------------
@@ -444,7 +498,8 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
   const float* groups[3] = {policy, replay, motion};
   for (int gi = 0; gi < 3; ++gi) {
     if (c.update_scaler) {
-      scaler_update_kernel<<<p.in_dim, kBlock, 0, st>>>(groups[gi], B, p.in_dim, row_stride, t->mean64, t->var64, t->count);
+      scaler_part_kernel<<<dim3((p.in_dim + 63) / 64, kChunks), kBlock, 0, st>>>(groups[gi], B, p.in_dim, row_stride, dpart);
+      scaler_merge_kernel<<<(p.in_dim + kBlock - 1) / kBlock, kBlock, 0, st>>>(dpart, B, p.in_dim, t->mean64, t->var64, t->count);
       t->count += (double)B;
     }
     if (c.use_scaler) {
@@ -469,22 +524,22 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
   bce_kernel<<<1, 1024, 0, st>>>(logit, 2 * B, B, c.loss_scale, dlogit, loss);
 
   // ---- 3. backward of the prediction loss ----------------------------------------------------------------------
-  colsum_kernel<<<(H2n + 63) / 64, kBlock, 0, st>>>(H2, M, H2n, H2n, dlogit, nullptr, 0, gw3, 0);   // gw3 = H2^T dlogit
-  colsum_kernel<<<1, kBlock, 0, st>>>(dlogit, M, 1, 1, nullptr, nullptr, 0, gb3, 0);
+  colsum(H2, M, H2n, H2n, dlogit, nullptr, 0, gw3, 0);   // gw3 = H2^T dlogit
+  colsum(dlogit, M, 1, 1, nullptr, nullptr, 0, gb3, 0);
   dh2_kernel<<<blocks(M * H2n), kBlock, 0, st>>>(dlogit, p.w3, H2, M, H2n, dH2);
-  colsum_kernel<<<(H2n + 63) / 64, kBlock, 0, st>>>(dH2, M, H2n, H2n, nullptr, nullptr, 0, gb2, 0);
+  colsum(dH2, M, H2n, H2n, nullptr, nullptr, 0, gb2, 0);
   transpose(st, p.w2, H2n, H1n, H1n, t->w2t, H2n, H1n);               // W2^T [h1, h2]
   transpose(st, p.w1p, H1n, k1p, k1p, t->w1t, H1n, kN);               // W1^T [kN, h1] (zero rows >= k1p)
   rc = gemm_nt(st, dH2, H2n, M, t->w2t, H2n, H1n, dH1, H1n, H1, H1n, 0);   // dH1 = (dH2 W2) * (H1 > 0)
   if (rc != AMP_OK) return rc;
-  colsum_kernel<<<(H1n + 63) / 64, kBlock, 0, st>>>(dH1, M, H1n, H1n, nullptr, nullptr, 0, gb1, 0);
+  colsum(dH1, M, H1n, H1n, nullptr, nullptr, 0, gb1, 0);
   transpose(st, dH2, M, H2n, H2n, dH2T, Mp, H2n);
   transpose(st, H1, M, H1n, H1n, H1T, Mp, H1n);
-  rc = gemm_nt(st, dH2T, Mp, H2n, H1T, (int)Mp, H1n, gW2, H1n, nullptr, 0, 0);   // gW2 = dH2^T H1
+  rc = gemm_nt(st, dH2T, Mp, H2n, H1T, (int)Mp, H1n, gW2, H1n, nullptr, 0, 0, split);   // gW2 = dH2^T H1
   if (rc != AMP_OK) return rc;
   transpose(st, dH1, M, H1n, H1n, dH1T, Mp, H1n);
   transpose(st, Xs, M, k1p, k1p, XsT, Mp, kN);
-  rc = gemm_nt(st, dH1T, Mp, H1n, XsT, (int)Mp, kN, gW1, kN, nullptr, 0, 0);     // gW1 = dH1^T Xs
+  rc = gemm_nt(st, dH1T, Mp, H1n, XsT, (int)Mp, kN, gW1, kN, nullptr, 0, 0, split);     // gW1 = dH1^T Xs
   if (rc != AMP_OK) return rc;
 
   // ---- 4. gradient penalty on the motion rows ------------------------------------------------------------------
@@ -496,29 +551,30 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
     if (rc != AMP_OK) return rc;
     rc = gemm_nt(st, a1, H1n, B, t->w1t, H1n, kN, g, kN, nullptr, 0, 0);         // g = a1 W1      [B, kN]
     if (rc != AMP_OK) return rc;
-    gp_kernel<<<1, 1024, 0, st>>>(g, B, p.in_dim, kN, c.grad_penalty_scale, c.loss_scale, loss);  // g <- dL/dg
+    // loss[1] = gp_scale * mean_rows |g|^2 ;  g <- dL/dg = (2 gp_scale loss_scale / B) g
+    sumsq(g, B, p.in_dim, kN, 2.0f * c.grad_penalty_scale * c.loss_scale / (float)B, 1, c.grad_penalty_scale / (float)B, 1, 0);
     transpose(st, a1, B, H1n, H1n, a1T, Bp, H1n);
     transpose(st, g, B, kN, kN, dgT, Bp, kN);
-    rc = gemm_nt(st, a1T, Bp, H1n, dgT, (int)Bp, kN, gW1, kN, nullptr, 0, 1);    // gW1 += a1^T dg
+    rc = gemm_nt(st, a1T, Bp, H1n, dgT, (int)Bp, kN, gW1, kN, nullptr, 0, 1, split);    // gW1 += a1^T dg
     if (rc != AMP_OK) return rc;
     rc = gemm_nt(st, g, kN, B, p.w1p, k1p, H1n, e1, H1n, H1m, H1n, 0);           // e1 = (dg W1^T) * m1   (K = k1p <= kN)
     if (rc != AMP_OK) return rc;
     transpose(st, a2, B, H2n, H2n, a2T, Bp, H2n);
     transpose(st, e1, B, H1n, H1n, e1T, Bp, H1n);
-    rc = gemm_nt(st, a2T, Bp, H2n, e1T, (int)Bp, H1n, gW2, H1n, nullptr, 0, 1);  // gW2 += a2^T e1
+    rc = gemm_nt(st, a2T, Bp, H2n, e1T, (int)Bp, H1n, gW2, H1n, nullptr, 0, 1, split);  // gW2 += a2^T e1
     if (rc != AMP_OK) return rc;
     rc = gemm_nt(st, e1, H1n, B, p.w2, H1n, H2n, da2, H2n, nullptr, 0, 0);       // da2 = e1 W2^T
     if (rc != AMP_OK) return rc;
-    colsum_kernel<<<(H2n + 63) / 64, kBlock, 0, st>>>(da2, B, H2n, H2n, nullptr, H2m, H2n, gw3, 1);  // gw3 += colsum(m2 * da2)
+    colsum(da2, B, H2n, H2n, nullptr, H2m, H2n, gw3, 1);  // gw3 += colsum(m2 * da2)
   } else {
     AMP_HIP(hipMemsetAsync(loss + 1, 0, sizeof(float), st));
   }
 
   // ---- 5. regularisers (values for the report; their gradients are folded into the Adam kernel) ----------------
-  sumsq_kernel<<<1, 1024, 0, st>>>(p.w3, 1, H2n, H2n, c.logit_reg_scale, loss, 2, 0);
-  sumsq_kernel<<<1, 1024, 0, st>>>(p.w1p, H1n, p.in_dim, k1p, c.weight_decay_scale, loss, 3, 0);
-  sumsq_kernel<<<1, 1024, 0, st>>>(p.w2, H2n, H1n, H1n, c.weight_decay_scale, loss, 3, 1);
-  sumsq_kernel<<<1, 1024, 0, st>>>(p.w3, 1, H2n, H2n, c.weight_decay_scale, loss, 3, 1);
+  sumsq(p.w3, 1, H2n, H2n, 0.0f, 0, c.logit_reg_scale, 2, 0);
+  sumsq(p.w1p, H1n, p.in_dim, k1p, 0.0f, 0, c.weight_decay_scale, 3, 0);
+  sumsq(p.w2, H2n, H1n, H1n, 0.0f, 0, c.weight_decay_scale, 3, 1);
+  sumsq(p.w3, 1, H2n, H2n, 0.0f, 0, c.weight_decay_scale, 3, 1);
   if (loss_dev) AMP_HIP(hipMemcpyAsync(loss_dev, loss, 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
 
   // ---- 6. Adam -------------------------------------------------------------------------------------------------
