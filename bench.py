@@ -27,7 +27,10 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
-DOMINANT_KERNEL = "disc_gemm_kernel<1>"  # layer 2 of the discriminator: 2*M*1024*512 of the 2*M*(in*1024+1024*512+512) FLOPs
+# layer 2 of the discriminator: 2*M*1024*512 of the 2*M*(in*1024+1024*512+512) FLOPs
+DOMINANT_KERNEL = {"f16x3": "disc_gemm_f16_kernel<1>", "f32": "disc_gemm_kernel<1>"}
+MFMA_PEAK_TFLOPS = {"f16x3": 16 * 157.3, "f32": 157.3}  # dense fp16 MFMA = 16 x the fp32 MFMA rate (MI355X_MICROARCH.md)
+MFMA_PER_PRODUCT = {"f16x3": 3, "f32": 1}               # the fp16 engine issues three MFMA products per algorithmic one
 
 
 def parse_args():
@@ -43,7 +46,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=0, help="envs of the CPU sample (0 = same as --envs)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 4096-env secondary measurement")
-    ap.add_argument("--split-modes", action="store_true", help="also time the experimental split-precision (bf16x6 / bf16x3) discriminator")
+    ap.add_argument("--disc-precision", default="f16x3", choices=["f16x3", "f32"],
+                    help="GEMM engine of the discriminator (both fp32-class accuracy): fp16-split (default) or fp32 MFMA")
+    ap.add_argument("--no-fp32-engine", action="store_true", help="skip the comparison run on the fp32-MFMA GEMM engine")
     ap.add_argument("--no-graph", action="store_true", help="never use hipGraph replay (secondary measurement included)")
     return ap.parse_args()
 
@@ -183,7 +188,8 @@ def main():
 
     spec = WORKLOADS[args.workload]
     with contextlib.redirect_stdout(sys.stderr):  # MotionLoader prints like the reference; stdout carries only the JSON line
-        hot = HotPath(spec, args.envs, device, seed=1234 + rank)
+        hot = HotPath(spec, args.envs, device, seed=1234 + rank, disc_precision=args.disc_precision)
+    dominant = DOMINANT_KERNEL[args.disc_precision]
     collective = None
     if world > 1:
         # the gathered minibatches feed the (out-of-scope) discriminator update, so nothing in the env path waits for
@@ -193,7 +199,7 @@ def main():
         collective = {"every": args.rollouts, "fn": lambda: [ag.start() for _ in range(args.minibatches)], "join": ag.wait_all}
 
     # ---- timed region: exactly --steps steps, the dominant kernel bracketed by HIP events on its stream --------
-    with nat.KernelTrace(capacity=args.steps + args.warmup + 8, kernel_filter=DOMINANT_KERNEL) as tr:
+    with nat.KernelTrace(capacity=args.steps + args.warmup + 8, kernel_filter=dominant) as tr:
         dt = timed_steps(hot, args.steps, args.warmup, world, collective)
     recs = tr.records()[-args.steps:]
     gemm2_ms = sum(ms for _, ms in recs) / max(len(recs), 1)
@@ -212,28 +218,37 @@ def main():
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            wg = {k.split("@")[0]: k for k in tj if k.endswith(f"@{(args.envs + 127) // 128 * 4}")}
-            traffic = tj[wg[DOMINANT_KERNEL.replace("<1>", "<128, 128, 16, 1, 1, 4>")]]["hbm_bytes"] if args.envs >= 16384 else None
+            # keys are "kernel<template args>@workgroups"; layer 2 at this shard size = ceil(envs / 128) * 4 workgroups
+            tmpl = {"f16x3": "disc_gemm_f16_kernel<2, 2, 64, 1, 2>", "f32": "disc_gemm_kernel<128, 128, 16, 1, 1, 4>"}[args.disc_precision]
+            traffic = tj[f"{tmpl}@{(args.envs + 127) // 128 * 4}"]["hbm_bytes"] if args.envs >= 16384 else None
         except Exception:
             traffic = None
         flops2 = 2.0 * args.envs * 1024 * 512 + 2.0 * args.envs * 512   # layer 2 + the fused 512 -> 1 dot
         achieved = flops2 / (gemm2_ms * 1e-3) / 1e12
+        peak = MFMA_PEAK_TFLOPS[args.disc_precision]
+        nprod = MFMA_PER_PRODUCT[args.disc_precision]
         hbm_kernels = ("collect_reference_kernel", "env_step_kernel", "compact_scatter_kernel")
         hbm_us = sum(per_kernel.get(k, 0.0) for k in hbm_kernels)
         alg_bytes = algorithmic_bytes_per_env_step(spec) * args.envs
         out = {
             "metric": "AMP obs+motion-sample+reward env-steps/s", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (GEMM operands as 2 fp16 planes, 3 fp16 MFMAs per product, f32 accumulate)" if nprod == 3 else "f32",
+            "data": "synthetic",
             "config": {"workload": f"{spec.description}, {args.envs} envs per GPU, synthetic joint states, discriminator "
                                    f"[{spec.K * spec.D},1024,512,1] seed-0 init", "envs_per_gpu": args.envs,
                        "global_envs": args.envs * world, "parallelism": f"env-shard x{world}",
                        "collective": (f"RCCL all-gather [{args.replay_minibatch},{spec.K * spec.D}] f32 per rank x "
                                       f"{args.minibatches} every {args.rollouts} steps, async on the RCCL stream, joined inside "
                                       "the timed region") if world > 1 else "none"},
-            "roofline": {"bound": "mfma", "kernel": DOMINANT_KERNEL, "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
-                         "avg_launch_ms": gemm2_ms, "launches_timed": len(recs), "flops_per_launch": flops2},
+            # achieved = ALGORITHMIC FLOPs / launch time against the dense MFMA peak of the operand type the kernel
+            # issues; the fp16-split engine executes 3 MFMA products per algorithmic one (frac_executed counts those)
+            "roofline": {"bound": "mfma", "kernel": dominant, "achieved": achieved, "peak": peak,
+                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                         "avg_launch_ms": gemm2_ms, "launches_timed": len(recs), "flops_per_launch": flops2,
+                         "mfma_products_per_flop": nprod, "frac_executed": nprod * achieved / peak,
+                         "vs_fp32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS},
             "roofline_hbm": {"bound": "hbm", "kernels": list(hbm_kernels), "achieved": alg_bytes / (hbm_us * 1e-6) / 1e9 if hbm_us else None,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (alg_bytes / (hbm_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if hbm_us else None,
                              "bytes_per_env_step": algorithmic_bytes_per_env_step(spec), "us": hbm_us},
@@ -256,21 +271,23 @@ def main():
                                 "launch": "eager" if args.no_graph else "hipGraph replay of the captured step"}
         del hot_s
 
-    # ---- opt-in split-precision discriminator (NOT the headline: `value` above is native fp32 MFMA) -----------------
-    if args.split_modes:
-        extra = {}
-        for mode in ("bf16x6", "bf16x3"):
-            torch.cuda.empty_cache()
-            with contextlib.redirect_stdout(sys.stderr):
-                hot_m = HotPath(spec, args.envs, device, seed=1234 + rank, disc_precision=mode)
+    # ---- the same step on the fp32-MFMA GEMM engine (exact fp32 fma chain), for comparison ---------------------------
+    if not args.no_fp32_engine and args.disc_precision != "f32" and world == 1:
+        torch.cuda.empty_cache()
+        with contextlib.redirect_stdout(sys.stderr):
+            hot_m = HotPath(spec, args.envs, device, seed=1234 + rank, disc_precision="f32")
+        with nat.KernelTrace(capacity=args.steps + args.warmup + 8, kernel_filter=DOMINANT_KERNEL["f32"]) as trm:
             dtm = timed_steps(hot_m, args.steps, args.warmup, world, None)
-            extra[mode] = {"value": args.envs * world * args.steps / dtm, "unit": "env-steps/s", "ms_per_step": dtm / args.steps * 1e3}
-            del hot_m
-        if rank == 0:
-            out["split_precision_modes"] = {
-                "note": "experimental, opt-in (AmpDiscriminator(precision=...)): fp32 operands as 3 / 2 bf16 planes, 6 / 3 bf16 "
-                        "MFMAs per k-step, fp32 accumulate; bf16x6 error <= native fp32's, bf16x3 ~1e-5*|logit|.  Not the headline.",
-                **extra}
+        rm = trm.records()[-args.steps:]
+        ms32 = sum(ms for _, ms in rm) / max(len(rm), 1)
+        flops2 = 2.0 * args.envs * 1024 * 512 + 2.0 * args.envs * 512
+        out["fp32_mfma_engine"] = {
+            "value": args.envs * world * args.steps / dtm, "unit": "env-steps/s", "ms_per_step": dtm / args.steps * 1e3,
+            "roofline": {"bound": "mfma", "kernel": DOMINANT_KERNEL["f32"], "achieved": flops2 / (ms32 * 1e-3) / 1e12,
+                         "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops2 / (ms32 * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                         "avg_launch_ms": ms32},
+            "note": "AmpDiscriminator(precision='f32'): v_mfma_f32_32x32x2_f32 on fp32 operands; same results to <= 1e-6"}
+        del hot_m
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

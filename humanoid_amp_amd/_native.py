@@ -13,8 +13,10 @@ import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libamp_engine.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
+AMP_DISC_F16X3, AMP_DISC_FP32 = 0, 1
+AMP_DISC_INPUT_F32_ROWS, AMP_DISC_INPUT_F16_PLANES = 0, 1
 AMP_PHASE_DONES, AMP_PHASE_REWARD, AMP_PHASE_OBS = 1, 2, 4
 AMP_PHASE_ALL = 7
 TILE_ENVS = 64
@@ -86,8 +88,14 @@ class AmpEnvBuffers(C.Structure):
         ("just_reset", C.c_void_p), ("reward", C.c_void_p), ("reward_terms", C.c_void_p), ("died", C.c_void_p),
         ("time_out", C.c_void_p), ("reset_mask", C.c_void_p), ("reset_tile_counts", C.c_void_p),
         ("disc_input", C.c_void_p), ("disc_input_stride", C.c_int64), ("scaler_mean", C.c_void_p), ("scaler_den", C.c_void_p),
-        ("scaler_clip", C.c_float), ("reserved", C.c_int32),
+        ("scaler_clip", C.c_float), ("disc_input_format", C.c_int32), ("disc_input_plane", C.c_int64),
+        ("disc_plane_scale", C.c_float), ("reserved", C.c_int32),
     ]
+
+
+class AmpDiscInputLayout(C.Structure):
+    _fields_ = [("format", C.c_int32), ("padded_dim", C.c_int32), ("mean_dev", C.c_void_p), ("den_dev", C.c_void_p),
+                ("clip", C.c_float), ("plane_scale", C.c_float)]
 
 
 class AmpDiscDesc(C.Structure):
@@ -129,7 +137,7 @@ SIGNATURES = {
     "amp_disc_set_scaler": (C.c_int, [_vp, _vp, _vp, _f32, _f32, _vp]),
     "amp_disc_set_precision": (C.c_int, [_vp, _i32, _vp]),
     "amp_disc_workspace_bytes": (_i64, [_vp, _i64]),
-    "amp_disc_input_layout": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_f32)]),
+    "amp_disc_input_layout": (C.c_int, [_vp, C.POINTER(AmpDiscInputLayout)]),
     "amp_disc_get_weights": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "amp_disc_trainer_create": (C.c_int, [_vp, C.POINTER(AmpDiscTrainCfg), _vp, _vp, C.c_double, _vp, C.POINTER(_vp)]),
     "amp_disc_trainer_destroy": (C.c_int, [_vp]),

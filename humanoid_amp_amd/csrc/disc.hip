@@ -1,26 +1,31 @@
 // Discriminator style reward: scaler -> Linear(K*D,1024)+ReLU -> Linear(1024,512)+ReLU -> Linear(512,1)
-// -> -log(max(1 - sigmoid, 1e-4)) * scale -> reward mix.  fp32 end to end on the gfx950 matrix cores
-// (v_mfma_f32_32x32x2_f32: exact fp32 fma chain; the 1e-5 budget rules out bf16/fp8 operands).
+// -> -log(max(1 - sigmoid, 1e-4)) * scale -> reward mix, at fp32 accuracy (the path's 1e-5 budget).
+//
+// Two GEMM engines share the layout below (amp_disc_set_precision):
+//   AMP_DISC_F16X3 (default)  fp32 operands as two fp16 planes, three v_mfma_f32_32x32x16_f16 per k-step into one fp32
+//                             accumulator (disc_gemm_f16.hpp): fp32-class error at 3/16 of the fp32 pipe's MFMA cycles.
+//   AMP_DISC_FP32             v_mfma_f32_32x32x2_f32 on fp32 operands (disc_gemm.hpp): exact fp32 fma chain.
 //
 //   scale    one pass over amp_obs: RunningStandardScaler (exact fp32 divide, once per element) + zero padding of
-//            K*D to a multiple of 32 -> Xs [M, k1p] in the workspace (16-B aligned rows for the GEMM staging).
-//   layer 1  GEMM [M, k1p] x [k1p, 1024]: bias + ReLU in the epilogue, transposed through LDS so every store is
-//            a full 256-B row segment; H1 [M,1024] written once to the workspace.
-//   layer 2  GEMM [M,1024] x [1024,512]: bias + ReLU + the 512->1 output layer as an in-register dot with
-//            w3, reduced over the tile's columns (lane butterfly, then LDS across the two column waves);
-//            only per-(row, column-tile) partial logits leave the kernel.
-//   finalize fixed-order sum of the 4 column-tile partials + b3, style reward, reward mix.
+//            K*D to the k-tile -> Xs in the workspace (fp32 rows, or the two fp16 planes of s_x * Xs).
+//   layer 1  GEMM [M, k] x [k, 1024]: bias + ReLU in the epilogue, transposed through LDS so every store is a full
+//            row segment; H1 written once to the workspace (fp32, or the two planes of s_h * H1).
+//   layer 2  GEMM [M,1024] x [1024,512]: bias + ReLU + the 512->1 output layer as a per-lane dot with w3 over the
+//            transposed accumulator tile; only per-(row, column-tile) partial logits leave the kernel.
+//   finalize fixed-order sum of the column-tile partials + b3, style reward, reward mix.
 //
-// Tile: 128 x 128 x 32, 4 waves as 2 x 2, each wave 64 x 64 = 2 x 2 MFMA 32x32 accumulators (64 VGPRs).
-// LDS rows are padded to 36 floats so the four ds_read_b128 a lane issues per operand row are conflict-free.
-// Global->LDS staging is register-prefetched one k-tile ahead.  Workgroups are renumbered so that the
-// column tiles of one row tile run on the same XCD (they share the A tile through that XCD's L2).
+// Plane scales are powers of two derived from BOUNDS, not from the data: |Xs| <= clip (the scaler's clamp; without a
+// clamp an abs-max pass over the scaled input supplies it), |W| <= max |W|, |H1| <= max_j sum_k |W1[j,k]| * bound_x +
+// max |b1|.  A loose bound costs nothing (fp16 keeps 2^-11 relative precision over 2^30 below the bound), and results
+// do not depend on which other rows share the batch.
 #include "disc_gemm.hpp"
-#include "disc_gemm_split.hpp"
+#include "disc_gemm_f16.hpp"
 
 #include <cstdlib>
 
 typedef float f4 __attribute__((ext_vector_type(4)));  // native vector: HIP's f4 struct turns into memcpy -> scratch
+
+using amp::DiscRange;  // device-resident range record of the fp16-split path (disc_gemm_f16.hpp)
 
 struct AmpDisc {
   int32_t in_dim, h1, h2, k1p;
@@ -34,16 +39,19 @@ struct AmpDisc {
   float* den;  // [k1p] sqrt(var) + eps
   float clip;
   bool has_scaler;
-  // opt-in split-precision GEMMs (disc_gemm_split.hpp): 0 = native fp32 MFMA, 2 = bf16x3, 3 = bf16x6
-  int32_t planes;
-  __bf16* w1s;  // [planes][h1][k1p]
-  __bf16* w2s;  // [planes][h2][h1]
+  int32_t mode;       // AMP_DISC_F16X3 / AMP_DISC_FP32
+  int32_t k1h;        // in_dim padded to the fp16 k-tile
+  _Float16* w1h;      // [2][h1][k1h] planes of s_w1 * W1
+  _Float16* w2h;      // [2][h2][h1]  planes of s_w2 * W2
+  DiscRange* range;   // device
 };
 
 namespace amp {
 
 constexpr int kMinN = 128;  // h1 / h2 must be multiples of the widest column tile
-constexpr int kPadK = 16;  // in_dim is zero-padded to a multiple of the layer-1 k-tile
+constexpr int kPadK = 16;  // in_dim is zero-padded to a multiple of the fp32 layer-1 k-tile
+constexpr int kPadKH = 32; // ... and of the fp16 layer-1 k-tile
+constexpr int64_t kWsHeader = 256;  // workspace header: [0] abs-max of the scaled input (dynamic bound)
 
 __global__ __launch_bounds__(kBlock) void disc_finalize_kernel(const float* __restrict__ partial, int n_tiles,
                                                                const float* __restrict__ b3, int64_t M, float scale,
@@ -124,6 +132,104 @@ __global__ __launch_bounds__(kBlock) void disc_scale_pad_kernel(const float* __r
 
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
+// ---- fp16-split path: ranges, plane scales, input split ------------------------------------------------------------
+
+// One workgroup: max |W1|, max_j sum_k |W1[j,k]|, max |b1|, max |W2| -> DiscRange (runs when the weights change).
+__global__ __launch_bounds__(1024) void disc_weight_range_kernel(const float* __restrict__ w1p, int h1, int k1p,
+                                                                 const float* __restrict__ b1, const float* __restrict__ w2,
+                                                                 int h2, DiscRange* __restrict__ out) {
+  __shared__ float red[4][1024];
+  const int t = threadIdx.x;
+  float wmax1 = 0.0f, rsum = 0.0f, bmax = 0.0f, wmax2 = 0.0f;
+  for (int j = t; j < h1; j += 1024) {
+    float rs = 0.0f;
+    for (int k = 0; k < k1p; ++k) {
+      const float a = fabsf(w1p[(int64_t)j * k1p + k]);
+      wmax1 = fmaxf(wmax1, a);
+      rs += a;
+    }
+    rsum = fmaxf(rsum, rs);
+    bmax = fmaxf(bmax, fabsf(b1[j]));
+  }
+  for (int64_t e = t; e < (int64_t)h2 * h1; e += 1024) wmax2 = fmaxf(wmax2, fabsf(w2[e]));
+  red[0][t] = wmax1; red[1][t] = rsum; red[2][t] = bmax; red[3][t] = wmax2;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (t < o)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) red[q][t] = fmaxf(red[q][t], red[q][t + o]);
+    __syncthreads();
+  }
+  if (t == 0) {
+    out->s_w1 = plane_scale(red[0][0]);
+    out->s_w2 = plane_scale(red[3][0]);
+    out->wsum1 = red[1][0] * 1.0001f;  // the row sums were rounded: keep the bound a bound
+    out->bmax1 = red[2][0];
+  }
+}
+
+__global__ void disc_set_clip_kernel(DiscRange* r, float clip) { r->clip = clip; }
+
+// abs-max of the scaled input (only when no clamp bounds it): one atomicMax per workgroup on the bit pattern of a
+// non-negative float (order-independent, hence deterministic)
+__global__ __launch_bounds__(kBlock) void disc_absmax_kernel(const float* __restrict__ x, int64_t row_stride, int64_t M, int k,
+                                                             const float* __restrict__ mean, const float* __restrict__ den,
+                                                             float clip, unsigned* __restrict__ amax) {
+  __shared__ float red[kBlock];
+  float m = 0.0f;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < M * k; e += (int64_t)gridDim.x * kBlock) {
+    const int64_t r = e / k;
+    const int c = (int)(e - r * k);
+    float v = x[r * row_stride + c];
+    if (mean) v = fminf(fmaxf((v - mean[c]) / den[c], -clip), clip);
+    m = fmaxf(m, fabsf(v));
+  }
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicMax(amax, __float_as_uint(red[0]));
+}
+
+// amp_obs [M, in] (any row stride) -> the two fp16 planes of s_x * clamp((x - mean) / den) [M, kh], zero padded.
+// One thread per 8 columns (16-B stores per plane).  Also snapshots the task reward like disc_scale_pad_kernel.
+__global__ __launch_bounds__(kBlock) void disc_scale_split_kernel(const float* __restrict__ x, int64_t row_stride, int64_t M,
+                                                                  int k, int kh, const float* __restrict__ mean,
+                                                                  const float* __restrict__ den, float clip,
+                                                                  const DiscRange* __restrict__ range,
+                                                                  const float* __restrict__ amax, _Float16* __restrict__ planes,
+                                                                  const float* __restrict__ task, float* __restrict__ task_copy) {
+  const int o_per_row = kh >> 3;
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (task && e < M) task_copy[e] = task[e];
+  if (e >= M * o_per_row) return;
+  const float s_x = plane_scale(amax ? amax[0] : range->clip);
+  const int64_t m = e / o_per_row;
+  const int c0 = (int)(e - m * o_per_row) * 8;
+  const float* row = x + m * row_stride;
+  h8 p0, p1;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = c0 + i;
+    float v = 0.0f;
+    if (c < k) {
+      v = row[c];
+      if (mean) {
+        v = (v - mean[c]) / den[c];
+        v = fminf(fmaxf(v, -clip), clip);
+      }
+    }
+    v *= s_x;
+    const _Float16 a = (_Float16)v;
+    p0[i] = a;
+    p1[i] = (_Float16)(v - (float)a);
+  }
+  *reinterpret_cast<h8*>(planes + m * kh + c0) = p0;
+  *reinterpret_cast<h8*>(planes + M * kh + m * kh + c0) = p1;
+}
+
 }  // namespace amp
 
 namespace amp {
@@ -175,56 +281,80 @@ static int disc_forward(const AmpDisc* h, const float* Xs, int64_t rows, float* 
   }
   return launch_status("disc_finalize_kernel");
 }
-// split-precision forward on bf16 planes Xp [planes][rows][k1p] (disc_gemm_split.hpp)
-static int disc_forward_split(const AmpDisc* h, const __bf16* Xp, int64_t rows, __bf16* H1p, float* partial, float scale,
-                              const float* task, float task_w, float style_w, float* logits, float* style, float* combined,
-                              hipStream_t st) {
+// fp16-split forward on the planes Xp [2][rows][k1h] of the scaled input (disc_gemm_f16.hpp); `amax` = the dynamic
+// bound of the scaled input, or null when the scaler's clamp bounds it
+template <int TM, int TN, int BK, int MODE, int MINW>
+static int launch_f16(GemmF16Args g, int64_t rows, int N, const char* name, hipStream_t st) {
+  g.n_tiles = N / (64 * TN);
+  g.m_tiles = (int)((rows + 64 * TM - 1) / (64 * TM));
+  const unsigned grid = (unsigned)(((int64_t)g.m_tiles * g.n_tiles + 7) / 8 * 8);
+  amp::TraceScope trace__(name, st);
+  disc_gemm_f16_kernel<TM, TN, BK, MODE, MINW><<<grid, kBlock, gemm_f16_lds_bytes<TM, TN, BK>(), st>>>(g);
+  return launch_status(name);
+}
+// kernels whose LDS tile exceeds the 64 KB default need the limit raised once (not capturable: done at create)
+static int f16_kernels_init() {
+  static bool done = false;
+  if (done) return AMP_OK;
+  AMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gemm_f16_kernel<2, 4, 32, 0, 2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, gemm_f16_lds_bytes<2, 4, 32>()));
+  AMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gemm_f16_kernel<2, 2, 64, 1, 2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, gemm_f16_lds_bytes<2, 2, 64>()));
+  done = true;
+  return AMP_OK;
+}
+static int f16_n_tiles(const AmpDisc* h, int64_t rows) {
+  const bool big = (rows + 127) / 128 * (h->h2 / 128) >= 512;
+  return h->h2 / (big ? 128 : 64);
+}
+static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* amax, int64_t rows, _Float16* H1p, float* partial,
+                            float scale, const float* task, float task_w, float style_w, float* logits, float* style,
+                            float* combined, hipStream_t st) {
+  // Tile choice measured with tools/gemm_f16_bench.hip (profiles/r01_gemm_f16_variants.txt): layer 1 (k = 192, store
+  // bound) 128 x 256 x 32, layer 2 128 x 128 x 64, each at 2 workgroups / CU; shards with < 512 such tiles use 64 x 64
   auto big_tiles = [&](int N) { return (rows + 127) / 128 * (N / 128) >= 512; };
-  SplitGemmArgs g1{};
-  g1.A = Xp; g1.a_plane = rows * h->k1p; g1.lda = h->k1p; g1.M = rows;
-  g1.W = h->w1s; g1.w_plane = (int64_t)h->h1 * h->k1p; g1.Kp = h->k1p; g1.bias = h->b1; g1.N = h->h1;
-  g1.C = H1p; g1.c_plane = rows * h->h1; g1.ldc = h->h1;
-  {
-    const bool big = big_tiles(h->h1);
-    const int bm = big ? 128 : 64;
-    g1.n_tiles = h->h1 / bm; g1.m_tiles = (int)((rows + bm - 1) / bm);
-    const unsigned grid = (unsigned)(((int64_t)g1.m_tiles * g1.n_tiles + 7) / 8 * 8);
-    amp::TraceScope trace__("disc_gemm_split_kernel<0>", st);
-    if (h->planes == 3) {
-      if (big) disc_gemm_split_kernel<128, 128, 3, 0, 2><<<grid, kBlock, 0, st>>>(g1);
-      else disc_gemm_split_kernel<64, 64, 3, 0, 4><<<grid, kBlock, 0, st>>>(g1);
-    } else {
-      if (big) disc_gemm_split_kernel<128, 128, 2, 0, 2><<<grid, kBlock, 0, st>>>(g1);
-      else disc_gemm_split_kernel<64, 64, 2, 0, 4><<<grid, kBlock, 0, st>>>(g1);
-    }
-  }
-  int rc = launch_status("disc_gemm_split_kernel<0>");
+  GemmF16Args g1{};
+  g1.A = Xp; g1.lda = h->k1h; g1.plane_a = rows * h->k1h; g1.M = rows;
+  g1.W = h->w1h; g1.plane_w = (int64_t)h->h1 * h->k1h; g1.Kp = h->k1h; g1.N = h->h1;
+  g1.bias = h->b1; g1.range = h->range; g1.amax = amax; g1.layer = 1;
+  g1.H = H1p; g1.ldh = h->h1; g1.plane_h = rows * h->h1;
+  int rc;
+  if (big_tiles(h->h1) && h->h1 % 256 == 0) rc = launch_f16<2, 4, 32, 0, 2>(g1, rows, h->h1, "disc_gemm_f16_kernel<0>", st);
+  else if (big_tiles(h->h1)) rc = launch_f16<2, 2, 32, 0, 3>(g1, rows, h->h1, "disc_gemm_f16_kernel<0>", st);
+  else rc = launch_f16<1, 1, 32, 0, 6>(g1, rows, h->h1, "disc_gemm_f16_kernel<0>", st);
   if (rc != AMP_OK) return rc;
-  SplitGemmArgs g2{};
-  g2.A = H1p; g2.a_plane = rows * h->h1; g2.lda = h->h1; g2.M = rows;
-  g2.W = h->w2s; g2.w_plane = (int64_t)h->h2 * h->h1; g2.Kp = h->h1; g2.bias = h->b2; g2.N = h->h2;
+
+  GemmF16Args g2{};
+  g2.A = H1p; g2.lda = h->h1; g2.plane_a = rows * h->h1; g2.M = rows;
+  g2.W = h->w2h; g2.plane_w = (int64_t)h->h2 * h->h1; g2.Kp = h->h1; g2.N = h->h2;
+  g2.bias = h->b2; g2.range = h->range; g2.amax = amax; g2.layer = 2;
   g2.w3 = h->w3; g2.partial = partial;
-  {
-    const bool big = big_tiles(h->h2);
-    const int bm = big ? 128 : 64;
-    g2.n_tiles = h->h2 / bm; g2.m_tiles = (int)((rows + bm - 1) / bm);
-    const unsigned grid = (unsigned)(((int64_t)g2.m_tiles * g2.n_tiles + 7) / 8 * 8);
-    amp::TraceScope trace__("disc_gemm_split_kernel<1>", st);
-    if (h->planes == 3) {
-      if (big) disc_gemm_split_kernel<128, 128, 3, 1, 2><<<grid, kBlock, 0, st>>>(g2);
-      else disc_gemm_split_kernel<64, 64, 3, 1, 4><<<grid, kBlock, 0, st>>>(g2);
-    } else {
-      if (big) disc_gemm_split_kernel<128, 128, 2, 1, 2><<<grid, kBlock, 0, st>>>(g2);
-      else disc_gemm_split_kernel<64, 64, 2, 1, 4><<<grid, kBlock, 0, st>>>(g2);
-    }
-  }
-  rc = launch_status("disc_gemm_split_kernel<1>");
+  const int n_tiles = f16_n_tiles(h, rows);
+  if (big_tiles(h->h2)) rc = launch_f16<2, 2, 64, 1, 2>(g2, rows, h->h2, "disc_gemm_f16_kernel<1>", st);
+  else rc = launch_f16<1, 1, 64, 1, 4>(g2, rows, h->h2, "disc_gemm_f16_kernel<1>", st);
   if (rc != AMP_OK) return rc;
   { amp::TraceScope trace__("disc_finalize_kernel", st);
-    disc_finalize_kernel<<<(unsigned)((rows + kBlock - 1) / kBlock), kBlock, 0, st>>>(partial, g2.n_tiles, h->b3, rows, scale, task,
+    disc_finalize_kernel<<<(unsigned)((rows + kBlock - 1) / kBlock), kBlock, 0, st>>>(partial, n_tiles, h->b3, rows, scale, task,
                                                                                    task_w, style_w, logits, style, combined);
   }
   return launch_status("disc_finalize_kernel");
+}
+
+// weights (or the scaler) changed: ranges, plane scales and the fp16 planes of W1 / W2
+static int f16_refresh(AmpDisc* h, hipStream_t st) {
+  { amp::TraceScope trace__("disc_weight_range_kernel", st);
+    disc_weight_range_kernel<<<1, 1024, 0, st>>>(h->w1p, h->h1, h->k1p, h->b1, h->w2, h->h2, h->range);
+  }
+  int rc = launch_status("disc_weight_range_kernel");
+  if (rc != AMP_OK) return rc;
+  const int64_t n1 = (int64_t)h->h1 * h->k1h, n2 = (int64_t)h->h2 * h->h1;
+  { amp::TraceScope trace__("split_rows_f16_kernel", st);
+    split_rows_f16_kernel<<<(unsigned)((n1 / 4 + kBlock - 1) / kBlock), kBlock, 0, st>>>(h->w1p, h->h1, h->k1p, h->k1p, &h->range->s_w1,
+                                                                                        h->w1h, h->k1h, n1);
+    split_rows_f16_kernel<<<(unsigned)((n2 / 4 + kBlock - 1) / kBlock), kBlock, 0, st>>>(h->w2, h->h2, h->h1, h->h1, &h->range->s_w2,
+                                                                                        h->w2h, h->h1, n2);
+  }
+  return launch_status("split_rows_f16_kernel");
 }
 }  // namespace amp
 
@@ -236,8 +366,8 @@ struct DiscParams {
 };
 DiscParams disc_params(AmpDisc* h) { return DiscParams{h->in_dim, h->h1, h->h2, h->k1p, h->w1p, h->b1, h->w2, h->b2, h->w3, h->b3}; }
 int disc_refresh_derived(AmpDisc* h, hipStream_t st) {
-  // the fp32 weights changed in place: re-split the bf16 planes of the opt-in split-precision mode
-  return h->planes ? amp_disc_set_precision(h, h->planes, (amp_stream_t)st) : AMP_OK;
+  // the fp32 weights changed in place: ranges and fp16 planes follow
+  return f16_refresh(h, st);
 }
 }  // namespace amp
 
@@ -255,8 +385,9 @@ int amp_disc_destroy(AmpDisc* h) {
   (void)hipFree(h->b3);
   (void)hipFree(h->mean);
   (void)hipFree(h->den);
-  (void)hipFree(h->w1s);
-  (void)hipFree(h->w2s);
+  (void)hipFree(h->w1h);
+  (void)hipFree(h->w2h);
+  (void)hipFree(h->range);
   delete h;
   return AMP_OK;
 }
@@ -274,6 +405,8 @@ int amp_disc_create(const AmpDiscDesc* d, amp_stream_t stream, AmpDisc** out) {
   h->h1 = d->h1;
   h->h2 = d->h2;
   h->k1p = (int32_t)round_up(d->in_dim, kPadK);
+  h->k1h = (int32_t)round_up(d->in_dim, kPadKH);
+  h->mode = AMP_DISC_F16X3;
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipMalloc(&h->w1p, sizeof(float) * (size_t)h->h1 * h->k1p);
   if (e == hipSuccess) e = hipMalloc(&h->b1, sizeof(float) * h->h1);
@@ -283,6 +416,10 @@ int amp_disc_create(const AmpDiscDesc* d, amp_stream_t stream, AmpDisc** out) {
   if (e == hipSuccess) e = hipMalloc(&h->b3, sizeof(float));
   if (e == hipSuccess) e = hipMalloc(&h->mean, sizeof(float) * h->k1p);
   if (e == hipSuccess) e = hipMalloc(&h->den, sizeof(float) * h->k1p);
+  if (e == hipSuccess) e = hipMalloc(&h->w1h, sizeof(_Float16) * 2 * (size_t)h->h1 * h->k1h);
+  if (e == hipSuccess) e = hipMalloc(&h->w2h, sizeof(_Float16) * 2 * (size_t)h->h2 * h->h1);
+  if (e == hipSuccess) e = hipMalloc(&h->range, sizeof(DiscRange));
+  if (e == hipSuccess) e = hipMemsetAsync(h->range, 0, sizeof(DiscRange), st);
   if (e == hipSuccess) e = hipMemcpyAsync(h->b1, d->b1, sizeof(float) * h->h1, hipMemcpyDeviceToDevice, st);
   if (e == hipSuccess) e = hipMemcpyAsync(h->w2, d->w2, sizeof(float) * (size_t)h->h2 * h->h1, hipMemcpyDeviceToDevice, st);
   if (e == hipSuccess) e = hipMemcpyAsync(h->b2, d->b2, sizeof(float) * h->h2, hipMemcpyDeviceToDevice, st);
@@ -297,6 +434,8 @@ int amp_disc_create(const AmpDiscDesc* d, amp_stream_t stream, AmpDisc** out) {
     disc_pad_rows_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(d->w1, h->h1, h->in_dim, h->k1p, h->w1p);
   }
   int rc = launch_status("disc_pad_rows_kernel");
+  if (rc == AMP_OK) rc = f16_kernels_init();
+  if (rc == AMP_OK) rc = f16_refresh(h, st);
   if (rc == AMP_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail(AMP_ERR_HIP, "amp_disc_create: stream sync failed");
   if (rc != AMP_OK) {
     amp_disc_destroy(h);
@@ -318,34 +457,19 @@ int amp_disc_set_scaler(AmpDisc* h, const double* mean, const double* var, float
   }
   int rc = launch_status("disc_scaler_kernel");
   if (rc != AMP_OK) return rc;
+  disc_set_clip_kernel<<<1, 1, 0, (hipStream_t)stream>>>(h->range, clip);
+  rc = launch_status("disc_set_clip_kernel");
+  if (rc != AMP_OK) return rc;
   h->clip = clip;
   h->has_scaler = true;
   return AMP_OK;
 }
 
-int amp_disc_set_precision(AmpDisc* h, int32_t bf16_planes, amp_stream_t stream) {
+int amp_disc_set_precision(AmpDisc* h, int32_t mode, amp_stream_t stream) {
+  (void)stream;
   AMP_REQUIRE(h, "amp_disc_set_precision: null handle");
-  AMP_REQUIRE(bf16_planes == 0 || bf16_planes == 2 || bf16_planes == 3,
-              "amp_disc_set_precision: planes must be 0 (native fp32), 2 (bf16x3) or 3 (bf16x6)");
-  (void)hipFree(h->w1s);
-  (void)hipFree(h->w2s);
-  h->w1s = h->w2s = nullptr;
-  h->planes = 0;
-  if (bf16_planes == 0) return AMP_OK;
-  hipStream_t st = (hipStream_t)stream;
-  const int64_t n1 = (int64_t)h->h1 * h->k1p, n2 = (int64_t)h->h2 * h->h1;
-  AMP_HIP(hipMalloc(&h->w1s, sizeof(__bf16) * n1 * bf16_planes));
-  AMP_HIP(hipMalloc(&h->w2s, sizeof(__bf16) * n2 * bf16_planes));
-  {
-    amp::TraceScope trace__("disc_split_rows_kernel", st);
-    disc_split_rows_kernel<<<(unsigned)((n1 / 4 + kBlock - 1) / kBlock), kBlock, 0, st>>>(h->w1p, h->k1p, h->h1, h->k1p, h->k1p, nullptr,
-                                                                                        nullptr, 0.0f, bf16_planes, h->w1s, n1, nullptr, nullptr);
-    disc_split_rows_kernel<<<(unsigned)((n2 / 4 + kBlock - 1) / kBlock), kBlock, 0, st>>>(h->w2, h->h1, h->h2, h->h1, h->h1, nullptr,
-                                                                                        nullptr, 0.0f, bf16_planes, h->w2s, n2, nullptr, nullptr);
-  }
-  int rc = launch_status("disc_split_rows_kernel");
-  if (rc != AMP_OK) return rc;
-  h->planes = bf16_planes;
+  AMP_REQUIRE(mode == AMP_DISC_F16X3 || mode == AMP_DISC_FP32, "amp_disc_set_precision: mode must be AMP_DISC_F16X3 (0) or AMP_DISC_FP32 (1)");
+  h->mode = mode;
   return AMP_OK;
 }
 
@@ -363,15 +487,29 @@ int amp_disc_get_weights(const AmpDisc* h, float* w1, float* b1, float* w2, floa
   return AMP_OK;
 }
 
+namespace amp {
+// workspace: [header][Xs: fp32 [rows, k1p] or planes [2][rows, k1h]][H1: fp32 or planes, 4 B / element][partial][task]
+struct DiscWorkspace {
+  float* header; void* xs; void* h1; float* partial; float* task_copy; int64_t bytes;
+};
+static DiscWorkspace disc_workspace(const AmpDisc* h, int64_t rows, void* base) {
+  DiscWorkspace w;
+  char* p = (char*)base;
+  w.header = (float*)p; p += kWsHeader;
+  w.xs = p; p += round_up(4 * rows * (h->k1h > h->k1p ? h->k1h : h->k1p), 256);
+  w.h1 = p; p += round_up(4 * rows * h->h1, 256);
+  w.partial = (float*)p; p += round_up((int64_t)sizeof(float) * rows * (h->h2 / 64), 256);
+  w.task_copy = (float*)p; p += round_up((int64_t)sizeof(float) * rows, 256);
+  w.bytes = p - (char*)base;
+  return w;
+}
+// the clamp bounds the scaled input only when a scaler with a finite positive clamp is set
+static bool static_bound(const AmpDisc* h) { return h->has_scaler && h->clip > 0.0f && h->clip < 1e30f; }
+}  // namespace amp
+
 int64_t amp_disc_workspace_bytes(const AmpDisc* h, int64_t rows) {
   if (!h || rows < 0) return -1;
-  // fp32 path: Xs, H1 as fp32; split path: 3 bf16 planes each (the same offsets are used by both)
-  const int64_t elt = h->planes ? 6 : 4;
-  const int64_t xs_bytes = round_up(elt * rows * h->k1p, 256);
-  const int64_t h1_bytes = round_up(elt * rows * h->h1, 256);
-  const int64_t part_bytes = round_up((int64_t)sizeof(float) * rows * (h->h2 / 64), 256);
-  const int64_t task_bytes = round_up((int64_t)sizeof(float) * rows, 256);
-  return xs_bytes + h1_bytes + part_bytes + task_bytes;
+  return disc_workspace(h, rows, nullptr).bytes;
 }
 
 int amp_disc_style_reward(const AmpDisc* h, const float* x, int64_t rows, int64_t row_stride, float scale, const float* task,
@@ -385,78 +523,89 @@ int amp_disc_style_reward(const AmpDisc* h, const float* x, int64_t rows, int64_
   AMP_REQUIRE((uintptr_t)workspace % 16 == 0, "amp_disc_style_reward: workspace must be 16-byte aligned");
   AMP_REQUIRE(rows <= ((int64_t)1 << 30), "amp_disc_style_reward: too many rows");
   hipStream_t st = (hipStream_t)stream;
-  const int64_t elt = h->planes ? 6 : 4;
-  float* Xs = (float*)workspace;
-  float* H1 = (float*)((char*)Xs + round_up(elt * rows * h->k1p, 256));
-  float* partial = (float*)((char*)H1 + round_up(elt * rows * h->h1, 256));
-  float* task_copy = (float*)((char*)partial + round_up((int64_t)sizeof(float) * rows * (h->h2 / 64), 256));
-  if (h->planes) {
-    // split-precision path: scaler + split into bf16 planes in one pass (also snapshots the task reward)
-    __bf16* Xp = (__bf16*)Xs;
-    __bf16* H1p = (__bf16*)H1;
-    {
-      const int64_t quads = rows * (h->k1p / 4);
-      amp::TraceScope trace__("disc_split_rows_kernel", st);
-      disc_split_rows_kernel<<<(unsigned)((quads + kBlock - 1) / kBlock), kBlock, 0, st>>>(
-          x, row_stride, rows, h->in_dim, h->k1p, h->has_scaler ? h->mean : nullptr, h->den, h->clip, h->planes, Xp,
-          rows * h->k1p, task, task_copy);
+  const DiscWorkspace ws = disc_workspace(h, rows, workspace);
+  const float* mean = h->has_scaler ? h->mean : nullptr;
+  if (h->mode == AMP_DISC_F16X3) {
+    const float* amax = nullptr;
+    if (!static_bound(h)) {  // no clamp: the bound of the scaled input is its abs-max (one extra pass)
+      AMP_HIP(hipMemsetAsync(ws.header, 0, sizeof(float), st));
+      amp::TraceScope trace__("disc_absmax_kernel", st);
+      disc_absmax_kernel<<<1024, kBlock, 0, st>>>(x, row_stride, rows, h->in_dim, mean, h->den, h->clip, (unsigned*)ws.header);
+      amax = ws.header;
     }
-    int rcs = launch_status("disc_split_rows_kernel");
+    {
+      const int64_t octs = rows * (h->k1h / 8);
+      amp::TraceScope trace__("disc_scale_split_kernel", st);
+      disc_scale_split_kernel<<<(unsigned)((octs + kBlock - 1) / kBlock), kBlock, 0, st>>>(
+          x, row_stride, rows, h->in_dim, h->k1h, mean, h->den, h->clip, h->range, amax, (_Float16*)ws.xs, task, ws.task_copy);
+    }
+    int rcs = launch_status("disc_scale_split_kernel");
     if (rcs != AMP_OK) return rcs;
     if (inputs_consumed) AMP_HIP(hipEventRecord((hipEvent_t)inputs_consumed, st));
-    return disc_forward_split(h, Xp, rows, H1p, partial, scale, task ? task_copy : nullptr, task_w, style_w, logits, style,
-                              combined, st);
+    return disc_forward_f16(h, (const _Float16*)ws.xs, amax, rows, (_Float16*)ws.h1, ws.partial, scale, task ? ws.task_copy : nullptr,
+                            task_w, style_w, logits, style, combined, st);
   }
+  float* Xs = (float*)ws.xs;
   {
     const int64_t quads = rows * (h->k1p / 4);
     amp::TraceScope trace__("disc_scale_pad_kernel", st);
-    disc_scale_pad_kernel<<<(unsigned)((quads + kBlock - 1) / kBlock), kBlock, 0, st>>>(
-        x, row_stride, rows, h->in_dim, h->k1p, h->has_scaler ? h->mean : nullptr, h->den, h->clip, Xs, task, task_copy);
+    disc_scale_pad_kernel<<<(unsigned)((quads + kBlock - 1) / kBlock), kBlock, 0, st>>>(x, row_stride, rows, h->in_dim, h->k1p, mean,
+                                                                                      h->den, h->clip, Xs, task, ws.task_copy);
   }
   int rc = launch_status("disc_scale_pad_kernel");
   if (rc != AMP_OK) return rc;
   // everything the caller handed in (amp_obs, task reward) has been consumed once this point of the stream is reached
   if (inputs_consumed) AMP_HIP(hipEventRecord((hipEvent_t)inputs_consumed, st));
-
-  return disc_forward(h, Xs, rows, H1, partial, scale, task ? task_copy : nullptr, task_w, style_w, logits, style, combined, st);
+  return disc_forward(h, Xs, rows, (float*)ws.h1, ws.partial, scale, task ? ws.task_copy : nullptr, task_w, style_w, logits, style,
+                      combined, st);
 }
 
-int amp_disc_input_layout(const AmpDisc* h, int32_t* padded_dim, const float** mean, const float** den, float* clip) {
-  AMP_REQUIRE(h, "amp_disc_input_layout: null handle");
-  if (padded_dim) *padded_dim = h->k1p;
-  if (mean) *mean = h->has_scaler ? h->mean : nullptr;
-  if (den) *den = h->den;
-  if (clip) *clip = h->clip;
+int amp_disc_input_layout(const AmpDisc* h, AmpDiscInputLayout* out) {
+  AMP_REQUIRE(h && out, "amp_disc_input_layout: null argument");
+  const bool planes = h->mode == AMP_DISC_F16X3 && static_bound(h);
+  out->format = planes ? AMP_DISC_INPUT_F16_PLANES : AMP_DISC_INPUT_F32_ROWS;
+  out->padded_dim = planes ? h->k1h : h->k1p;
+  out->mean_dev = h->has_scaler ? h->mean : nullptr;
+  out->den_dev = h->den;
+  out->clip = h->clip;
+  out->plane_scale = planes ? plane_scale(h->clip) : 1.0f;
   return AMP_OK;
 }
 
-int amp_disc_style_reward_prescaled(const AmpDisc* h, const float* xs, int64_t rows, float scale, const float* task, float task_w,
+int amp_disc_style_reward_prescaled(const AmpDisc* h, const void* xs_any, int64_t rows, float scale, const float* task, float task_w,
                                     float style_w, float* logits, float* style, float* combined, void* workspace,
                                     amp_stream_t stream) {
   AMP_REQUIRE(h, "amp_disc_style_reward_prescaled: null handle");
   AMP_REQUIRE(rows >= 0, "amp_disc_style_reward_prescaled: negative rows");
   if (rows == 0) return AMP_OK;
+  const float* xs = (const float*)xs_any;
   AMP_REQUIRE(xs && workspace, "amp_disc_style_reward_prescaled: null buffer");
   AMP_REQUIRE((uintptr_t)xs % 16 == 0 && (uintptr_t)workspace % 16 == 0, "amp_disc_style_reward_prescaled: 16-byte alignment required");
   AMP_REQUIRE(rows <= ((int64_t)1 << 30), "amp_disc_style_reward_prescaled: too many rows");
-  const int64_t elt = h->planes ? 6 : 4;
-  float* H1 = (float*)((char*)workspace + round_up(elt * rows * h->k1p, 256));
-  float* partial = (float*)((char*)H1 + round_up(elt * rows * h->h1, 256));
+  const DiscWorkspace ws = disc_workspace(h, rows, workspace);
   hipStream_t st = (hipStream_t)stream;
-  if (h->planes) {
-    __bf16* Xp = (__bf16*)workspace;
+  if (h->mode == AMP_DISC_F16X3 && static_bound(h))  // fp16 planes at the clamp's plane scale (amp_disc_input_layout)
+    return disc_forward_f16(h, (const _Float16*)xs_any, nullptr, rows, (_Float16*)ws.h1, ws.partial, scale, task, task_w, style_w,
+                            logits, style, combined, st);
+  if (h->mode == AMP_DISC_F16X3) {
+    // fp32 rows with no clamp to bound them: bound them by their abs-max, then split into planes
+    AMP_HIP(hipMemsetAsync(ws.header, 0, sizeof(float), st));
     {
-      const int64_t quads = rows * (h->k1p / 4);
-      amp::TraceScope trace__("disc_split_rows_kernel", st);
-      disc_split_rows_kernel<<<(unsigned)((quads + kBlock - 1) / kBlock), kBlock, 0, st>>>(
-          xs, h->k1p, rows, h->k1p, h->k1p, nullptr, nullptr, 0.0f, h->planes, Xp, rows * h->k1p, nullptr, nullptr);
+      amp::TraceScope trace__("disc_absmax_kernel", st);
+      disc_absmax_kernel<<<1024, kBlock, 0, st>>>(xs, h->k1p, rows, h->in_dim, nullptr, nullptr, 0.0f, (unsigned*)ws.header);
     }
-    int rcs = launch_status("disc_split_rows_kernel");
+    {
+      const int64_t octs = rows * (h->k1h / 8);
+      amp::TraceScope trace__("disc_scale_split_kernel", st);
+      disc_scale_split_kernel<<<(unsigned)((octs + kBlock - 1) / kBlock), kBlock, 0, st>>>(
+          xs, h->k1p, rows, h->in_dim, h->k1h, nullptr, nullptr, 0.0f, h->range, ws.header, (_Float16*)ws.xs, nullptr, nullptr);
+    }
+    int rcs = launch_status("disc_scale_split_kernel");
     if (rcs != AMP_OK) return rcs;
-    return disc_forward_split(h, Xp, rows, (__bf16*)H1, partial, scale, task, task_w, style_w, logits, style, combined, st);
+    return disc_forward_f16(h, (const _Float16*)ws.xs, ws.header, rows, (_Float16*)ws.h1, ws.partial, scale, task, task_w, style_w,
+                            logits, style, combined, st);
   }
-  return disc_forward(h, xs, rows, H1, partial, scale, task, task_w, style_w, logits, style, combined, st);
+  return disc_forward(h, xs, rows, (float*)ws.h1, ws.partial, scale, task, task_w, style_w, logits, style, combined, st);
 }
-
 
 }  // extern "C"

@@ -1,0 +1,301 @@
+// Split-operand GEMM of the discriminator forward: fp32 accuracy out of the fp16 matrix pipe.
+//
+// Every fp32 operand x (activations and weights alike) is carried as two fp16 planes of s*x, s a power of two that
+// brings the tensor's bound to <= 2^15:
+//     p0 = rn16(s x),  p1 = rn16(s x - p0)        (s x - p0 is exact in fp32)   =>   |s x - p0 - p1| <= 2^-23 |s x|
+// for every element within 2^18 of the bound (smaller ones keep an ABSOLUTE error <= 2^-25, i.e. 2^-40 of the bound:
+// fp16 subnormals are honoured by the gfx950 MFMA).  A product then needs three v_mfma_f32_32x32x16_f16 into ONE fp32
+// accumulator -- fp16 x fp16 products are exact in it --
+//     acc += a0 b0 + a0 b1 + a1 b0            a.b = acc / (s_a s_b)
+// and drops only a1 b1 (2^-22 relative): 96 MFMA cycles per 32x32x16 block instead of the 512 of eight
+// v_mfma_f32_32x32x2_f32, at a measured error no larger than the fp32 fma chain's (tests/test_gpu_disc.py).
+// In GEMM terms it is a plain fp16 product over the concatenated reduction [a0 | a0 | a1] . [b0 | b1 | b0] that
+// stages only two planes per operand.
+//
+//   MODE 0: H = relu(A W^T / (s_a s_w) + bias), written as the two fp16 planes of s_h H (the next layer's operand)
+//   MODE 1: partial[m, nt] = sum over the tile's columns of relu(A W^T / (s_a s_w) + bias)[m, n] * w3[n]
+//
+// Tile: (64 TM) x (64 TN) x BK, 4 waves as 2 x 2, each wave TM x TN accumulator blocks.  The MFMA's first operand is
+// the WEIGHT fragment, so the accumulators hold the transposed tile (registers = output columns n, lanes =
+// activation rows m): bias / w3 are per-register constants and the 512 -> 1 layer is a per-lane sum.
+// One LDS stage (rows padded by 8 halves: conflict-free ds_read_b128), register prefetch of the next k-tile pinned
+// above the MFMAs, raw lgkmcnt-only barriers -- the recipe the fp32 kernel (disc_gemm.hpp) arrived at.
+#pragma once
+#include "amp_common.hpp"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float fx16 __attribute__((ext_vector_type(16)));
+typedef float fv4 __attribute__((ext_vector_type(4)));
+
+namespace amp {
+
+// Range record of the discriminator (device resident; disc.hip fills it whenever weights or scaler change).
+struct DiscRange {
+  float s_w1, s_w2;    // power-of-two plane scales of W1 / W2
+  float wsum1, bmax1;  // max_j sum_k |W1[j, k]|, max_j |b1[j]|: |H1| <= wsum1 * bound_x + bmax1
+  float clip;          // static bound of the scaled input (the scaler's clamp)
+  float pad[3];
+};
+
+// largest power of two s with s * bound < 2^15 (fp16 tops out at 65504)
+__host__ __device__ __forceinline__ float plane_scale(float bound) {
+  if (!(bound > 0.0f)) return 1.0f;
+  int e;
+  (void)frexpf(bound, &e);  // bound = m 2^e, m in [0.5, 1)
+  return ldexpf(1.0f, 15 - e);
+}
+
+// Per-layer scales, recomputed by every workgroup from the range record (a handful of scalar ops; keeps the forward
+// free of per-call state in the handle): layer 1 consumes planes of s_x Xs and s_w1 W1 and emits planes of s_h H1,
+// layer 2 consumes those and s_w2 W2.  bound_x = the dynamic abs-max when `amax` is given, else the clamp.
+struct LayerScales { float descale, s_out; };
+__device__ __forceinline__ LayerScales layer_scales(const DiscRange* r, const float* amax, int layer) {
+  const float bx = amax ? amax[0] : r->clip;
+  const float s_h = plane_scale(r->wsum1 * bx + r->bmax1);
+  LayerScales o;
+  if (layer == 1) {
+    o.descale = 1.0f / (plane_scale(bx) * r->s_w1);
+    o.s_out = s_h;
+  } else {
+    o.descale = 1.0f / (s_h * r->s_w2);
+    o.s_out = 0.0f;
+  }
+  return o;
+}
+
+struct GemmF16Args {
+  const _Float16* A; int64_t lda, plane_a; int64_t M;           // activation planes: A + p * plane_a, rows of lda halves
+  const _Float16* W; int64_t plane_w; int32_t Kp; int32_t N;    // weight planes [N, Kp]
+  const float* bias;
+  const DiscRange* range; const float* amax; int32_t layer;     // -> layer_scales()
+  _Float16* H; int64_t ldh, plane_h;                            // mode 0 output planes
+  const float* w3; float* partial;                              // mode 1 output [M, n_tiles]
+  int32_t n_tiles, m_tiles;
+};
+
+// rn16(v), rn16(v - rn16(v)) for four values
+__device__ __forceinline__ void split_planes4(const fv4 v, h4& p0, h4& p1) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const _Float16 a = (_Float16)v[i];
+    p0[i] = a;
+    p1[i] = (_Float16)(v[i] - (float)a);
+  }
+}
+
+// planes of scale[0] * src[rows, cols] (row pitch ld_src floats) -> dst + p * plane, rows of ld_dst halves; columns in
+// [cols, ld_dst) are zero.  One thread per four columns.
+__global__ __launch_bounds__(kBlock) void split_rows_f16_kernel(const float* __restrict__ src, int64_t rows, int cols,
+                                                                int64_t ld_src, const float* __restrict__ scale,
+                                                                _Float16* __restrict__ dst, int64_t ld_dst, int64_t plane) {
+  const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x, per_row = ld_dst / 4;
+  if (q >= rows * per_row) return;
+  const int64_t r = q / per_row;
+  const int c = (int)(q - r * per_row) * 4;
+  const float s = scale[0];
+  fv4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = c + i < cols ? src[r * ld_src + c + i] * s : 0.0f;
+  h4 p0, p1;
+  split_planes4(v, p0, p1);
+  *reinterpret_cast<h4*>(&dst[r * ld_dst + c]) = p0;
+  *reinterpret_cast<h4*>(&dst[plane + r * ld_dst + c]) = p1;
+}
+
+__device__ __forceinline__ bool f16_tile_of_block(const GemmF16Args& g, int& mt, int& nt) {
+  const int total = g.m_tiles * g.n_tiles;
+  const int per_xcd = (total + 7) / 8;
+  const int v = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);  // one XCD (one L2) owns a run of row tiles
+  if (v >= total) return false;
+  mt = v / g.n_tiles;
+  nt = v - mt * g.n_tiles;
+  return true;
+}
+
+__device__ __forceinline__ void f16_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int BM, int BN, int BK>
+struct StageF16 {
+  static constexpr int LDK = BK + 8;                // halves per LDS row
+  static constexpr int CPR = BK / 8;                // 16-B chunks per row
+  static constexpr int CA = BM * CPR / kBlock;      // chunks per thread per plane
+  static constexpr int CB = BN * CPR / kBlock;
+  static constexpr int RPP = kBlock / CPR;          // rows per pass
+  h8 a[2][CA], b[2][CB];
+  __device__ __forceinline__ void load(const GemmF16Args& g, int64_t m0, int n0, int kt, int tid) {
+    const int kc = tid % CPR, r = tid / CPR;
+    const _Float16* w = g.W + (int64_t)(n0 + r) * g.Kp + kt * BK + 8 * kc;
+    const int64_t last = g.M - 1;  // rows past M re-read the last row; their results are never stored
+    const _Float16* x = g.A + kt * BK + 8 * kc;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+      for (int i = 0; i < CB; ++i) b[p][i] = *reinterpret_cast<const h8*>(w + p * g.plane_w + (int64_t)i * RPP * g.Kp);
+#pragma unroll
+      for (int i = 0; i < CA; ++i) {
+        const int64_t m = m0 + r + RPP * i;
+        a[p][i] = *reinterpret_cast<const h8*>(x + p * g.plane_a + (m < last ? m : last) * g.lda);
+      }
+    }
+  }
+  // LDS: [A p0][A p1][B p0][B p1], each rows x LDK
+  __device__ __forceinline__ void store(_Float16* s, int tid) const {
+    const int kc = tid % CPR, r = tid / CPR;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+      for (int i = 0; i < CA; ++i) *reinterpret_cast<h8*>(&s[p * BM * LDK + (r + RPP * i) * LDK + 8 * kc]) = a[p][i];
+#pragma unroll
+      for (int i = 0; i < CB; ++i)
+        *reinterpret_cast<h8*>(&s[2 * BM * LDK + p * BN * LDK + (r + RPP * i) * LDK + 8 * kc]) = b[p][i];
+    }
+  }
+};
+
+template <int TM, int TN, int BK, int MODE, int MINW>
+__global__ __launch_bounds__(kBlock, MINW) void disc_gemm_f16_kernel(GemmF16Args g) {
+  constexpr int BM = 64 * TM, BN = 64 * TN, LDK = BK + 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  _Float16* smem = reinterpret_cast<_Float16*>(smem_raw);
+  int mt, nt;
+  if (!f16_tile_of_block(g, mt, nt)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int64_t m0 = (int64_t)mt * BM;
+  const int n0 = nt * BN;
+  const int nk = g.Kp / BK;
+
+  fx16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  const _Float16* xa = smem + (wm * TM * 32 + li) * LDK + 8 * lh;                 // activation fragments, plane 0
+  const _Float16* wb = smem + 2 * BM * LDK + (wn * TN * 32 + li) * LDK + 8 * lh;  // weight fragments, plane 0
+  StageF16<BM, BN, BK> stg;
+  stg.load(g, m0, n0, 0, tid);
+  stg.store(smem, tid);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) stg.load(g, m0, n0, kt + 1, tid);  // in flight under this tile's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      h8 x0[TM], x1[TM], w0[TN], w1[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        x0[a] = *reinterpret_cast<const h8*>(xa + a * 32 * LDK + 16 * s);
+        x1[a] = *reinterpret_cast<const h8*>(xa + BM * LDK + a * 32 * LDK + 16 * s);
+      }
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        w0[b] = *reinterpret_cast<const h8*>(wb + b * 32 * LDK + 16 * s);
+        w1[b] = *reinterpret_cast<const h8*>(wb + BN * LDK + b * 32 * LDK + 16 * s);
+      }
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[b], x1[a], acc[a][b], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[b], x0[a], acc[a][b], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[b], x0[a], acc[a][b], 0, 0, 0);
+    }
+    f16_lds_barrier();
+    if (kt + 1 < nk) {
+      stg.store(smem, tid);
+      f16_lds_barrier();
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue: register r of lane half lh is output column (r & 3) + 8 (r >> 2) + 4 lh of the block, lane li is
+  //      activation row li
+  const LayerScales sc = layer_scales(g.range, g.amax, g.layer);
+  const float descale = sc.descale;
+  const fv4* bias4 = reinterpret_cast<const fv4*>(g.bias + n0 + wn * (TN * 32) + 4 * lh);
+  if (MODE == 0) {
+    // relu(. + bias) -> planes of s_h H, transposed through LDS per 32-row slab so that a lane stores 16 B and a
+    // quarter wave covers one contiguous row segment of each plane
+    constexpr int W = TN * 32, EPL = W + 8, CPRO = W / 8;  // slab width, padded row (halves), 16-B chunks per row
+    const float s_h = sc.s_out;
+    _Float16* ep = smem + wave * (2 * 32 * EPL);
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+          const fv4 bs = bias4[b * 8 + grp * 2];
+          fv4 v;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            v[i] = fmaxf(acc[a][b][4 * grp + i] * descale + bs[i], 0.0f) * s_h;
+          h4 p0, p1;
+          split_planes4(v, p0, p1);
+          const int col = b * 32 + 8 * grp + 4 * lh;
+          *reinterpret_cast<h4*>(&ep[li * EPL + col]) = p0;
+          *reinterpret_cast<h4*>(&ep[32 * EPL + li * EPL + col]) = p1;
+        }
+      // the slab is private to this wave and a wave's LDS operations execute in order: no workgroup barrier
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int i = 0; i < (2 * 32 * CPRO) / 64; ++i) {
+        const int idx = lane + 64 * i, p = idx / (32 * CPRO), row = (idx / CPRO) % 32, q = idx % CPRO;
+        const h8 v = *reinterpret_cast<const h8*>(&ep[p * 32 * EPL + row * EPL + 8 * q]);
+        const int64_t grow = m0 + wm * (TM * 32) + a * 32 + row;
+        if (grow < g.M) *reinterpret_cast<h8*>(&g.H[p * g.plane_h + grow * g.ldh + n0 + wn * W + 8 * q]) = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  } else {
+    float* red = reinterpret_cast<float*>(smem);  // [2][BM]
+    const fv4* w34 = reinterpret_cast<const fv4*>(g.w3 + n0 + wn * (TN * 32) + 4 * lh);
+    float sum[TM];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) sum[a] = 0.0f;
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int grp = 0; grp < 4; ++grp) {
+        const fv4 bs = bias4[b * 8 + grp * 2], ws = w34[b * 8 + grp * 2];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            sum[a] += fmaxf(acc[a][b][4 * grp + i] * descale + bs[i], 0.0f) * ws[i];
+      }
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const float v = sum[a] + __shfl_xor(sum[a], 32, 64);  // the other lane half holds the other columns
+      if (lh == 0) red[wn * BM + wm * (TM * 32) + a * 32 + li] = v;
+    }
+    __syncthreads();
+    if (tid < BM) {
+      const int64_t row = m0 + tid;
+      if (row < g.M) g.partial[row * g.n_tiles + nt] = red[tid] + red[BM + tid];
+    }
+  }
+}
+
+template <int TM, int TN, int BK>
+constexpr int gemm_f16_lds_bytes() {
+  constexpr int stage = 2 * (64 * TM + 64 * TN) * (BK + 8) * 2;
+  constexpr int ep = 4 * 2 * 32 * (TN * 32 + 8) * 2;
+  return stage > ep ? stage : ep;
+}
+
+}  // namespace amp

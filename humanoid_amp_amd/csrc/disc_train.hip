@@ -14,7 +14,6 @@
 #include "disc_gemm.hpp"
 
 struct AmpDisc;  // defined in disc.hip; accessed through the accessors below
-extern "C" int amp_disc_input_layout(const AmpDisc* h, int32_t* padded_dim, const float** mean, const float** den, float* clip);
 
 namespace amp {
 // accessors implemented in disc.hip
@@ -506,8 +505,9 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
       // the fp32 vectors live in the discriminator handle: refresh them there so inference sees the same scaler
       rc = amp_disc_set_scaler(t->disc, t->mean64, t->var64, c.scaler_epsilon, c.scaler_clip, stream);
       if (rc != AMP_OK) return rc;
-      int32_t kp;
-      amp_disc_input_layout(t->disc, &kp, &mean32, &den32, &clip);
+      AmpDiscInputLayout lay;
+      amp_disc_input_layout(t->disc, &lay);
+      mean32 = lay.mean_dev; den32 = lay.den_dev; clip = lay.clip;
     }
     scale_rows_kernel<<<blocks(B * k1p), kBlock, 0, st>>>(groups[gi], row_stride, B, p.in_dim, k1p, mean32, den32, clip,
                                                          Xs + gi * B * k1p);

@@ -190,21 +190,33 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(EnvPlan p, AmpSimState
     const int count = n_tile * D;
     const float inv_d = 1.0f / (float)D;
     constexpr int U = 4;  // independent columns per lane per trip: their loads are issued before any store
-    // optional fused discriminator input: the same values, scaled, into disc_input [N, stride]
-    float* const xs = bf.disc_input ? bf.disc_input + tile_base * bf.disc_input_stride : nullptr;
+    // optional fused discriminator input: the same values, scaled, into disc_input (fp32 rows or fp16 planes)
+    const bool planes = bf.disc_input_format == AMP_DISC_INPUT_F16_PLANES;
+    const bool fused = bf.disc_input != nullptr;
+    float* const xs = reinterpret_cast<float*>(bf.disc_input) + (planes ? 0 : tile_base * bf.disc_input_stride);
+    _Float16* const xh = reinterpret_cast<_Float16*>(bf.disc_input) + (planes ? tile_base * bf.disc_input_stride : 0);
+    const int64_t plane = bf.disc_input_plane;
+    const float s_x = bf.disc_plane_scale;
     const float* const mu = bf.scaler_mean;
     const float* const dn = bf.scaler_den;
     const float clip = bf.scaler_clip;
-    auto scaled = [&](float v, int c) {
+    auto emit = [&](int64_t off, float v, int c) {  // same operations, in the same order, as disc.hip's scaler passes
       if (mu) {
         v = (v - mu[c]) / dn[c];  // skrl RunningStandardScaler, exact fp32 divide
         v = fminf(fmaxf(v, -clip), clip);
       }
-      return v;
+      if (planes) {
+        v *= s_x;
+        const _Float16 a = (_Float16)v;
+        xh[off] = a;
+        xh[plane + off] = (_Float16)(v - (float)a);
+      } else {
+        xs[off] = v;
+      }
     };
     for (int e0 = tid; e0 < count; e0 += U * kBlock) {
       float* col[U];
-      float* xcol[U];
+      int64_t xoff[U];
       int jc[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -213,7 +225,7 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(EnvPlan p, AmpSimState
         const int s = (int)(((float)e + 0.5f) * inv_d);  // exact: e < 64 * D
         jc[u] = e - s * D;
         col[u] = buf + s * rowK + jc[u];
-        xcol[u] = xs ? xs + s * bf.disc_input_stride + jc[u] : nullptr;
+        xoff[u] = s * bf.disc_input_stride + jc[u];
       }
       for (int hi = K - 2; hi >= 0; hi -= 2) {
         float h[U][2];
@@ -228,7 +240,7 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(EnvPlan p, AmpSimState
           for (int i = 0; i < 2; ++i)
             if (hi - i >= 0 && e0 + u * kBlock < count) {
               col[u][(int64_t)(hi - i + 1) * D] = h[u][i];
-              if (xs) xcol[u][(hi - i + 1) * D] = scaled(h[u][i], (hi - i + 1) * D + jc[u]);
+              if (fused) emit(xoff[u] + (hi - i + 1) * D, h[u][i], (hi - i + 1) * D + jc[u]);
             }
       }
 #pragma unroll
@@ -236,7 +248,7 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(EnvPlan p, AmpSimState
         if (e0 + u * kBlock < count) {
           const float v = s_obs[e0 + u * kBlock];
           col[u][0] = v;
-          if (xs) xcol[u][0] = scaled(v, jc[u]);
+          if (fused) emit(xoff[u], v, jc[u]);
         }
     }
     // policy observation (g1_amp_env.py:195-242; humanoid_amp_env.py:126)
@@ -389,6 +401,10 @@ int amp_env_step(const AmpEnvCfg* cfg, const AmpSimState* st, const AmpEnvBuffer
     for (int k = 0; k < p.n_key; ++k) AMP_REQUIRE(st->key_body[k] >= 0, "amp_env_step(obs): negative key body index");
     AMP_REQUIRE(!bf->disc_input || bf->disc_input_stride >= (int64_t)p.K * p.D, "amp_env_step(obs): disc_input_stride too small");
     AMP_REQUIRE(!bf->disc_input || !bf->scaler_mean || bf->scaler_den, "amp_env_step(obs): scaler_den is null");
+    AMP_REQUIRE(!bf->disc_input || bf->disc_input_format == AMP_DISC_INPUT_F32_ROWS ||
+                    (bf->disc_input_format == AMP_DISC_INPUT_F16_PLANES && bf->disc_plane_scale > 0.0f &&
+                     bf->disc_input_plane >= N * bf->disc_input_stride),
+                "amp_env_step(obs): bad disc_input format / plane scale / plane stride");
   }
   const bool per_env_limits = g1_rew && st->soft_limits_stride != 0;
   const int tile = amp_env_step_tile_envs(N);

@@ -107,18 +107,22 @@ class EnvStepKernel:
             self.actor_obs_history_buffer, self.just_reset_mask = None, None
         self.reset_ids = torch.zeros(N, dtype=torch.int64, device=dev)
         self.reset_count = torch.zeros(1, dtype=torch.int64, device=dev)
-        self.disc_input, self._scaler = None, (None, None, 0.0)
+        self.disc_input, self._disc_layout = None, None
 
     def attach_discriminator(self, disc: "AmpDiscriminator") -> torch.Tensor:
         """Fuse ``disc``'s input scaler into the OBS phase: every OBS launch also writes the scaled, zero-padded
-        discriminator input ``disc_input [N, padded_dim]`` (feed it to ``disc.style_reward_prescaled``), which saves
-        the separate scaler pass over ``amp_obs``.  Call again after ``disc.set_scaler`` / ``set_weights``."""
-        padded, mean, den, clip = disc.input_layout()
-        if padded < self.cfg.num_amp_observations * self.cfg.amp_frame_size:
+        discriminator input in the layout the discriminator's GEMMs consume -- ``disc_input`` float32 ``[N, padded]``
+        or float16 planes ``[2, N, padded]`` (feed it to ``disc.style_reward_prescaled``) -- which saves the separate
+        scaler pass over ``amp_obs``.  Call again after ``disc.set_scaler`` / ``set_weights``."""
+        lay = disc.input_layout()
+        if lay.padded_dim < self.cfg.num_amp_observations * self.cfg.amp_frame_size:
             raise nat.AmpEngineError("discriminator input is narrower than K * D")
-        if self.disc_input is None or self.disc_input.shape[1] != padded:
-            self.disc_input = torch.zeros((self.num_envs, padded), device=self.device)  # padding columns stay zero
-        self._scaler = (mean, den, clip)
+        planes = lay.format == nat.AMP_DISC_INPUT_F16_PLANES
+        shape = (2, self.num_envs, lay.padded_dim) if planes else (self.num_envs, lay.padded_dim)
+        dtype = torch.float16 if planes else torch.float32
+        if self.disc_input is None or tuple(self.disc_input.shape) != shape or self.disc_input.dtype != dtype:
+            self.disc_input = torch.zeros(shape, dtype=dtype, device=self.device)  # padding columns stay zero
+        self._disc_layout = lay
         return self.disc_input
 
     def _buffers(self) -> nat.AmpEnvBuffers:
@@ -130,8 +134,11 @@ class EnvStepKernel:
         b.died, b.time_out, b.reset_mask = p(self.died), p(self.time_out), p(self.reset_mask)
         b.reset_tile_counts = p(self.reset_tile_counts)
         if self.disc_input is not None:
-            b.disc_input, b.disc_input_stride = self.disc_input.data_ptr(), int(self.disc_input.stride(0))
-            b.scaler_mean, b.scaler_den, b.scaler_clip = self._scaler
+            lay = self._disc_layout
+            b.disc_input, b.disc_input_stride = self.disc_input.data_ptr(), int(self.disc_input.stride(-2))
+            b.disc_input_format, b.disc_plane_scale = lay.format, lay.plane_scale
+            b.disc_input_plane = int(self.disc_input.stride(0)) if self.disc_input.dim() == 3 else 0
+            b.scaler_mean, b.scaler_den, b.scaler_clip = lay.mean_dev, lay.den_dev, lay.clip
         return b
 
     def launch(self, phases: int, *, joint_pos=None, joint_vel=None, joint_acc=None, actions=None, root_pos=None,
@@ -228,11 +235,12 @@ class AmpDiscriminator:
     def __init__(self, weights: Sequence, device, *, running_mean: Optional[torch.Tensor] = None,
                  running_variance: Optional[torch.Tensor] = None, epsilon: float = 1e-8, clip_threshold: float = 5.0,
                  discriminator_reward_scale: float = 2.0, task_reward_weight: float = 0.0, style_reward_weight: float = 1.0,
-                 precision: str = "f32"):
-        """``precision``: "f32" (native fp32 MFMA, default), "bf16x6" (split precision, fp32-level accuracy, ~2.7x
-        faster GEMMs) or "bf16x3" (~1e-5 * |logit| accuracy, ~5x); opt-in, see csrc/disc_gemm_split.hpp."""
+                 precision: str = "f16x3"):
+        """``precision`` selects the GEMM engine; both deliver fp32-class accuracy (<= 1e-6 on O(1) logits):
+        "f16x3" (default: fp32 operands as two fp16 planes, three fp16 MFMAs per k-step into one fp32 accumulator,
+        csrc/disc_gemm_f16.hpp) or "f32" (fp32 MFMA on fp32 operands: exact fma chain, ~2.7x slower)."""
         self.device = nat.require_gpu(device)
-        self._planes = {"f32": 0, "bf16x3": 2, "bf16x6": 3}[precision]
+        self._mode = {"f16x3": nat.AMP_DISC_F16X3, "f32": nat.AMP_DISC_FP32}[precision]
         self.precision = precision
         self._lib = nat.load()
         self._handle = None
@@ -265,10 +273,8 @@ class AmpDiscriminator:
         self._destroy()
         self._handle = h
         self.in_dim, self._h1, self._h2 = d.in_dim, d.h1, d.h2
-        if self._planes:
-            with torch.cuda.device(self.device):
-                nat.check(self._lib.amp_disc_set_precision(h, self._planes, nat.stream_ptr()), "amp_disc_set_precision")
-            self._ws = None  # workspace size depends on the precision
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.amp_disc_set_precision(h, self._mode, nat.stream_ptr()), "amp_disc_set_precision")
 
     def set_scaler(self, running_mean: torch.Tensor, running_variance: torch.Tensor) -> None:
         """RunningStandardScaler statistics (kept in float64 like skrl does)."""
@@ -325,22 +331,26 @@ class AmpDiscriminator:
             out["logits"] = logits
         return out
 
-    def input_layout(self):
-        """(padded_dim, mean_ptr, den_ptr, clip): layout of the scaled input the GEMMs consume (device pointers owned
-        by the handle; mean_ptr is None when no scaler is set)."""
-        padded, mean, den, clip = C.c_int32(), C.c_void_p(), C.c_void_p(), C.c_float()
-        nat.check(self._lib.amp_disc_input_layout(self._handle, C.byref(padded), C.byref(mean), C.byref(den), C.byref(clip)),
-                  "amp_disc_input_layout")
-        return int(padded.value), mean.value, den.value, float(clip.value)
+    def input_layout(self) -> nat.AmpDiscInputLayout:
+        """Layout of the scaled input the GEMMs consume (``format``: fp32 rows or fp16 planes, ``padded_dim``, the
+        handle's fp32 scaler vectors as device pointers, ``clip``, ``plane_scale``)."""
+        lay = nat.AmpDiscInputLayout()
+        nat.check(self._lib.amp_disc_input_layout(self._handle, C.byref(lay)), "amp_disc_input_layout")
+        return lay
 
     def style_reward_prescaled(self, scaled: torch.Tensor, task_reward: Optional[torch.Tensor] = None, *,
                                want_logits: bool = False):
-        """Same as :meth:`style_reward` for an already scaled + padded input (``EnvStepKernel.attach_discriminator``)."""
-        padded = self.input_layout()[0]
-        if scaled.dim() != 2 or scaled.shape[1] != padded or scaled.dtype != torch.float32 or not scaled.is_contiguous():
-            raise nat.AmpEngineError(f"scaled input must be a contiguous float32 [M, {padded}] tensor")
+        """Same as :meth:`style_reward` for an input already scaled, padded and laid out as :meth:`input_layout`
+        says (``EnvStepKernel.attach_discriminator``): float32 ``[M, padded]`` or float16 planes ``[2, M, padded]``."""
+        lay = self.input_layout()
+        planes = lay.format == nat.AMP_DISC_INPUT_F16_PLANES
+        want = (torch.float16, 3) if planes else (torch.float32, 2)
+        if scaled.dtype != want[0] or scaled.dim() != want[1] or scaled.shape[-1] != lay.padded_dim or not scaled.is_contiguous() \
+                or (planes and scaled.shape[0] != 2):
+            raise nat.AmpEngineError(f"scaled input must be a contiguous {'float16 [2, M, ' if planes else 'float32 [M, '}"
+                                     f"{lay.padded_dim}] tensor (see input_layout)")
         nat.require_gpu(scaled.device)
-        M = scaled.shape[0]
+        M = scaled.shape[-2]
         f32 = dict(dtype=torch.float32, device=self.device)
         style = torch.empty((M, 1), **f32)
         logits = torch.empty((M, 1), **f32) if want_logits else None

@@ -85,7 +85,7 @@ class HotPath:
     """All device state of one env shard + ``step()`` = one env-step of the hot path."""
 
     def __init__(self, spec: WorkloadSpec, num_envs: int, device, seed: int = 0, log_reward_terms: bool = False,
-                 overlap: bool = False, fused_scaler: bool = True, disc_precision: str = "f32"):
+                 overlap: bool = False, fused_scaler: bool = True, disc_precision: str = "f16x3"):
         """``overlap``: run the discriminator on a second HIP stream so that the HBM-bound kernels of step t+1
         (motion sample, env step, compaction) execute under the MFMA-bound GEMMs of step t.  The style reward is
         consumed asynchronously in AMP (skrl reads it at the agent update), so nothing waits for it inside a step;

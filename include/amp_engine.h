@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define AMP_ABI_VERSION 4
+#define AMP_ABI_VERSION 5
 
 typedef void* amp_stream_t; /* hipStream_t */
 typedef void* amp_event_t;  /* hipEvent_t  */
@@ -197,14 +197,20 @@ typedef struct {
   uint8_t* reset_mask;       /* [N] died | time_out */
   int32_t* reset_tile_counts; /* optional [ceil(N / amp_env_step_tile_envs(N))]: reset envs per tile (feeds amp_reset_compact_tiles) */
   /* Optional fusion of the discriminator's input scaler into the OBS phase (saves one pass over amp_obs):
-   * disc_input [N, disc_input_stride] receives clamp((amp_obs - mean) / den, -clip, clip) for the K*D columns (the
-   * padding columns are never written: zero them once).  mean / den / clip / stride come from amp_disc_input_layout();
-   * scaler_mean == NULL copies unscaled.  Feed the result to amp_disc_style_reward_prescaled(). */
-  float* disc_input;
+   * disc_input receives v = clamp((amp_obs - mean) / den, -clip, clip) for the K*D columns in the layout
+   * amp_disc_input_layout() reports (every field below comes from it; scaler_mean == NULL copies unscaled):
+   *   AMP_DISC_INPUT_F32_ROWS    float  [N, disc_input_stride]                       <- v
+   *   AMP_DISC_INPUT_F16_PLANES  _Float16 [2][N, disc_input_stride], plane p at + p * disc_input_plane halves
+   *                              <- p0 = rn16(s v), p1 = rn16(s v - p0), s = disc_plane_scale
+   * The padding columns are never written: zero the buffer once.  Feed it to amp_disc_style_reward_prescaled(). */
+  void* disc_input;
   int64_t disc_input_stride;
   const float* scaler_mean;
   const float* scaler_den;
   float scaler_clip;
+  int32_t disc_input_format;
+  int64_t disc_input_plane;
+  float disc_plane_scale;
   int32_t reserved;
 } AmpEnvBuffers;
 
@@ -257,16 +263,25 @@ int amp_disc_destroy(AmpDisc* h);
 /* RunningStandardScaler statistics (fp64 on device, as skrl keeps them); NULL mean disables scaling. */
 int amp_disc_set_scaler(AmpDisc* h, const double* running_mean_dev, const double* running_variance_dev,
                         float epsilon, float clip_threshold, amp_stream_t stream);
-/* OPT-IN split-precision GEMMs: 0 = native fp32 MFMA (default), 3 = "bf16x6" (fp32 operands carried as three bf16
- * planes, six bf16 MFMAs per k-step: fp32-level accuracy, ~2.7x the fp32-MFMA rate), 2 = "bf16x3" (two planes, three
- * MFMAs: ~1e-5 * |logit| accuracy, ~5x).  Re-splits the weights; call again after amp_disc_create.  The workspace
- * size depends on it. */
-int amp_disc_set_precision(AmpDisc* h, int32_t bf16_planes, amp_stream_t stream);
+/* GEMM engine of the forward pass.  Both deliver fp32-class accuracy (the path's 1e-5 budget; measured <= 1e-6 on O(1)
+ * logits): AMP_DISC_F16X3 (default) carries every fp32 operand as two fp16 planes and issues three fp16 MFMAs per
+ * k-step into one fp32 accumulator; AMP_DISC_FP32 runs the fp32 MFMA on fp32 operands (exact fma chain, ~2.7x slower). */
+enum { AMP_DISC_F16X3 = 0, AMP_DISC_FP32 = 1 };
+int amp_disc_set_precision(AmpDisc* h, int32_t mode, amp_stream_t stream);
 int64_t amp_disc_workspace_bytes(const AmpDisc* h, int64_t rows);
-/* Layout of the scaled input the GEMMs consume: padded row length (multiple of 16, rows 16-B aligned) and the
- * handle's fp32 scaler vectors (device pointers valid until the next amp_disc_set_scaler / destroy; NULL mean when
- * no scaler is set). */
-int amp_disc_input_layout(const AmpDisc* h, int32_t* padded_dim, const float** mean_dev, const float** den_dev, float* clip);
+/* Layout of the scaled input the GEMMs consume, for producers that write it directly (amp_env_step's fused scaler).
+ * AMP_DISC_F16X3 with a clamping scaler consumes fp16 planes (the clamp bounds the plane scale); every other
+ * configuration consumes fp32 rows.  Device pointers stay valid until the next amp_disc_set_scaler / destroy. */
+enum { AMP_DISC_INPUT_F32_ROWS = 0, AMP_DISC_INPUT_F16_PLANES = 1 };
+typedef struct {
+  int32_t format;          /* AMP_DISC_INPUT_* */
+  int32_t padded_dim;      /* row length in elements: K*D zero-padded to the layer-1 k-tile; rows 16-B aligned */
+  const float* mean_dev;   /* fp32 scaler vectors; NULL mean when no scaler is set */
+  const float* den_dev;
+  float clip;
+  float plane_scale;       /* F16_PLANES: the power of two s with s * clip < 2^15 */
+} AmpDiscInputLayout;
+int amp_disc_input_layout(const AmpDisc* h, AmpDiscInputLayout* out);
 /* amp_obs_dev [rows, in_dim] (row stride in elements) -> logits [rows], style [rows] =
  * -log(max(1 - sigmoid(logit), 1e-4)) * reward_scale, combined = task_w * task + style_w * style.
  * logits / style / task / combined may be NULL.
@@ -279,9 +294,10 @@ int amp_disc_style_reward(const AmpDisc* h, const float* amp_obs_dev, int64_t ro
                           float* logits_dev, float* style_dev, float* combined_dev, void* workspace_dev,
                           amp_event_t inputs_consumed, amp_stream_t stream);
 
-/* Same as amp_disc_style_reward for an input that is already scaled and padded (amp_env_step's disc_input, or any
- * [rows, padded_dim] fp32 matrix with 16-B aligned rows whose padding columns are zero): skips the scaler pass. */
-int amp_disc_style_reward_prescaled(const AmpDisc* h, const float* scaled_dev, int64_t rows, float reward_scale,
+/* Same as amp_disc_style_reward for an input that is already scaled, padded and in the layout amp_disc_input_layout()
+ * reports (amp_env_step's disc_input; fp32 rows [rows, padded_dim], or fp16 planes [2][rows, padded_dim] with plane
+ * stride rows * padded_dim; padding columns zero): skips the scaler pass. */
+int amp_disc_style_reward_prescaled(const AmpDisc* h, const void* scaled_dev, int64_t rows, float reward_scale,
                                     const float* task_reward_dev, float task_weight, float style_weight,
                                     float* logits_dev, float* style_dev, float* combined_dev, void* workspace_dev,
                                     amp_stream_t stream);

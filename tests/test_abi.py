@@ -45,15 +45,31 @@ def test_no_cxx_symbols_leak_into_the_abi_names():
         assert n in exported
 
 
-def test_struct_layouts_match_the_header():
-    """ctypes mirrors: spot-check sizes that would silently corrupt arguments if they drifted."""
+def test_struct_layouts_match_the_header(tmp_path):
+    """ctypes mirrors vs the header itself: gcc compiles include/amp_engine.h as C and reports sizeof / offsetof of
+    every struct and field the binding passes by pointer; a drift would silently corrupt arguments."""
+    import subprocess
+
     from humanoid_amp_amd import _native as nat
 
-    assert ctypes.sizeof(nat.AmpMotionDesc) == 4 * 4 + 8 + 8 + 8 + 6 * 8
-    assert ctypes.sizeof(nat.AmpEnvCfg) == 10 * 4 + 8 + 6 * 4 + 3 * 8
-    assert ctypes.sizeof(nat.AmpSimState) == 9 * 16 + 32 + 16 + 3 * 8
-    assert ctypes.sizeof(nat.AmpEnvBuffers) == 10 * 8 + 8 + 8 + 8 + 8 + 4 + 4
-    assert ctypes.sizeof(nat.AmpDiscDesc) == 16 + 6 * 8
+    structs = {"AmpMotionDesc": nat.AmpMotionDesc, "AmpEnvCfg": nat.AmpEnvCfg, "AmpSimState": nat.AmpSimState,
+               "AmpEnvBuffers": nat.AmpEnvBuffers, "AmpDiscDesc": nat.AmpDiscDesc, "AmpDiscInputLayout": nat.AmpDiscInputLayout,
+               "AmpResetArgs": nat.AmpResetArgs, "AmpDiscTrainCfg": nat.AmpDiscTrainCfg}
+    lines = ["#include <stddef.h>", "#include <stdio.h>", '#include "amp_engine.h"', "int main(void) {"]
+    for name, cls in structs.items():
+        lines.append(f'  printf("{name} %zu\\n", sizeof({name}));')
+        for field, _ in cls._fields_:
+            lines.append(f'  printf("{name}.{field} %zu\\n", offsetof({name}, {field}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(ln.split() for ln in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for name, cls in structs.items():
+        assert int(got[name]) == ctypes.sizeof(cls), name
+        for field, _ in cls._fields_:
+            assert int(got[f"{name}.{field}"]) == getattr(cls, field).offset, f"{name}.{field}"
 
 
 def test_errors_are_codes_not_exceptions_and_need_no_gpu():

@@ -134,7 +134,7 @@ def test_fused_scaler_matches_separate_pass(workload, envs):
         res[fused] = (outs[-1]["style"].clone(), outs[-1]["combined"].clone(), hot.kernel.amp_observation_buffer.clone())
         if fused:
             xs = hot.kernel.disc_input
-            assert float(xs[:, kd:].abs().max()) == 0.0 if xs.shape[1] > kd else True  # padding untouched
+            assert xs.shape[-1] == kd or float(xs[..., kd:].abs().max()) == 0.0  # padding untouched
     for a, b in zip(res[False], res[True]):
         assert torch.equal(a, b)
 
@@ -164,11 +164,11 @@ def test_graph_replay_matches_eager():
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("precision,bar", [("bf16x6", 1e-6), ("bf16x3", 1e-5)])
+@pytest.mark.parametrize("precision,bar", [("f16x3", 1e-6), ("f32", 1e-6)])
 @pytest.mark.parametrize("in_dim,rows", [(166, 4096), (830, 777), (162, 70000)])
-def test_split_precision_modes(precision, bar, in_dim, rows):
-    """Opt-in split-precision GEMMs: bf16x6 must be as accurate as native fp32 (<= 1e-6 vs fp64 on O(1) logits),
-    bf16x3 must stay inside the 1e-5 budget on O(1) logits."""
+def test_gemm_engines_vs_fp64(precision, bar, in_dim, rows):
+    """Both GEMM engines (fp16-split default, fp32 MFMA) must be as accurate as an fp32 forward: <= 1e-6 against the
+    fp64 evaluation of the same fp32 weights on O(1) logits, a tenth of the path's 1e-5 budget."""
     from humanoid_amp_amd.engine import AmpDiscriminator
 
     g = torch.Generator().manual_seed(in_dim + rows)
@@ -188,8 +188,41 @@ def test_split_precision_modes(precision, bar, in_dim, rows):
     assert float((out["logits"][sub].cpu().double() - lg64).abs().max()) <= bar * scale
     assert float((out["style"][sub].cpu() - ref["style"]).abs().max()) <= 2.5 * bar * scale + 1e-6
     assert float((out["combined"][sub].cpu() - ref["combined"]).abs().max()) <= 2.5 * bar * scale + 1e-6
-    # prescaled entry point == generic entry point in the same mode
-    xs = torch.zeros(rows, d.input_layout()[0], device="cuda")
-    xs[:, :in_dim] = odisc.scale_states(x, mean, var).cuda()
-    pre = d.style_reward_prescaled(xs, task.cuda(), want_logits=True)
+    # prescaled entry point (host-built input in the layout the engine reports) == generic entry point
+    from humanoid_amp_amd import _native as nat
+
+    lay = d.input_layout()
+    xs = torch.zeros(rows, lay.padded_dim)
+    xs[:, :in_dim] = odisc.scale_states(x, mean, var)
+    if lay.format == nat.AMP_DISC_INPUT_F16_PLANES:
+        assert precision == "f16x3" and lay.plane_scale == 4096.0  # 4096 * clip(5) < 2^15
+        v = xs * lay.plane_scale
+        p0 = v.half()
+        xs = torch.stack([p0, (v - p0.float()).half()])
+    pre = d.style_reward_prescaled(xs.cuda(), task.cuda(), want_logits=True)
     assert float((pre["logits"] - out["logits"]).abs().max()) <= bar * scale  # host-scaled vs device-scaled input
+
+
+def test_f16_engine_without_clamp_uses_dynamic_bound():
+    """No scaler => nothing bounds the input: the fp16 engine takes the abs-max of the batch as the plane bound.
+    Inputs spanning 1e-6 .. 1e4 must neither overflow fp16 nor lose the small rows."""
+    from humanoid_amp_amd.engine import AmpDiscriminator
+
+    g = torch.Generator().manual_seed(77)
+    w = odisc.make_weights(166, seed=4)
+    x = torch.randn(600, 166, generator=g)
+    x[:200] *= 1e-6
+    x[200:400] *= 30.0
+    x[599] *= 1e4
+    d = AmpDiscriminator([(p.cuda(), q.cuda()) for p, q in w], "cuda:0")
+    out = d.style_reward(x.cuda(), want_logits=True)["logits"].cpu().double()
+    with torch.no_grad():
+        lg64 = odisc.logits(w, x, dtype=torch.float64)
+        lg32 = odisc.logits(w, x, dtype=torch.float32).double()
+    assert torch.isfinite(out).all()
+    err, err32 = (out - lg64).abs(), (lg32 - lg64).abs()
+    # per-tensor plane scales: the error floor is relative to the LARGEST row of the batch (documented in DESIGN.md);
+    # rows of ordinary magnitude must match an fp32 forward
+    scale = lg64.abs().clamp(min=1.0)
+    assert float((err[:599] / scale[:599]).max()) <= 1e-6 + float((err32[:599] / scale[:599]).max())
+    assert float(err[599] / scale[599]) <= 2e-6

@@ -1,0 +1,189 @@
+// Stand-alone micro-benchmark + accuracy check of the split-operand fp16 GEMM (csrc/disc_gemm_f16.hpp).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I humanoid_amp_amd/csrc tools/gemm_f16_bench.hip \
+//         humanoid_amp_amd/csrc/core.hip -o tools/bin/gemm_f16_bench && tools/bin/gemm_f16_bench [M] [N] [K]
+// N == 512: mode 1 (partial logits); otherwise mode 0 (stores the planes of the hidden layer).
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <algorithm>
+#include <vector>
+
+#include "disc_gemm_f16.hpp"
+
+using namespace amp;
+
+#define CK(x)                                                                  \
+  do {                                                                         \
+    hipError_t e = (x);                                                        \
+    if (e != hipSuccess) {                                                     \
+      printf("%s: %s\n", #x, hipGetErrorString(e));                            \
+      exit(1);                                                                 \
+    }                                                                          \
+  } while (0)
+
+static double g_us = 0;
+
+template <int TM, int TN, int BK, int MODE, int MW>
+static void run(GemmF16Args g, int64_t M, int N, int K, bool quiet) {
+  g.n_tiles = N / (64 * TN);
+  g.m_tiles = (int)((M + 64 * TM - 1) / (64 * TM));
+  const unsigned grid = (unsigned)(((int64_t)g.m_tiles * g.n_tiles + 7) / 8 * 8);
+  constexpr int lds = gemm_f16_lds_bytes<TM, TN, BK>();
+  auto kern = disc_gemm_f16_kernel<TM, TN, BK, MODE, MW>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a));
+  CK(hipEventCreate(&b));
+  for (int i = 0; i < 3; ++i) kern<<<grid, kBlock, lds>>>(g);
+  CK(hipDeviceSynchronize());
+  const int reps = 10;
+  CK(hipEventRecord(a));
+  for (int i = 0; i < reps; ++i) kern<<<grid, kBlock, lds>>>(g);
+  CK(hipEventRecord(b));
+  CK(hipEventSynchronize(b));
+  float ms;
+  CK(hipEventElapsedTime(&ms, a, b));
+  g_us = ms * 1e3 / reps;
+  int occ = 0;
+  CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, kBlock, lds));
+  if (!quiet) {
+    const double tf = 2.0 * M * N * K / (g_us * 1e-6) / 1e12;
+    printf("tile %3dx%3dx%2d mode %d minw %d lds %6d blocks/CU %d  %8.1f us  %6.1f TF(alg)  %.3f of fp16 peak executed\n", 64 * TM,
+           64 * TN, BK, MODE, MW, lds, occ, g_us, tf, 3 * tf / 2516.6);
+    fflush(stdout);
+  }
+}
+
+int main(int argc, char** argv) {
+  const int64_t M = argc > 1 ? atoll(argv[1]) : 65536;
+  const int N = argc > 2 ? atoi(argv[2]) : 512;
+  const int K = argc > 3 ? atoi(argv[3]) : 1024;
+  const int mode = N == 512 ? 1 : 0;
+  printf("f16-split GEMM M=%lld N=%d K=%d mode %d\n", (long long)M, N, K, mode);
+  std::vector<float> hA((size_t)M * K), hW((size_t)N * K), hb(N), hw3(N);
+  unsigned s = 12345;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xFFFF) / 65536.0f - 0.5f; };
+  for (auto& v : hA) v = std::max(rnd() * 3.0f, 0.0f) * (1.0f + rnd());
+  for (int64_t m = 5; m < M; m += M / 64) {  // rows far below the tensor's bound: fp16 subnormal territory
+    const float tiny = m % 2 ? 3e-7f : 1e-9f;
+    for (int k = 0; k < K; ++k) hA[m * K + k] *= tiny;
+  }
+  for (auto& v : hW) v = rnd() * 0.1f;
+  for (auto& v : hb) v = rnd();
+  for (auto& v : hw3) v = rnd();
+  float amax = 0, wmax = 0;
+  for (float v : hA) amax = std::max(amax, std::fabs(v));
+  for (float v : hW) wmax = std::max(wmax, std::fabs(v));
+  const float sa = std::exp2(15.0f - std::ceil(std::log2(amax))), sw = std::exp2(15.0f - std::ceil(std::log2(wmax)));
+  const float sh = 256.0f;
+  float hs[4] = {1.0f / (sa * sw), sh, 0, 0};
+  float *A, *W, *b, *w3, *P, *sc, *one;
+  _Float16 *Ap, *Wp, *Hp;
+  CK(hipMalloc(&A, hA.size() * 4));
+  CK(hipMalloc(&W, hW.size() * 4));
+  CK(hipMalloc(&Ap, hA.size() * 4));
+  CK(hipMalloc(&Wp, hW.size() * 4));
+  CK(hipMalloc(&Hp, (size_t)M * N * 4));
+  CK(hipMalloc(&b, N * 4));
+  CK(hipMalloc(&w3, N * 4));
+  CK(hipMalloc(&P, (size_t)M * 16 * 4));
+  CK(hipMalloc(&sc, 16));
+  CK(hipMalloc(&one, 8));
+  CK(hipMemcpy(A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(W, hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(b, hb.data(), N * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(w3, hw3.data(), N * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(sc, hs, 16, hipMemcpyHostToDevice));
+  float s2[2] = {sa, sw};
+  CK(hipMemcpy(one, s2, 8, hipMemcpyHostToDevice));
+  split_rows_f16_kernel<<<(unsigned)((M * K / 4 + 255) / 256), 256>>>(A, M, K, K, one, Ap, K, M * K);
+  split_rows_f16_kernel<<<(unsigned)(((int64_t)N * K / 4 + 255) / 256), 256>>>(W, N, K, K, one + 1, Wp, K, (int64_t)N * K);
+  CK(hipDeviceSynchronize());
+  GemmF16Args g{};
+  g.A = Ap; g.lda = K; g.plane_a = M * K; g.M = M; g.W = Wp; g.plane_w = (int64_t)N * K; g.Kp = K; g.N = N;
+  g.bias = b; g.scales = sc; g.H = Hp; g.ldh = N; g.plane_h = M * N; g.w3 = w3; g.partial = P;
+
+  auto check = [&](int n_tiles) {
+    const int rows = 64;
+    double worst = 0, scale = 0;
+    if (mode == 1) {
+      std::vector<float> hp((size_t)M * n_tiles);
+      CK(hipMemcpy(hp.data(), P, hp.size() * 4, hipMemcpyDeviceToHost));
+      for (int r = 0; r < rows; ++r) {
+        const int64_t m = (int64_t)r * (M / rows) + (r % 7);
+        double ref = 0, got = 0;
+        for (int n = 0; n < N; ++n) {
+          double d = hb[n];
+          for (int k = 0; k < K; ++k) d += (double)hA[m * K + k] * hW[(size_t)n * K + k];
+          ref += std::max(d, 0.0) * hw3[n];
+        }
+        for (int t = 0; t < n_tiles; ++t) got += hp[m * n_tiles + t];
+        worst = std::max(worst, std::fabs(got - ref));
+        scale = std::max(scale, std::fabs(ref));
+      }
+    } else {
+      std::vector<_Float16> hh((size_t)2 * M * N);
+      CK(hipMemcpy(hh.data(), Hp, hh.size() * 2, hipMemcpyDeviceToHost));
+      for (int r = 0; r < rows; ++r) {
+        const int64_t m = (int64_t)r * (M / rows) + (r % 7);
+        for (int n = 0; n < N; n += 3) {
+          double d = hb[n];
+          for (int k = 0; k < K; ++k) d += (double)hA[m * K + k] * hW[(size_t)n * K + k];
+          const double ref = std::max(d, 0.0);
+          const double got = ((double)(float)hh[m * N + n] + (double)(float)hh[(size_t)M * N + m * N + n]) / sh;
+          worst = std::max(worst, std::fabs(got - ref));
+          scale = std::max(scale, std::fabs(ref));
+        }
+      }
+    }
+    printf("    max |err| vs fp64 on %d rows: %.3e (|ref| up to %.3e)\n", rows, worst, scale);
+    if (mode == 1) {
+      std::vector<float> hp((size_t)M * n_tiles);
+      CK(hipMemcpy(hp.data(), P, hp.size() * 4, hipMemcpyDeviceToHost));
+      for (int64_t m = 5; m < M; m += M / 64 * 21) {
+        double ref = 0, got = 0, refb = 0;
+        for (int n = 0; n < N; ++n) {
+          double d = hb[n];
+          for (int k = 0; k < K; ++k) d += (double)hA[m * K + k] * hW[(size_t)n * K + k];
+          ref += std::max(d, 0.0) * hw3[n];
+          refb += std::max((double)hb[n], 0.0) * hw3[n];
+        }
+        for (int t = 0; t < n_tiles; ++t) got += hp[m * n_tiles + t];
+        printf("    tiny row %lld: ref %.9e got %.9e (bias-only %.9e)\n", (long long)m, ref, got, refb);
+      }
+    }
+  };
+
+#define V(TM, TN, BK, MW)                                        \
+  do {                                                           \
+    if (mode == 1) run<TM, TN, BK, 1, MW>(g, M, N, K, quiet);    \
+    else run<TM, TN, BK, 0, MW>(g, M, N, K, quiet);              \
+  } while (0)
+  bool quiet = false;
+  V(2, 2, 32, 3); check(N / 128);
+  V(2, 2, 64, 2); check(N / 128);
+  V(1, 1, 32, 6); check(N / 64);
+  V(1, 1, 64, 4); check(N / 64);
+  V(4, 2, 32, 2); check(N / 128);
+  V(2, 4, 32, 2); check(N / 256);
+  V(4, 2, 64, 1); check(N / 128);
+  quiet = true;
+  const char* names[7] = {"128x128x32 w3", "128x128x64 w2", "64x64x32 w6", "64x64x64 w4", "256x128x32 w2", "128x256x32 w2", "256x128x64 w1"};
+  std::vector<std::vector<double>> t(7);
+  for (int r = 0; r < 5; ++r) {
+    V(2, 2, 32, 3); t[0].push_back(g_us);
+    V(2, 2, 64, 2); t[1].push_back(g_us);
+    V(1, 1, 32, 6); t[2].push_back(g_us);
+    V(1, 1, 64, 4); t[3].push_back(g_us);
+    V(4, 2, 32, 2); t[4].push_back(g_us);
+    V(2, 4, 32, 2); t[5].push_back(g_us);
+    V(4, 2, 64, 1); t[6].push_back(g_us);
+  }
+  for (int i = 0; i < 7; ++i) {
+    std::sort(t[i].begin(), t[i].end());
+    const double med = t[i][t[i].size() / 2], tf = 2.0 * M * N * K / (med * 1e-6) / 1e12;
+    printf("%-16s median %8.1f us (min %8.1f max %8.1f)  %6.1f TF algorithmic, %.3f of the fp16 peak executed\n", names[i], med,
+           t[i].front(), t[i].back(), tf, 3 * tf / 2516.6);
+  }
+  return 0;
+}
