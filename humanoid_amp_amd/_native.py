@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libamp_engine.so")
 ABI_VERSION = 5
 
 AMP_DISC_F16X3, AMP_DISC_FP32 = 0, 1
-AMP_DISC_INPUT_F32_ROWS, AMP_DISC_INPUT_F16_PLANES = 0, 1
+AMP_DISC_INPUT_F32_ROWS, AMP_DISC_INPUT_F16_PAIRS = 0, 1
 AMP_PHASE_DONES, AMP_PHASE_REWARD, AMP_PHASE_OBS = 1, 2, 4
 AMP_PHASE_ALL = 7
 TILE_ENVS = 64
@@ -88,8 +88,8 @@ class AmpEnvBuffers(C.Structure):
         ("just_reset", C.c_void_p), ("reward", C.c_void_p), ("reward_terms", C.c_void_p), ("died", C.c_void_p),
         ("time_out", C.c_void_p), ("reset_mask", C.c_void_p), ("reset_tile_counts", C.c_void_p),
         ("disc_input", C.c_void_p), ("disc_input_stride", C.c_int64), ("scaler_mean", C.c_void_p), ("scaler_den", C.c_void_p),
-        ("scaler_clip", C.c_float), ("disc_input_format", C.c_int32), ("disc_input_plane", C.c_int64),
-        ("disc_plane_scale", C.c_float), ("reserved", C.c_int32),
+        ("scaler_clip", C.c_float), ("disc_input_format", C.c_int32), ("disc_plane_scale", C.c_float),
+        ("reserved", C.c_int32),
     ]
 
 

@@ -126,4 +126,12 @@ __device__ __forceinline__ Vec3 quat_rotate_inverse_ref(Quat q, Vec3 v) {
   return o;
 }
 
+// ---- fp16 plane pairs (disc_gemm_f16.hpp; also written by amp_env_step's fused scaler) -----------------------------
+// one (p0, p1) pair per element: p0 = rn16(v), p1 = rn16(v - p0) for a value already multiplied by its plane scale
+__device__ __forceinline__ uint32_t plane_pair(float v) {
+  const _Float16 a = (_Float16)v;
+  const _Float16 b = (_Float16)(v - (float)a);
+  return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+}
+
 }  // namespace amp

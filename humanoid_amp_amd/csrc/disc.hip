@@ -7,7 +7,7 @@
 //   AMP_DISC_FP32             v_mfma_f32_32x32x2_f32 on fp32 operands (disc_gemm.hpp): exact fp32 fma chain.
 //
 //   scale    one pass over amp_obs: RunningStandardScaler (exact fp32 divide, once per element) + zero padding of
-//            K*D to the k-tile -> Xs in the workspace (fp32 rows, or the two fp16 planes of s_x * Xs).
+//            K*D to the k-tile -> Xs in the workspace (fp32 rows, or (p0, p1) fp16 pairs of s_x * Xs).
 //   layer 1  GEMM [M, k] x [k, 1024]: bias + ReLU in the epilogue, transposed through LDS so every store is a full
 //            row segment; H1 written once to the workspace (fp32, or the two planes of s_h * H1).
 //   layer 2  GEMM [M,1024] x [1024,512]: bias + ReLU + the 512->1 output layer as a per-lane dot with w3 over the
@@ -193,25 +193,25 @@ __global__ __launch_bounds__(kBlock) void disc_absmax_kernel(const float* __rest
   if (threadIdx.x == 0) atomicMax(amax, __float_as_uint(red[0]));
 }
 
-// amp_obs [M, in] (any row stride) -> the two fp16 planes of s_x * clamp((x - mean) / den) [M, kh], zero padded.
-// One thread per 8 columns (16-B stores per plane).  Also snapshots the task reward like disc_scale_pad_kernel.
+// amp_obs [M, in] (any row stride) -> (p0, p1) fp16 pairs of s_x * clamp((x - mean) / den) [M, kh], zero padded.
+// One thread per 4 columns (one 16-B store).  Also snapshots the task reward like disc_scale_pad_kernel.
 __global__ __launch_bounds__(kBlock) void disc_scale_split_kernel(const float* __restrict__ x, int64_t row_stride, int64_t M,
                                                                   int k, int kh, const float* __restrict__ mean,
                                                                   const float* __restrict__ den, float clip,
                                                                   const DiscRange* __restrict__ range,
-                                                                  const float* __restrict__ amax, _Float16* __restrict__ planes,
+                                                                  const float* __restrict__ amax, uint32_t* __restrict__ pairs,
                                                                   const float* __restrict__ task, float* __restrict__ task_copy) {
-  const int o_per_row = kh >> 3;
+  const int q_per_row = kh >> 2;
   const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (task && e < M) task_copy[e] = task[e];
-  if (e >= M * o_per_row) return;
+  if (e >= M * q_per_row) return;
   const float s_x = plane_scale(amax ? amax[0] : range->clip);
-  const int64_t m = e / o_per_row;
-  const int c0 = (int)(e - m * o_per_row) * 8;
+  const int64_t m = e / q_per_row;
+  const int c0 = (int)(e - m * q_per_row) * 4;
   const float* row = x + m * row_stride;
-  h8 p0, p1;
+  uv4 o;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < 4; ++i) {
     const int c = c0 + i;
     float v = 0.0f;
     if (c < k) {
@@ -221,13 +221,9 @@ __global__ __launch_bounds__(kBlock) void disc_scale_split_kernel(const float* _
         v = fminf(fmaxf(v, -clip), clip);
       }
     }
-    v *= s_x;
-    const _Float16 a = (_Float16)v;
-    p0[i] = a;
-    p1[i] = (_Float16)(v - (float)a);
+    o[i] = plane_pair(v * s_x);
   }
-  *reinterpret_cast<h8*>(planes + m * kh + c0) = p0;
-  *reinterpret_cast<h8*>(planes + M * kh + m * kh + c0) = p1;
+  *reinterpret_cast<uv4*>(pairs + m * kh + c0) = o;
 }
 
 }  // namespace amp
@@ -281,7 +277,7 @@ static int disc_forward(const AmpDisc* h, const float* Xs, int64_t rows, float* 
   }
   return launch_status("disc_finalize_kernel");
 }
-// fp16-split forward on the planes Xp [2][rows][k1h] of the scaled input (disc_gemm_f16.hpp); `amax` = the dynamic
+// fp16-split forward on the (p0, p1) pairs Xp [rows][k1h] of the scaled input (disc_gemm_f16.hpp); `amax` = the dynamic
 // bound of the scaled input, or null when the scaler's clamp bounds it
 template <int TM, int TN, int BK, int MODE, int MINW>
 static int launch_f16(GemmF16Args g, int64_t rows, int N, const char* name, hipStream_t st) {
@@ -314,7 +310,7 @@ static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* a
   // bound) 128 x 256 x 32, layer 2 128 x 128 x 64, each at 2 workgroups / CU; shards with < 512 such tiles use 64 x 64
   auto big_tiles = [&](int N) { return (rows + 127) / 128 * (N / 128) >= 512; };
   GemmF16Args g1{};
-  g1.A = Xp; g1.lda = h->k1h; g1.plane_a = rows * h->k1h; g1.M = rows;
+  g1.A = Xp; g1.lda = h->k1h; g1.plane_a = 0; g1.M = rows;
   g1.W = h->w1h; g1.plane_w = (int64_t)h->h1 * h->k1h; g1.Kp = h->k1h; g1.N = h->h1;
   g1.bias = h->b1; g1.range = h->range; g1.amax = amax; g1.layer = 1;
   g1.H = H1p; g1.ldh = h->h1; g1.plane_h = rows * h->h1;
@@ -534,10 +530,10 @@ int amp_disc_style_reward(const AmpDisc* h, const float* x, int64_t rows, int64_
       amax = ws.header;
     }
     {
-      const int64_t octs = rows * (h->k1h / 8);
+      const int64_t quads = rows * (h->k1h / 4);
       amp::TraceScope trace__("disc_scale_split_kernel", st);
-      disc_scale_split_kernel<<<(unsigned)((octs + kBlock - 1) / kBlock), kBlock, 0, st>>>(
-          x, row_stride, rows, h->in_dim, h->k1h, mean, h->den, h->clip, h->range, amax, (_Float16*)ws.xs, task, ws.task_copy);
+      disc_scale_split_kernel<<<(unsigned)((quads + kBlock - 1) / kBlock), kBlock, 0, st>>>(
+          x, row_stride, rows, h->in_dim, h->k1h, mean, h->den, h->clip, h->range, amax, (uint32_t*)ws.xs, task, ws.task_copy);
     }
     int rcs = launch_status("disc_scale_split_kernel");
     if (rcs != AMP_OK) return rcs;
@@ -563,7 +559,7 @@ int amp_disc_style_reward(const AmpDisc* h, const float* x, int64_t rows, int64_
 int amp_disc_input_layout(const AmpDisc* h, AmpDiscInputLayout* out) {
   AMP_REQUIRE(h && out, "amp_disc_input_layout: null argument");
   const bool planes = h->mode == AMP_DISC_F16X3 && static_bound(h);
-  out->format = planes ? AMP_DISC_INPUT_F16_PLANES : AMP_DISC_INPUT_F32_ROWS;
+  out->format = planes ? AMP_DISC_INPUT_F16_PAIRS : AMP_DISC_INPUT_F32_ROWS;
   out->padded_dim = planes ? h->k1h : h->k1p;
   out->mean_dev = h->has_scaler ? h->mean : nullptr;
   out->den_dev = h->den;
@@ -584,7 +580,7 @@ int amp_disc_style_reward_prescaled(const AmpDisc* h, const void* xs_any, int64_
   AMP_REQUIRE(rows <= ((int64_t)1 << 30), "amp_disc_style_reward_prescaled: too many rows");
   const DiscWorkspace ws = disc_workspace(h, rows, workspace);
   hipStream_t st = (hipStream_t)stream;
-  if (h->mode == AMP_DISC_F16X3 && static_bound(h))  // fp16 planes at the clamp's plane scale (amp_disc_input_layout)
+  if (h->mode == AMP_DISC_F16X3 && static_bound(h))  // fp16 pairs at the clamp's plane scale (amp_disc_input_layout)
     return disc_forward_f16(h, (const _Float16*)xs_any, nullptr, rows, (_Float16*)ws.h1, ws.partial, scale, task, task_w, style_w,
                             logits, style, combined, st);
   if (h->mode == AMP_DISC_F16X3) {
@@ -595,10 +591,10 @@ int amp_disc_style_reward_prescaled(const AmpDisc* h, const void* xs_any, int64_
       disc_absmax_kernel<<<1024, kBlock, 0, st>>>(xs, h->k1p, rows, h->in_dim, nullptr, nullptr, 0.0f, (unsigned*)ws.header);
     }
     {
-      const int64_t octs = rows * (h->k1h / 8);
+      const int64_t quads = rows * (h->k1h / 4);
       amp::TraceScope trace__("disc_scale_split_kernel", st);
-      disc_scale_split_kernel<<<(unsigned)((octs + kBlock - 1) / kBlock), kBlock, 0, st>>>(
-          xs, h->k1p, rows, h->in_dim, h->k1h, nullptr, nullptr, 0.0f, h->range, ws.header, (_Float16*)ws.xs, nullptr, nullptr);
+      disc_scale_split_kernel<<<(unsigned)((quads + kBlock - 1) / kBlock), kBlock, 0, st>>>(
+          xs, h->k1p, rows, h->in_dim, h->k1h, nullptr, nullptr, 0.0f, h->range, ws.header, (uint32_t*)ws.xs, nullptr, nullptr);
     }
     int rcs = launch_status("disc_scale_split_kernel");
     if (rcs != AMP_OK) return rcs;

@@ -27,6 +27,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float fx16 __attribute__((ext_vector_type(16)));
 typedef float fv4 __attribute__((ext_vector_type(4)));
+typedef uint32_t uv4 __attribute__((ext_vector_type(4)));
 
 namespace amp {
 
@@ -65,7 +66,9 @@ __device__ __forceinline__ LayerScales layer_scales(const DiscRange* r, const fl
 }
 
 struct GemmF16Args {
-  const _Float16* A; int64_t lda, plane_a; int64_t M;           // activation planes: A + p * plane_a, rows of lda halves
+  // activations: planes A + p * plane_a with rows of lda halves, or (PAIRS) one array of (p0, p1) half pairs, rows of
+  // lda pairs -- the layout producers write with one 32-bit store per element (amp_env_step's fused scaler)
+  const _Float16* A; int64_t lda, plane_a; int64_t M;
   const _Float16* W; int64_t plane_w; int32_t Kp; int32_t N;    // weight planes [N, Kp]
   const float* bias;
   const DiscRange* range; const float* amax; int32_t layer;     // -> layer_scales()
@@ -103,6 +106,21 @@ __global__ __launch_bounds__(kBlock) void split_rows_f16_kernel(const float* __r
   *reinterpret_cast<h4*>(&dst[plane + r * ld_dst + c]) = p1;
 }
 
+// (p0, p1) pairs of scale[0] * src[rows, cols] -> dst [rows, ld_dst] words; columns in [cols, ld_dst) are zero
+__global__ __launch_bounds__(kBlock) void split_rows_pairs_kernel(const float* __restrict__ src, int64_t rows, int cols,
+                                                                  int64_t ld_src, const float* __restrict__ scale,
+                                                                  uint32_t* __restrict__ dst, int64_t ld_dst) {
+  const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x, per_row = ld_dst / 4;
+  if (q >= rows * per_row) return;
+  const int64_t r = q / per_row;
+  const int c = (int)(q - r * per_row) * 4;
+  const float s = scale[0];
+  uv4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = c + i < cols ? plane_pair(src[r * ld_src + c + i] * s) : 0u;
+  *reinterpret_cast<uv4*>(&dst[r * ld_dst + c]) = o;
+}
+
 __device__ __forceinline__ bool f16_tile_of_block(const GemmF16Args& g, int& mt, int& nt) {
   const int total = g.m_tiles * g.n_tiles;
   const int per_xcd = (total + 7) / 8;
@@ -115,7 +133,7 @@ __device__ __forceinline__ bool f16_tile_of_block(const GemmF16Args& g, int& mt,
 
 __device__ __forceinline__ void f16_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int BM, int BN, int BK>
+template <int BM, int BN, int BK, bool PAIRS>
 struct StageF16 {
   static constexpr int LDK = BK + 8;                // halves per LDS row
   static constexpr int CPR = BK / 8;                // 16-B chunks per row
@@ -129,14 +147,33 @@ struct StageF16 {
     const int64_t last = g.M - 1;  // rows past M re-read the last row; their results are never stored
     const _Float16* x = g.A + kt * BK + 8 * kc;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < 2; ++p)
 #pragma unroll
       for (int i = 0; i < CB; ++i) b[p][i] = *reinterpret_cast<const h8*>(w + p * g.plane_w + (int64_t)i * RPP * g.Kp);
+    if (PAIRS) {
+      // 8 elements = 8 (p0, p1) words = two 16-B loads; v_perm_b32 gathers the low / high halves into plane chunks
+      const uint32_t* x32 = reinterpret_cast<const uint32_t*>(g.A) + kt * BK + 8 * kc;
 #pragma unroll
       for (int i = 0; i < CA; ++i) {
         const int64_t m = m0 + r + RPP * i;
-        a[p][i] = *reinterpret_cast<const h8*>(x + p * g.plane_a + (m < last ? m : last) * g.lda);
+        const uint32_t* src = x32 + (m < last ? m : last) * g.lda;
+        const uv4 lo = *reinterpret_cast<const uv4*>(src), hi = *reinterpret_cast<const uv4*>(src + 4);
+        uv4 q0, q1;
+        q0[0] = __builtin_amdgcn_perm(lo[1], lo[0], 0x05040100u); q1[0] = __builtin_amdgcn_perm(lo[1], lo[0], 0x07060302u);
+        q0[1] = __builtin_amdgcn_perm(lo[3], lo[2], 0x05040100u); q1[1] = __builtin_amdgcn_perm(lo[3], lo[2], 0x07060302u);
+        q0[2] = __builtin_amdgcn_perm(hi[1], hi[0], 0x05040100u); q1[2] = __builtin_amdgcn_perm(hi[1], hi[0], 0x07060302u);
+        q0[3] = __builtin_amdgcn_perm(hi[3], hi[2], 0x05040100u); q1[3] = __builtin_amdgcn_perm(hi[3], hi[2], 0x07060302u);
+        a[0][i] = __builtin_bit_cast(h8, q0);
+        a[1][i] = __builtin_bit_cast(h8, q1);
       }
+    } else {
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int i = 0; i < CA; ++i) {
+          const int64_t m = m0 + r + RPP * i;
+          a[p][i] = *reinterpret_cast<const h8*>(x + p * g.plane_a + (m < last ? m : last) * g.lda);
+        }
     }
   }
   // LDS: [A p0][A p1][B p0][B p1], each rows x LDK
@@ -153,6 +190,7 @@ struct StageF16 {
   }
 };
 
+// MODE 0 reads its activations as (p0, p1) pairs (the scaled input), MODE 1 as planes (H1, written by MODE 0).
 template <int TM, int TN, int BK, int MODE, int MINW>
 __global__ __launch_bounds__(kBlock, MINW) void disc_gemm_f16_kernel(GemmF16Args g) {
   constexpr int BM = 64 * TM, BN = 64 * TN, LDK = BK + 8;
@@ -177,7 +215,7 @@ __global__ __launch_bounds__(kBlock, MINW) void disc_gemm_f16_kernel(GemmF16Args
 
   const _Float16* xa = smem + (wm * TM * 32 + li) * LDK + 8 * lh;                 // activation fragments, plane 0
   const _Float16* wb = smem + 2 * BM * LDK + (wn * TN * 32 + li) * LDK + 8 * lh;  // weight fragments, plane 0
-  StageF16<BM, BN, BK> stg;
+  StageF16<BM, BN, BK, MODE == 0> stg;
   stg.load(g, m0, n0, 0, tid);
   stg.store(smem, tid);
   __syncthreads();

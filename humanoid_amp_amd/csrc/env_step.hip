@@ -190,12 +190,11 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(EnvPlan p, AmpSimState
     const int count = n_tile * D;
     const float inv_d = 1.0f / (float)D;
     constexpr int U = 4;  // independent columns per lane per trip: their loads are issued before any store
-    // optional fused discriminator input: the same values, scaled, into disc_input (fp32 rows or fp16 planes)
-    const bool planes = bf.disc_input_format == AMP_DISC_INPUT_F16_PLANES;
+    // optional fused discriminator input: the same values, scaled, into disc_input (fp32 rows or fp16 (p0, p1) pairs:
+    // one 32-bit store per element either way)
+    const bool pairs = bf.disc_input_format == AMP_DISC_INPUT_F16_PAIRS;
     const bool fused = bf.disc_input != nullptr;
-    float* const xs = reinterpret_cast<float*>(bf.disc_input) + (planes ? 0 : tile_base * bf.disc_input_stride);
-    _Float16* const xh = reinterpret_cast<_Float16*>(bf.disc_input) + (planes ? tile_base * bf.disc_input_stride : 0);
-    const int64_t plane = bf.disc_input_plane;
+    uint32_t* const xs = reinterpret_cast<uint32_t*>(bf.disc_input) + tile_base * bf.disc_input_stride;
     const float s_x = bf.disc_plane_scale;
     const float* const mu = bf.scaler_mean;
     const float* const dn = bf.scaler_den;
@@ -205,14 +204,7 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(EnvPlan p, AmpSimState
         v = (v - mu[c]) / dn[c];  // skrl RunningStandardScaler, exact fp32 divide
         v = fminf(fmaxf(v, -clip), clip);
       }
-      if (planes) {
-        v *= s_x;
-        const _Float16 a = (_Float16)v;
-        xh[off] = a;
-        xh[plane + off] = (_Float16)(v - (float)a);
-      } else {
-        xs[off] = v;
-      }
+      xs[off] = pairs ? plane_pair(v * s_x) : __float_as_uint(v);
     };
     for (int e0 = tid; e0 < count; e0 += U * kBlock) {
       float* col[U];
@@ -402,9 +394,8 @@ int amp_env_step(const AmpEnvCfg* cfg, const AmpSimState* st, const AmpEnvBuffer
     AMP_REQUIRE(!bf->disc_input || bf->disc_input_stride >= (int64_t)p.K * p.D, "amp_env_step(obs): disc_input_stride too small");
     AMP_REQUIRE(!bf->disc_input || !bf->scaler_mean || bf->scaler_den, "amp_env_step(obs): scaler_den is null");
     AMP_REQUIRE(!bf->disc_input || bf->disc_input_format == AMP_DISC_INPUT_F32_ROWS ||
-                    (bf->disc_input_format == AMP_DISC_INPUT_F16_PLANES && bf->disc_plane_scale > 0.0f &&
-                     bf->disc_input_plane >= N * bf->disc_input_stride),
-                "amp_env_step(obs): bad disc_input format / plane scale / plane stride");
+                    (bf->disc_input_format == AMP_DISC_INPUT_F16_PAIRS && bf->disc_plane_scale > 0.0f),
+                "amp_env_step(obs): bad disc_input format / plane scale");
   }
   const bool per_env_limits = g1_rew && st->soft_limits_stride != 0;
   const int tile = amp_env_step_tile_envs(N);

@@ -112,14 +112,14 @@ class EnvStepKernel:
     def attach_discriminator(self, disc: "AmpDiscriminator") -> torch.Tensor:
         """Fuse ``disc``'s input scaler into the OBS phase: every OBS launch also writes the scaled, zero-padded
         discriminator input in the layout the discriminator's GEMMs consume -- ``disc_input`` float32 ``[N, padded]``
-        or float16 planes ``[2, N, padded]`` (feed it to ``disc.style_reward_prescaled``) -- which saves the separate
-        scaler pass over ``amp_obs``.  Call again after ``disc.set_scaler`` / ``set_weights``."""
+        or float16 (p0, p1) pairs ``[N, padded, 2]`` (feed it to ``disc.style_reward_prescaled``) -- which saves the
+        separate scaler pass over ``amp_obs``.  Call again after ``disc.set_scaler`` / ``set_weights``."""
         lay = disc.input_layout()
         if lay.padded_dim < self.cfg.num_amp_observations * self.cfg.amp_frame_size:
             raise nat.AmpEngineError("discriminator input is narrower than K * D")
-        planes = lay.format == nat.AMP_DISC_INPUT_F16_PLANES
-        shape = (2, self.num_envs, lay.padded_dim) if planes else (self.num_envs, lay.padded_dim)
-        dtype = torch.float16 if planes else torch.float32
+        pairs = lay.format == nat.AMP_DISC_INPUT_F16_PAIRS
+        shape = (self.num_envs, lay.padded_dim, 2) if pairs else (self.num_envs, lay.padded_dim)
+        dtype = torch.float16 if pairs else torch.float32
         if self.disc_input is None or tuple(self.disc_input.shape) != shape or self.disc_input.dtype != dtype:
             self.disc_input = torch.zeros(shape, dtype=dtype, device=self.device)  # padding columns stay zero
         self._disc_layout = lay
@@ -135,9 +135,8 @@ class EnvStepKernel:
         b.reset_tile_counts = p(self.reset_tile_counts)
         if self.disc_input is not None:
             lay = self._disc_layout
-            b.disc_input, b.disc_input_stride = self.disc_input.data_ptr(), int(self.disc_input.stride(-2))
+            b.disc_input, b.disc_input_stride = self.disc_input.data_ptr(), lay.padded_dim  # elements per row
             b.disc_input_format, b.disc_plane_scale = lay.format, lay.plane_scale
-            b.disc_input_plane = int(self.disc_input.stride(0)) if self.disc_input.dim() == 3 else 0
             b.scaler_mean, b.scaler_den, b.scaler_clip = lay.mean_dev, lay.den_dev, lay.clip
         return b
 
@@ -332,7 +331,7 @@ class AmpDiscriminator:
         return out
 
     def input_layout(self) -> nat.AmpDiscInputLayout:
-        """Layout of the scaled input the GEMMs consume (``format``: fp32 rows or fp16 planes, ``padded_dim``, the
+        """Layout of the scaled input the GEMMs consume (``format``: fp32 rows or fp16 pairs, ``padded_dim``, the
         handle's fp32 scaler vectors as device pointers, ``clip``, ``plane_scale``)."""
         lay = nat.AmpDiscInputLayout()
         nat.check(self._lib.amp_disc_input_layout(self._handle, C.byref(lay)), "amp_disc_input_layout")
@@ -341,16 +340,15 @@ class AmpDiscriminator:
     def style_reward_prescaled(self, scaled: torch.Tensor, task_reward: Optional[torch.Tensor] = None, *,
                                want_logits: bool = False):
         """Same as :meth:`style_reward` for an input already scaled, padded and laid out as :meth:`input_layout`
-        says (``EnvStepKernel.attach_discriminator``): float32 ``[M, padded]`` or float16 planes ``[2, M, padded]``."""
+        says (``EnvStepKernel.attach_discriminator``): float32 ``[M, padded]`` or float16 pairs ``[M, padded, 2]``."""
         lay = self.input_layout()
-        planes = lay.format == nat.AMP_DISC_INPUT_F16_PLANES
-        want = (torch.float16, 3) if planes else (torch.float32, 2)
-        if scaled.dtype != want[0] or scaled.dim() != want[1] or scaled.shape[-1] != lay.padded_dim or not scaled.is_contiguous() \
-                or (planes and scaled.shape[0] != 2):
-            raise nat.AmpEngineError(f"scaled input must be a contiguous {'float16 [2, M, ' if planes else 'float32 [M, '}"
-                                     f"{lay.padded_dim}] tensor (see input_layout)")
+        pairs = lay.format == nat.AMP_DISC_INPUT_F16_PAIRS
+        want = (torch.float16, (lay.padded_dim, 2)) if pairs else (torch.float32, (lay.padded_dim,))
+        if scaled.dtype != want[0] or tuple(scaled.shape[1:]) != want[1] or not scaled.is_contiguous():
+            raise nat.AmpEngineError(f"scaled input must be a contiguous {want[0]} [M, {', '.join(map(str, want[1]))}] tensor "
+                                     "(see input_layout)")
         nat.require_gpu(scaled.device)
-        M = scaled.shape[-2]
+        M = scaled.shape[0]
         f32 = dict(dtype=torch.float32, device=self.device)
         style = torch.empty((M, 1), **f32)
         logits = torch.empty((M, 1), **f32) if want_logits else None

@@ -199,17 +199,16 @@ typedef struct {
   /* Optional fusion of the discriminator's input scaler into the OBS phase (saves one pass over amp_obs):
    * disc_input receives v = clamp((amp_obs - mean) / den, -clip, clip) for the K*D columns in the layout
    * amp_disc_input_layout() reports (every field below comes from it; scaler_mean == NULL copies unscaled):
-   *   AMP_DISC_INPUT_F32_ROWS    float  [N, disc_input_stride]                       <- v
-   *   AMP_DISC_INPUT_F16_PLANES  _Float16 [2][N, disc_input_stride], plane p at + p * disc_input_plane halves
-   *                              <- p0 = rn16(s v), p1 = rn16(s v - p0), s = disc_plane_scale
-   * The padding columns are never written: zero the buffer once.  Feed it to amp_disc_style_reward_prescaled(). */
+   *   AMP_DISC_INPUT_F32_ROWS   float       [N, disc_input_stride]   <- v
+   *   AMP_DISC_INPUT_F16_PAIRS  _Float16[2] [N, disc_input_stride]   <- {p0 = rn16(s v), p1 = rn16(s v - p0)}, s = disc_plane_scale
+   * (both 4 bytes per element, one store).  The padding columns are never written: zero the buffer once.  Feed it to
+   * amp_disc_style_reward_prescaled(). */
   void* disc_input;
   int64_t disc_input_stride;
   const float* scaler_mean;
   const float* scaler_den;
   float scaler_clip;
   int32_t disc_input_format;
-  int64_t disc_input_plane;
   float disc_plane_scale;
   int32_t reserved;
 } AmpEnvBuffers;
@@ -270,16 +269,17 @@ enum { AMP_DISC_F16X3 = 0, AMP_DISC_FP32 = 1 };
 int amp_disc_set_precision(AmpDisc* h, int32_t mode, amp_stream_t stream);
 int64_t amp_disc_workspace_bytes(const AmpDisc* h, int64_t rows);
 /* Layout of the scaled input the GEMMs consume, for producers that write it directly (amp_env_step's fused scaler).
- * AMP_DISC_F16X3 with a clamping scaler consumes fp16 planes (the clamp bounds the plane scale); every other
- * configuration consumes fp32 rows.  Device pointers stay valid until the next amp_disc_set_scaler / destroy. */
-enum { AMP_DISC_INPUT_F32_ROWS = 0, AMP_DISC_INPUT_F16_PLANES = 1 };
+ * AMP_DISC_F16X3 with a clamping scaler consumes one (p0, p1) fp16 pair per element (the clamp bounds the plane
+ * scale); every other configuration consumes fp32 rows.  Device pointers stay valid until the next
+ * amp_disc_set_scaler / destroy. */
+enum { AMP_DISC_INPUT_F32_ROWS = 0, AMP_DISC_INPUT_F16_PAIRS = 1 };
 typedef struct {
   int32_t format;          /* AMP_DISC_INPUT_* */
   int32_t padded_dim;      /* row length in elements: K*D zero-padded to the layer-1 k-tile; rows 16-B aligned */
   const float* mean_dev;   /* fp32 scaler vectors; NULL mean when no scaler is set */
   const float* den_dev;
   float clip;
-  float plane_scale;       /* F16_PLANES: the power of two s with s * clip < 2^15 */
+  float plane_scale;       /* F16_PAIRS: the power of two s with s * clip < 2^15 */
 } AmpDiscInputLayout;
 int amp_disc_input_layout(const AmpDisc* h, AmpDiscInputLayout* out);
 /* amp_obs_dev [rows, in_dim] (row stride in elements) -> logits [rows], style [rows] =
@@ -295,8 +295,8 @@ int amp_disc_style_reward(const AmpDisc* h, const float* amp_obs_dev, int64_t ro
                           amp_event_t inputs_consumed, amp_stream_t stream);
 
 /* Same as amp_disc_style_reward for an input that is already scaled, padded and in the layout amp_disc_input_layout()
- * reports (amp_env_step's disc_input; fp32 rows [rows, padded_dim], or fp16 planes [2][rows, padded_dim] with plane
- * stride rows * padded_dim; padding columns zero): skips the scaler pass. */
+ * reports (amp_env_step's disc_input; fp32 rows or fp16 pairs [rows, padded_dim], padding columns zero): skips the
+ * scaler pass. */
 int amp_disc_style_reward_prescaled(const AmpDisc* h, const void* scaled_dev, int64_t rows, float reward_scale,
                                     const float* task_reward_dev, float task_weight, float style_weight,
                                     float* logits_dev, float* style_dev, float* combined_dev, void* workspace_dev,

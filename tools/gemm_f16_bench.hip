@@ -74,10 +74,13 @@ int main(int argc, char** argv) {
   float amax = 0, wmax = 0;
   for (float v : hA) amax = std::max(amax, std::fabs(v));
   for (float v : hW) wmax = std::max(wmax, std::fabs(v));
-  const float sa = std::exp2(15.0f - std::ceil(std::log2(amax))), sw = std::exp2(15.0f - std::ceil(std::log2(wmax)));
-  const float sh = 256.0f;
-  float hs[4] = {1.0f / (sa * sw), sh, 0, 0};
-  float *A, *W, *b, *w3, *P, *sc, *one;
+  const float sa = plane_scale(amax), sw = plane_scale(wmax);
+  // range record such that layer_scales() reproduces these scales: bound_x = amax (clip), |H| <= 0 * bound_x + 100
+  DiscRange hr{};
+  hr.s_w1 = hr.s_w2 = sw; hr.wsum1 = 0.0f; hr.bmax1 = mode == 0 ? 100.0f : amax; hr.clip = amax;
+  const float sh = plane_scale(100.0f);
+  float *A, *W, *b, *w3, *P, *one;
+  DiscRange* sc;
   _Float16 *Ap, *Wp, *Hp;
   CK(hipMalloc(&A, hA.size() * 4));
   CK(hipMalloc(&W, hW.size() * 4));
@@ -87,21 +90,22 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&b, N * 4));
   CK(hipMalloc(&w3, N * 4));
   CK(hipMalloc(&P, (size_t)M * 16 * 4));
-  CK(hipMalloc(&sc, 16));
+  CK(hipMalloc(&sc, sizeof(DiscRange)));
   CK(hipMalloc(&one, 8));
   CK(hipMemcpy(A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(W, hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(b, hb.data(), N * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(w3, hw3.data(), N * 4, hipMemcpyHostToDevice));
-  CK(hipMemcpy(sc, hs, 16, hipMemcpyHostToDevice));
+  CK(hipMemcpy(sc, &hr, sizeof(DiscRange), hipMemcpyHostToDevice));
   float s2[2] = {sa, sw};
   CK(hipMemcpy(one, s2, 8, hipMemcpyHostToDevice));
-  split_rows_f16_kernel<<<(unsigned)((M * K / 4 + 255) / 256), 256>>>(A, M, K, K, one, Ap, K, M * K);
+  if (mode == 0) split_rows_pairs_kernel<<<(unsigned)((M * K / 4 + 255) / 256), 256>>>(A, M, K, K, one, (uint32_t*)Ap, K);
+  else split_rows_f16_kernel<<<(unsigned)((M * K / 4 + 255) / 256), 256>>>(A, M, K, K, one, Ap, K, M * K);
   split_rows_f16_kernel<<<(unsigned)(((int64_t)N * K / 4 + 255) / 256), 256>>>(W, N, K, K, one + 1, Wp, K, (int64_t)N * K);
   CK(hipDeviceSynchronize());
   GemmF16Args g{};
   g.A = Ap; g.lda = K; g.plane_a = M * K; g.M = M; g.W = Wp; g.plane_w = (int64_t)N * K; g.Kp = K; g.N = N;
-  g.bias = b; g.scales = sc; g.H = Hp; g.ldh = N; g.plane_h = M * N; g.w3 = w3; g.partial = P;
+  g.bias = b; g.range = sc; g.amax = nullptr; g.layer = mode == 0 ? 1 : 2; g.H = Hp; g.ldh = N; g.plane_h = M * N; g.w3 = w3; g.partial = P;
 
   auto check = [&](int n_tiles) {
     const int rows = 64;
