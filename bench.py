@@ -199,9 +199,12 @@ def main():
         collective = {"every": args.rollouts, "fn": lambda: [ag.start() for _ in range(args.minibatches)], "join": ag.wait_all}
 
     # ---- timed region: exactly --steps steps, the dominant kernel bracketed by HIP events on its stream --------
-    with nat.KernelTrace(capacity=args.steps + args.warmup + 8, kernel_filter=dominant) as tr:
+    with nat.KernelTrace(capacity=4 * (args.steps + args.warmup) + 8, kernel_filter=dominant) as tr:
         dt = timed_steps(hot, args.steps, args.warmup, world, collective)
-    recs = tr.records()[-args.steps:]
+    # the engine may run a large shard as several row chunks: launches per step = records / steps over the timed region
+    allrecs = tr.records()
+    per_step = max(1, round(len(allrecs) / (args.steps + args.warmup)))
+    recs = allrecs[-args.steps * per_step:]
     gemm2_ms = sum(ms for _, ms in recs) / max(len(recs), 1)
     value = args.envs * world * args.steps / dt
 
@@ -209,7 +212,7 @@ def main():
     with nat.KernelTrace(capacity=16 * 8) as tr_all:
         for _ in range(8):
             hot.step()
-    per_kernel = {k: round(t / c * 1e3, 2) for k, (c, t) in tr_all.summary().items()}  # us per launch
+    per_kernel = {k: round(t / 8 * 1e3, 2) for k, (c, t) in tr_all.summary().items()}  # us per step (all launches of the kernel)
 
     out = None
     if rank == 0:
@@ -219,11 +222,14 @@ def main():
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             # keys are "kernel<template args>@workgroups"; layer 2 at this shard size = ceil(envs / 128) * 4 workgroups
-            tmpl = {"f16x3": "disc_gemm_f16_kernel<2, 2, 64, 1, 2>", "f32": "disc_gemm_kernel<128, 128, 16, 1, 1, 4>"}[args.disc_precision]
-            traffic = tj[f"{tmpl}@{(args.envs + 127) // 128 * 4}"]["hbm_bytes"] if args.envs >= 16384 else None
+            # keys are "kernel<template args>@workgroups" (workgroups of one launch)
+            rows = args.envs // per_step
+            key = {"f16x3": f"disc_gemm_f16_dma_kernel<0>@{(rows + 255) // 256 * 2}",
+                   "f32": f"disc_gemm_kernel<128, 128, 16, 1, 1, 4>@{(rows + 127) // 128 * 4}"}[args.disc_precision]
+            traffic = tj[key]["hbm_bytes"] if args.envs >= 16384 else None
         except Exception:
             traffic = None
-        flops2 = 2.0 * args.envs * 1024 * 512 + 2.0 * args.envs * 512   # layer 2 + the fused 512 -> 1 dot
+        flops2 = (2.0 * args.envs * 1024 * 512 + 2.0 * args.envs * 512) / per_step   # layer 2 + the fused 512 -> 1 dot, per launch
         achieved = flops2 / (gemm2_ms * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS[args.disc_precision]
         nprod = MFMA_PER_PRODUCT[args.disc_precision]
@@ -246,13 +252,14 @@ def main():
             # issues; the fp16-split engine executes 3 MFMA products per algorithmic one (frac_executed counts those)
             "roofline": {"bound": "mfma", "kernel": dominant, "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                         "avg_launch_ms": gemm2_ms, "launches_timed": len(recs), "flops_per_launch": flops2,
+                         "avg_launch_ms": gemm2_ms, "launches_timed": len(recs), "launches_per_step": per_step,
+                         "rows_per_launch": args.envs // per_step, "flops_per_launch": flops2,
                          "mfma_products_per_flop": nprod, "frac_executed": nprod * achieved / peak,
                          "vs_fp32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS},
             "roofline_hbm": {"bound": "hbm", "kernels": list(hbm_kernels), "achieved": alg_bytes / (hbm_us * 1e-6) / 1e9 if hbm_us else None,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (alg_bytes / (hbm_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if hbm_us else None,
                              "bytes_per_env_step": algorithmic_bytes_per_env_step(spec), "us": hbm_us},
-            "kernel_us": per_kernel,
+            "kernel_us_per_step": per_kernel,
             "disc_flops_per_env_step": disc_flops_per_row(spec.K * spec.D),
         }
 
@@ -280,7 +287,7 @@ def main():
             dtm = timed_steps(hot_m, args.steps, args.warmup, world, None)
         rm = trm.records()[-args.steps:]
         ms32 = sum(ms for _, ms in rm) / max(len(rm), 1)
-        flops2 = 2.0 * args.envs * 1024 * 512 + 2.0 * args.envs * 512
+        flops2 = 2.0 * args.envs * 1024 * 512 + 2.0 * args.envs * 512  # the fp32 engine runs the shard as one launch
         out["fp32_mfma_engine"] = {
             "value": args.envs * world * args.steps / dtm, "unit": "env-steps/s", "ms_per_step": dtm / args.steps * 1e3,
             "roofline": {"bound": "mfma", "kernel": DOMINANT_KERNEL["f32"], "achieved": flops2 / (ms32 * 1e-3) / 1e12,

@@ -20,6 +20,7 @@
 // do not depend on which other rows share the batch.
 #include "disc_gemm.hpp"
 #include "disc_gemm_f16.hpp"
+#include "disc_gemm_f16_dma.hpp"
 
 #include <cstdlib>
 
@@ -292,42 +293,69 @@ static int launch_f16(GemmF16Args g, int64_t rows, int N, const char* name, hipS
 static int f16_kernels_init() {
   static bool done = false;
   if (done) return AMP_OK;
-  AMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gemm_f16_kernel<2, 4, 32, 0, 2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, gemm_f16_lds_bytes<2, 4, 32>()));
   AMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gemm_f16_kernel<2, 2, 64, 1, 2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, gemm_f16_lds_bytes<2, 2, 64>()));
+  AMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gemm_f16_dma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kDmaLdsBytes));
   done = true;
   return AMP_OK;
 }
+// Row chunking of a large shard: layer 1 writes the hidden layer of a chunk (4 KB / row) and layer 2 reads it back
+// right away, so a chunk that fits the 256 MB Infinity Cache next to everything else touched in between is served
+// on-die instead of from HBM (a 65 536-row shard writes 268 MB: read back in the same order NOTHING would still be
+// resident).  32 768 rows = 134 MB, and 128 x 2 layer-2 tiles = one workgroup per CU.
+constexpr int64_t kChunkRows = 32768;
+static bool f16_use_dma(const AmpDisc* h, int64_t rows) {  // 256 x 256 LDS-DMA kernel: needs >= ~1 tile per CU
+  return h->h2 % kDmaBN == 0 && (rows + kDmaBM - 1) / kDmaBM * (h->h2 / kDmaBN) >= 192;
+}
+static int64_t f16_chunk_rows(const AmpDisc* h, int64_t rows) {
+  return f16_use_dma(h, kChunkRows) && rows > kChunkRows + kChunkRows / 2 ? kChunkRows : rows;
+}
 static int f16_n_tiles(const AmpDisc* h, int64_t rows) {
-  const bool big = (rows + 127) / 128 * (h->h2 / 128) >= 512;
+  const int64_t chunk = f16_chunk_rows(h, rows);
+  if (f16_use_dma(h, chunk)) return h->h2 / kDmaBN;
+  const bool big = (chunk + 127) / 128 * (h->h2 / 128) >= 512;
   return h->h2 / (big ? 128 : 64);
 }
 static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* amax, int64_t rows, _Float16* H1p, float* partial,
                             float scale, const float* task, float task_w, float style_w, float* logits, float* style,
                             float* combined, hipStream_t st) {
   // Tile choice measured with tools/gemm_f16_bench.hip (profiles/r01_gemm_f16_variants.txt): layer 1 (k = 192, store
-  // bound) 128 x 256 x 32, layer 2 128 x 128 x 64, each at 2 workgroups / CU; shards with < 512 such tiles use 64 x 64
-  auto big_tiles = [&](int N) { return (rows + 127) / 128 * (N / 128) >= 512; };
-  GemmF16Args g1{};
-  g1.A = Xp; g1.lda = h->k1h; g1.plane_a = 0; g1.M = rows;
-  g1.W = h->w1h; g1.plane_w = (int64_t)h->h1 * h->k1h; g1.Kp = h->k1h; g1.N = h->h1;
-  g1.bias = h->b1; g1.range = h->range; g1.amax = amax; g1.layer = 1;
-  g1.H = H1p; g1.ldh = h->h1; g1.plane_h = rows * h->h1;
-  int rc;
-  if (big_tiles(h->h1) && h->h1 % 256 == 0) rc = launch_f16<2, 4, 32, 0, 2>(g1, rows, h->h1, "disc_gemm_f16_kernel<0>", st);
-  else if (big_tiles(h->h1)) rc = launch_f16<2, 2, 32, 0, 3>(g1, rows, h->h1, "disc_gemm_f16_kernel<0>", st);
-  else rc = launch_f16<1, 1, 32, 0, 6>(g1, rows, h->h1, "disc_gemm_f16_kernel<0>", st);
-  if (rc != AMP_OK) return rc;
-
-  GemmF16Args g2{};
-  g2.A = H1p; g2.lda = h->h1; g2.plane_a = rows * h->h1; g2.M = rows;
-  g2.W = h->w2h; g2.plane_w = (int64_t)h->h2 * h->h1; g2.Kp = h->h1; g2.N = h->h2;
-  g2.bias = h->b2; g2.range = h->range; g2.amax = amax; g2.layer = 2;
-  g2.w3 = h->w3; g2.partial = partial;
+  // bound) 128 x 128 x 32 at 3 workgroups / CU; layer 2 the 256 x 256 LDS-DMA kernel when a chunk fills the chip,
+  // else 128 x 128 x 64 at 2 workgroups / CU; shards with < 512 such tiles use 64 x 64
+  const int64_t chunk = f16_chunk_rows(h, rows);
   const int n_tiles = f16_n_tiles(h, rows);
-  if (big_tiles(h->h2)) rc = launch_f16<2, 2, 64, 1, 2>(g2, rows, h->h2, "disc_gemm_f16_kernel<1>", st);
-  else rc = launch_f16<1, 1, 64, 1, 4>(g2, rows, h->h2, "disc_gemm_f16_kernel<1>", st);
+  int rc = AMP_OK;
+  for (int64_t r0 = 0; r0 < rows && rc == AMP_OK; r0 += chunk) {
+    const int64_t m = rows - r0 < chunk ? rows - r0 : chunk;
+    auto big_tiles = [&](int N) { return (m + 127) / 128 * (N / 128) >= 512; };
+    GemmF16Args g1{};
+    g1.A = Xp + 2 * r0 * h->k1h; g1.lda = h->k1h; g1.plane_a = 0; g1.M = m;  // (p0, p1) pairs: two halves per element
+    g1.W = h->w1h; g1.plane_w = (int64_t)h->h1 * h->k1h; g1.Kp = h->k1h; g1.N = h->h1;
+    g1.bias = h->b1; g1.range = h->range; g1.amax = amax; g1.layer = 1;
+    g1.H = H1p + r0 * h->h1; g1.ldh = h->h1; g1.plane_h = rows * h->h1;
+    if (big_tiles(h->h1)) rc = launch_f16<2, 2, 32, 0, 3>(g1, m, h->h1, "disc_gemm_f16_kernel<0>", st);
+    else rc = launch_f16<1, 1, 32, 0, 6>(g1, m, h->h1, "disc_gemm_f16_kernel<0>", st);
+    if (rc != AMP_OK) return rc;
+
+    GemmF16Args g2{};
+    g2.A = H1p + r0 * h->h1; g2.lda = h->h1; g2.plane_a = rows * h->h1; g2.M = m;
+    g2.W = h->w2h; g2.plane_w = (int64_t)h->h2 * h->h1; g2.Kp = h->h1; g2.N = h->h2;
+    g2.bias = h->b2; g2.range = h->range; g2.amax = amax; g2.layer = 2;
+    g2.w3 = h->w3; g2.partial = partial + r0 * n_tiles;
+    if (n_tiles == h->h2 / kDmaBN && f16_use_dma(h, chunk)) {  // every chunk (a short last one too): one partial layout
+      g2.n_tiles = n_tiles;
+      g2.m_tiles = (int)((m + kDmaBM - 1) / kDmaBM);
+      const unsigned grid = (unsigned)(((int64_t)g2.m_tiles * g2.n_tiles + 7) / 8 * 8);
+      amp::TraceScope trace__("disc_gemm_f16_kernel<1>", st);
+      disc_gemm_f16_dma_kernel<0><<<grid, kDmaThreads, kDmaLdsBytes, st>>>(g2);
+      rc = launch_status("disc_gemm_f16_dma_kernel");
+    } else if (n_tiles == h->h2 / 128) {
+      rc = launch_f16<2, 2, 64, 1, 2>(g2, m, h->h2, "disc_gemm_f16_kernel<1>", st);
+    } else {
+      rc = launch_f16<1, 1, 64, 1, 4>(g2, m, h->h2, "disc_gemm_f16_kernel<1>", st);
+    }
+  }
   if (rc != AMP_OK) return rc;
   { amp::TraceScope trace__("disc_finalize_kernel", st);
     disc_finalize_kernel<<<(unsigned)((rows + kBlock - 1) / kBlock), kBlock, 0, st>>>(partial, n_tiles, h->b3, rows, scale, task,

@@ -8,7 +8,7 @@
 #include <algorithm>
 #include <vector>
 
-#include "disc_gemm_f16.hpp"
+#include "disc_gemm_f16_dma.hpp"
 
 using namespace amp;
 
@@ -21,15 +21,60 @@ using namespace amp;
     }                                                                          \
   } while (0)
 
+// Calibration: nothing but fp16 MFMAs on register operands (ACCS independent accumulators per wave).
+template <int ACCS>
+__global__ __launch_bounds__(256) void mfma_f16_only_kernel(float* out, int iters) {
+  fx16 acc[ACCS];
+#pragma unroll
+  for (int i = 0; i < ACCS; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+  h8 a, b;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(threadIdx.x * 1e-3f + i); b[i] = (_Float16)(blockIdx.x * 1e-4f + 0.5f); }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < ACCS; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i], 0, 0, 0);
+    a[0] += (_Float16)1e-3f;
+  }
+  float s = 0;
+#pragma unroll
+  for (int i = 0; i < ACCS; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int ACCS>
+static void calib(float* out, int blocks_per_cu, int iters) {
+  const int grid = 256 * blocks_per_cu;
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a));
+  CK(hipEventCreate(&b));
+  mfma_f16_only_kernel<ACCS><<<grid, 256>>>(out, iters);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(a));
+  mfma_f16_only_kernel<ACCS><<<grid, 256>>>(out, iters);
+  CK(hipEventRecord(b));
+  CK(hipEventSynchronize(b));
+  float ms;
+  CK(hipEventElapsedTime(&ms, a, b));
+  const double flops = (double)grid * 4 * iters * 4 * ACCS * 32768.0;
+  printf("fp16 mfma-only: %d accumulators, %d blocks/CU, %d iters: %.1f us  %.1f TF  %.3f of the 2516.8 TF peak\n", ACCS, blocks_per_cu,
+         iters, ms * 1e3, flops / (ms * 1e-3) / 1e12, flops / (ms * 1e-3) / 1e12 / 2516.8);
+}
+
 static double g_us = 0;
 
-template <int TM, int TN, int BK, int MODE, int MW>
+template <int TM, int TN, int BK, int MODE, int MW, int PF = 1, int XP = 0>
 static void run(GemmF16Args g, int64_t M, int N, int K, bool quiet) {
   g.n_tiles = N / (64 * TN);
   g.m_tiles = (int)((M + 64 * TM - 1) / (64 * TM));
   const unsigned grid = (unsigned)(((int64_t)g.m_tiles * g.n_tiles + 7) / 8 * 8);
   constexpr int lds = gemm_f16_lds_bytes<TM, TN, BK>();
-  auto kern = disc_gemm_f16_kernel<TM, TN, BK, MODE, MW>;
+  auto kern = disc_gemm_f16_kernel<TM, TN, BK, MODE, MW, PF, XP>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   hipEvent_t a, b;
   CK(hipEventCreate(&a));
@@ -48,8 +93,34 @@ static void run(GemmF16Args g, int64_t M, int N, int K, bool quiet) {
   CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, kBlock, lds));
   if (!quiet) {
     const double tf = 2.0 * M * N * K / (g_us * 1e-6) / 1e12;
-    printf("tile %3dx%3dx%2d mode %d minw %d lds %6d blocks/CU %d  %8.1f us  %6.1f TF(alg)  %.3f of fp16 peak executed\n", 64 * TM,
-           64 * TN, BK, MODE, MW, lds, occ, g_us, tf, 3 * tf / 2516.6);
+    printf("tile %3dx%3dx%2d mode %d minw %d pf %d lds %6d blocks/CU %d  %8.1f us  %6.1f TF(alg)  %.3f of fp16 peak executed\n", 64 * TM,
+           64 * TN, BK, MODE, MW, PF, lds, occ, g_us, tf, 3 * tf / 2516.6);
+    fflush(stdout);
+  }
+}
+
+template <int XP = 0>
+static void run_dma(GemmF16Args g, int64_t M, int N, int K, bool quiet) {
+  g.n_tiles = N / kDmaBN;
+  g.m_tiles = (int)((M + kDmaBM - 1) / kDmaBM);
+  const unsigned grid = (unsigned)(((int64_t)g.m_tiles * g.n_tiles + 7) / 8 * 8);
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gemm_f16_dma_kernel<XP>), hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLdsBytes));
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a));
+  CK(hipEventCreate(&b));
+  for (int i = 0; i < 3; ++i) disc_gemm_f16_dma_kernel<XP><<<grid, kDmaThreads, kDmaLdsBytes>>>(g);
+  CK(hipDeviceSynchronize());
+  const int reps = 10;
+  CK(hipEventRecord(a));
+  for (int i = 0; i < reps; ++i) disc_gemm_f16_dma_kernel<XP><<<grid, kDmaThreads, kDmaLdsBytes>>>(g);
+  CK(hipEventRecord(b));
+  CK(hipEventSynchronize(b));
+  float ms;
+  CK(hipEventElapsedTime(&ms, a, b));
+  g_us = ms * 1e3 / reps;
+  if (!quiet) {
+    const double tf = 2.0 * M * N * K / (g_us * 1e-6) / 1e12;
+    printf("LDS-DMA 256x256x16, 4 stages, 512 threads            %8.1f us   %6.1f TF(alg)  %.3f of fp16 peak executed\n", g_us, tf, 3 * tf / 2516.6);
     fflush(stdout);
   }
 }
@@ -158,35 +229,60 @@ int main(int argc, char** argv) {
     }
   };
 
-#define V(TM, TN, BK, MW)                                        \
-  do {                                                           \
-    if (mode == 1) run<TM, TN, BK, 1, MW>(g, M, N, K, quiet);    \
-    else run<TM, TN, BK, 0, MW>(g, M, N, K, quiet);              \
+#define V(TM, TN, BK, MW, PF)                                        \
+  do {                                                               \
+    if (mode == 1) run<TM, TN, BK, 1, MW, PF>(g, M, N, K, quiet);    \
+    else run<TM, TN, BK, 0, MW, PF>(g, M, N, K, quiet);              \
   } while (0)
   bool quiet = false;
-  V(2, 2, 32, 3); check(N / 128);
-  V(2, 2, 64, 2); check(N / 128);
-  V(1, 1, 32, 6); check(N / 64);
-  V(1, 1, 64, 4); check(N / 64);
-  V(4, 2, 32, 2); check(N / 128);
-  V(2, 4, 32, 2); check(N / 256);
-  V(4, 2, 64, 1); check(N / 128);
-  quiet = true;
-  const char* names[7] = {"128x128x32 w3", "128x128x64 w2", "64x64x32 w6", "64x64x64 w4", "256x128x32 w2", "128x256x32 w2", "256x128x64 w1"};
-  std::vector<std::vector<double>> t(7);
-  for (int r = 0; r < 5; ++r) {
-    V(2, 2, 32, 3); t[0].push_back(g_us);
-    V(2, 2, 64, 2); t[1].push_back(g_us);
-    V(1, 1, 32, 6); t[2].push_back(g_us);
-    V(1, 1, 64, 4); t[3].push_back(g_us);
-    V(4, 2, 32, 2); t[4].push_back(g_us);
-    V(2, 4, 32, 2); t[5].push_back(g_us);
-    V(4, 2, 64, 1); t[6].push_back(g_us);
+  if (getenv("CALIB")) {
+    calib<4>((float*)Hp, 1, 512);    // ~50 us
+    calib<4>((float*)Hp, 1, 2048);   // ~200 us
+    calib<4>((float*)Hp, 2, 2048);
+    calib<4>((float*)Hp, 1, 16384);  // ~1.7 ms
+    return 0;
   }
-  for (int i = 0; i < 7; ++i) {
+  if (getenv("XP") && mode == 1) {
+    printf("experiments on 128x128x64 w2 (wrong results by construction):\n");
+    run<2, 2, 64, 1, 2, 1, 0>(g, M, N, K, false);
+    printf("  ^ full kernel\n");
+    run<2, 2, 64, 1, 2, 1, 1>(g, M, N, K, false);
+    printf("  ^ no global loads / LDS writes (barriers kept)\n");
+    run<2, 2, 64, 1, 2, 1, 2>(g, M, N, K, false);
+    printf("  ^ no global loads / LDS writes / barriers: ds_read + MFMA only\n");
+    run_dma<0>(g, M, N, K, false);
+    printf("  ^ LDS-DMA kernel, full\n");
+    run_dma<1>(g, M, N, K, false);
+    printf("  ^ LDS-DMA kernel, no fills in the loop\n");
+    run_dma<2>(g, M, N, K, false);
+    printf("  ^ LDS-DMA kernel, no fills, no fragment reads: barriers + MFMA\n");
+    return 0;
+  }
+  if (mode == 1) { run_dma(g, M, N, K, false); check(N / kDmaBN); }
+  V(2, 2, 32, 3, 1); check(N / 128);
+  V(2, 2, 64, 2, 1); check(N / 128);
+  V(2, 2, 32, 3, 2); check(N / 128);
+  V(2, 2, 32, 2, 2); check(N / 128);
+  V(1, 1, 64, 4, 1); check(N / 64);
+  V(1, 1, 32, 6, 2); check(N / 64);
+  V(1, 1, 64, 4, 2); check(N / 64);
+  quiet = true;
+  const char* names[8] = {"128x128x32 w3 pf1", "128x128x64 w2 pf1", "128x128x32 w3 pf2", "128x128x32 w2 pf2", "64x64x64 w4 pf1", "64x64x32 w6 pf2", "64x64x64 w4 pf2", "LDS-DMA 256x256x16"};
+  std::vector<std::vector<double>> t(8);
+  for (int r = 0; r < 5; ++r) {
+    V(2, 2, 32, 3, 1); t[0].push_back(g_us);
+    V(2, 2, 64, 2, 1); t[1].push_back(g_us);
+    V(2, 2, 32, 3, 2); t[2].push_back(g_us);
+    V(2, 2, 32, 2, 2); t[3].push_back(g_us);
+    V(1, 1, 64, 4, 1); t[4].push_back(g_us);
+    V(1, 1, 32, 6, 2); t[5].push_back(g_us);
+    V(1, 1, 64, 4, 2); t[6].push_back(g_us);
+    if (mode == 1) { run_dma(g, M, N, K, true); t[7].push_back(g_us); }
+  }
+  for (int i = 0; i < (mode == 1 ? 8 : 7); ++i) {
     std::sort(t[i].begin(), t[i].end());
     const double med = t[i][t[i].size() / 2], tf = 2.0 * M * N * K / (med * 1e-6) / 1e12;
-    printf("%-16s median %8.1f us (min %8.1f max %8.1f)  %6.1f TF algorithmic, %.3f of the fp16 peak executed\n", names[i], med,
+    printf("%-18s median %8.1f us (min %8.1f max %8.1f)  %6.1f TF algorithmic, %.3f of the fp16 peak executed\n", names[i], med,
            t[i].front(), t[i].back(), tf, 3 * tf / 2516.6);
   }
   return 0;
