@@ -297,6 +297,8 @@ static int f16_kernels_init() {
                               hipFuncAttributeMaxDynamicSharedMemorySize, gemm_f16_lds_bytes<2, 2, 64>()));
   AMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gemm_f16_dma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               kDmaLdsBytes));
+  AMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gemm_f16_dma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kDmaLdsBytes));
   done = true;
   return AMP_OK;
 }
@@ -334,8 +336,18 @@ static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* a
     g1.W = h->w1h; g1.plane_w = (int64_t)h->h1 * h->k1h; g1.Kp = h->k1h; g1.N = h->h1;
     g1.bias = h->b1; g1.range = h->range; g1.amax = amax; g1.layer = 1;
     g1.H = H1p + r0 * h->h1; g1.ldh = h->h1; g1.plane_h = rows * h->h1;
-    if (big_tiles(h->h1)) rc = launch_f16<2, 2, 32, 0, 3>(g1, m, h->h1, "disc_gemm_f16_kernel<0>", st);
-    else rc = launch_f16<1, 1, 32, 0, 6>(g1, m, h->h1, "disc_gemm_f16_kernel<0>", st);
+    if (f16_use_dma(h, chunk) && h->h1 % kDmaBN == 0) {
+      g1.n_tiles = h->h1 / kDmaBN;
+      g1.m_tiles = (int)((m + kDmaBM - 1) / kDmaBM);
+      const unsigned grid = (unsigned)(((int64_t)g1.m_tiles * g1.n_tiles + 7) / 8 * 8);
+      amp::TraceScope trace__("disc_gemm_f16_kernel<0>", st);
+      disc_gemm_f16_dma_kernel<0><<<grid, kDmaThreads, kDmaLdsBytes, st>>>(g1);
+      rc = launch_status("disc_gemm_f16_dma_kernel<0>");
+    } else if (big_tiles(h->h1)) {
+      rc = launch_f16<2, 2, 32, 0, 3>(g1, m, h->h1, "disc_gemm_f16_kernel<0>", st);
+    } else {
+      rc = launch_f16<1, 1, 32, 0, 6>(g1, m, h->h1, "disc_gemm_f16_kernel<0>", st);
+    }
     if (rc != AMP_OK) return rc;
 
     GemmF16Args g2{};
@@ -348,7 +360,7 @@ static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* a
       g2.m_tiles = (int)((m + kDmaBM - 1) / kDmaBM);
       const unsigned grid = (unsigned)(((int64_t)g2.m_tiles * g2.n_tiles + 7) / 8 * 8);
       amp::TraceScope trace__("disc_gemm_f16_kernel<1>", st);
-      disc_gemm_f16_dma_kernel<0><<<grid, kDmaThreads, kDmaLdsBytes, st>>>(g2);
+      disc_gemm_f16_dma_kernel<1><<<grid, kDmaThreads, kDmaLdsBytes, st>>>(g2);
       rc = launch_status("disc_gemm_f16_dma_kernel");
     } else if (n_tiles == h->h2 / 128) {
       rc = launch_f16<2, 2, 64, 1, 2>(g2, m, h->h2, "disc_gemm_f16_kernel<1>", st);

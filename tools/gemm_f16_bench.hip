@@ -47,6 +47,18 @@ __global__ __launch_bounds__(256) void mfma_f16_only_kernel(float* out, int iter
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// Store-only floor of layer 1: every thread writes 16 B per plane the way the epilogue does (row segments of 128 B).
+__global__ __launch_bounds__(256) void store_only_kernel(_Float16* out, int64_t rows, int cols, int64_t plane) {
+  const int64_t chunks_per_row = cols / 8, total = rows * chunks_per_row;
+  for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < total; c += (int64_t)gridDim.x * 256) {
+    h8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (_Float16)(float)(c & 1023);
+    *reinterpret_cast<h8*>(out + c * 8) = v;
+    *reinterpret_cast<h8*>(out + plane + c * 8) = v;
+  }
+}
+
 template <int ACCS>
 static void calib(float* out, int blocks_per_cu, int iters) {
   const int grid = 256 * blocks_per_cu;
@@ -99,20 +111,20 @@ static void run(GemmF16Args g, int64_t M, int N, int K, bool quiet) {
   }
 }
 
-template <int XP = 0>
+template <int MODE, int XP = 0>
 static void run_dma(GemmF16Args g, int64_t M, int N, int K, bool quiet) {
   g.n_tiles = N / kDmaBN;
   g.m_tiles = (int)((M + kDmaBM - 1) / kDmaBM);
   const unsigned grid = (unsigned)(((int64_t)g.m_tiles * g.n_tiles + 7) / 8 * 8);
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gemm_f16_dma_kernel<XP>), hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLdsBytes));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gemm_f16_dma_kernel<MODE, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLdsBytes));
   hipEvent_t a, b;
   CK(hipEventCreate(&a));
   CK(hipEventCreate(&b));
-  for (int i = 0; i < 3; ++i) disc_gemm_f16_dma_kernel<XP><<<grid, kDmaThreads, kDmaLdsBytes>>>(g);
+  for (int i = 0; i < 3; ++i) disc_gemm_f16_dma_kernel<MODE, XP><<<grid, kDmaThreads, kDmaLdsBytes>>>(g);
   CK(hipDeviceSynchronize());
   const int reps = 10;
   CK(hipEventRecord(a));
-  for (int i = 0; i < reps; ++i) disc_gemm_f16_dma_kernel<XP><<<grid, kDmaThreads, kDmaLdsBytes>>>(g);
+  for (int i = 0; i < reps; ++i) disc_gemm_f16_dma_kernel<MODE, XP><<<grid, kDmaThreads, kDmaLdsBytes>>>(g);
   CK(hipEventRecord(b));
   CK(hipEventSynchronize(b));
   float ms;
@@ -240,6 +252,21 @@ int main(int argc, char** argv) {
     calib<4>((float*)Hp, 1, 2048);   // ~200 us
     calib<4>((float*)Hp, 2, 2048);
     calib<4>((float*)Hp, 1, 16384);  // ~1.7 ms
+    for (int grid : {2048, 8192, 65536}) {
+      hipEvent_t a, b;
+      CK(hipEventCreate(&a));
+      CK(hipEventCreate(&b));
+      store_only_kernel<<<grid, 256>>>(Hp, M, 1024, M * 1024);
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(a));
+      for (int i = 0; i < 5; ++i) store_only_kernel<<<grid, 256>>>(Hp, M, 1024, M * 1024);
+      CK(hipEventRecord(b));
+      CK(hipEventSynchronize(b));
+      float ms;
+      CK(hipEventElapsedTime(&ms, a, b));
+      printf("store-only %lld x 1024 x 2 planes (%.0f MB), grid %d: %.1f us  %.2f TB/s\n", (long long)M, M * 4096.0 / 1e6, grid, ms * 200,
+             M * 4096.0 / (ms / 5 * 1e-3) / 1e12);
+    }
     return 0;
   }
   if (getenv("XP") && mode == 1) {
@@ -250,15 +277,16 @@ int main(int argc, char** argv) {
     printf("  ^ no global loads / LDS writes (barriers kept)\n");
     run<2, 2, 64, 1, 2, 1, 2>(g, M, N, K, false);
     printf("  ^ no global loads / LDS writes / barriers: ds_read + MFMA only\n");
-    run_dma<0>(g, M, N, K, false);
+    run_dma<1, 0>(g, M, N, K, false);
     printf("  ^ LDS-DMA kernel, full\n");
-    run_dma<1>(g, M, N, K, false);
+    run_dma<1, 1>(g, M, N, K, false);
     printf("  ^ LDS-DMA kernel, no fills in the loop\n");
-    run_dma<2>(g, M, N, K, false);
+    run_dma<1, 2>(g, M, N, K, false);
     printf("  ^ LDS-DMA kernel, no fills, no fragment reads: barriers + MFMA\n");
     return 0;
   }
-  if (mode == 1) { run_dma(g, M, N, K, false); check(N / kDmaBN); }
+  if (mode == 1) run_dma<1>(g, M, N, K, false); else run_dma<0>(g, M, N, K, false);
+  check(N / kDmaBN);
   V(2, 2, 32, 3, 1); check(N / 128);
   V(2, 2, 64, 2, 1); check(N / 128);
   V(2, 2, 32, 3, 2); check(N / 128);
@@ -277,9 +305,10 @@ int main(int argc, char** argv) {
     V(1, 1, 64, 4, 1); t[4].push_back(g_us);
     V(1, 1, 32, 6, 2); t[5].push_back(g_us);
     V(1, 1, 64, 4, 2); t[6].push_back(g_us);
-    if (mode == 1) { run_dma(g, M, N, K, true); t[7].push_back(g_us); }
+    if (mode == 1) run_dma<1>(g, M, N, K, true); else run_dma<0>(g, M, N, K, true);
+    t[7].push_back(g_us);
   }
-  for (int i = 0; i < (mode == 1 ? 8 : 7); ++i) {
+  for (int i = 0; i < 8; ++i) {
     std::sort(t[i].begin(), t[i].end());
     const double med = t[i][t[i].size() / 2], tf = 2.0 * M * N * K / (med * 1e-6) / 1e12;
     printf("%-18s median %8.1f us (min %8.1f max %8.1f)  %6.1f TF algorithmic, %.3f of the fp16 peak executed\n", names[i], med,
