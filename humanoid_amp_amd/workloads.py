@@ -85,13 +85,20 @@ class HotPath:
     """All device state of one env shard + ``step()`` = one env-step of the hot path."""
 
     def __init__(self, spec: WorkloadSpec, num_envs: int, device, seed: int = 0, log_reward_terms: bool = False,
-                 overlap: bool = False, fused_scaler: bool = True, disc_precision: str = "f16x3"):
+                 overlap: bool = False, fused_scaler: bool = True, disc_precision: str = "f16x3",
+                 expert_stream: bool = False):
         """``overlap``: run the discriminator on a second HIP stream so that the HBM-bound kernels of step t+1
         (motion sample, env step, compaction) execute under the MFMA-bound GEMMs of step t.  The style reward is
         consumed asynchronously in AMP (skrl reads it at the agent update), so nothing waits for it inside a step;
         ``synchronize()`` / ``torch.cuda.synchronize()`` joins both streams.  Bit-identical to the serial schedule
         (tests/test_gpu_disc.py).  Measured on MI355X it is a wash (+1.5 % at 65 536 envs, -10 % at 4 096): the GEMM
-        workgroups already hold every wave slot, so the two streams time-slice instead of overlapping -> default off."""
+        workgroups already hold every wave slot, so the two streams time-slice instead of overlapping -> default off.
+
+        ``expert_stream``: the expert-motion sample (``collect_reference``: the motion dataset's rows, no data
+        dependence on the env state) runs on a side stream forked at the start of the step and joined at its end, i.e.
+        under the env-step / compaction kernels instead of in front of them.  Measured: +1 % at 65 536 envs (both are
+        HBM-bound and share the bandwidth), -22 % at 4 096 envs as a hipGraph (the cross-stream edges cost more than
+        the 12 us kernel) -> default off."""
         self.spec, self.num_envs = spec, int(num_envs)
         self.overlap = bool(overlap)
         self.fused_scaler = bool(fused_scaler) and not self.overlap  # the overlapped schedule needs the snapshot pass
@@ -131,6 +138,10 @@ class HotPath:
                 self._sim.pop(k)
         self.last = None
         self._n = 0
+        self._expert_stream = None
+        if expert_stream:
+            self._expert_stream = torch.cuda.Stream(device=self.device)
+            self._fork, self._join = torch.cuda.Event(), torch.cuda.Event()
         if self.overlap:
             self._disc_stream = torch.cuda.Stream(device=self.device)
             self._obs_ready = torch.cuda.Event()
@@ -155,7 +166,14 @@ class HotPath:
         if self.overlap and self._n > 0:
             # the previous discriminator call must have read amp_obs / reward before this step shifts / rewrites them
             env_stream.wait_event(self._consumed[(self._n - 1) & 1])
-        self.motion.collect_reference(s["motion_times"], s["motion_ids"], self.spec.K, out=self.expert_obs)
+        if self._expert_stream is None:
+            self.motion.collect_reference(s["motion_times"], s["motion_ids"], self.spec.K, out=self.expert_obs)
+        else:
+            self._fork.record(env_stream)
+            with torch.cuda.stream(self._expert_stream):
+                self._expert_stream.wait_event(self._fork)
+                self.motion.collect_reference(s["motion_times"], s["motion_ids"], self.spec.K, out=self.expert_obs)
+                self._join.record(self._expert_stream)
         k.launch(nat.AMP_PHASE_ALL, key_body_indexes=[0, 1, 2, 3], **self._sim)
         k.compact_resets()
         amp = k.amp_observation_buffer.view(self.num_envs, -1)
@@ -169,6 +187,8 @@ class HotPath:
             with torch.cuda.stream(self._disc_stream):
                 self._disc_stream.wait_event(self._obs_ready)
                 self.last = self.disc.style_reward(amp, k.reward, inputs_consumed=self._consumed[slot], workspace_slot=slot)
+        if self._expert_stream is not None:
+            env_stream.wait_event(self._join)  # the step is complete only with its expert rows
         self._n += 1
         return self.last
 
