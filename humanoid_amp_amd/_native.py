@@ -143,6 +143,12 @@ SIGNATURES = {
     "amp_disc_trainer_destroy": (C.c_int, [_vp]),
     "amp_disc_trainer_scaler": (C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_double), _vp]),
     "amp_disc_train_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "amp_ring_create": (C.c_int, [_i64, _i32, C.POINTER(_vp)]),
+    "amp_ring_destroy": (C.c_int, [_vp]),
+    "amp_ring_size": (_i64, [_vp]),
+    "amp_ring_head": (_i64, [_vp]),
+    "amp_ring_append": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
+    "amp_ring_sample": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _i64, _vp, _i64, _vp, _vp]),
     "amp_disc_style_reward_prescaled": (C.c_int, [_vp, _vp, _i64, _f32, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "amp_disc_style_reward": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
 }

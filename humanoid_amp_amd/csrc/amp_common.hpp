@@ -126,6 +126,22 @@ __device__ __forceinline__ Vec3 quat_rotate_inverse_ref(Quat q, Vec3 v) {
   return o;
 }
 
+// ---- Philox4x32-10 (Salmon et al., SC'11; Random123 constants): the engine's counter-based generator; pinned bit for
+// bit by oracle/rng.py, itself pinned by the Random123 known-answer vectors
+__host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t out[4]) {
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+
 // ---- fp16 plane pairs (disc_gemm_f16.hpp; also written by amp_env_step's fused scaler) -----------------------------
 // one (p0, p1) pair per element: p0 = rn16(v), p1 = rn16(v - p0) for a value already multiplied by its plane scale
 __device__ __forceinline__ uint32_t plane_pair(float v) {

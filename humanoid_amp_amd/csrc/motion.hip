@@ -363,19 +363,6 @@ __global__ __launch_bounds__(kBlock) void reset_state_kernel(MotionView v, const
 // how many other envs reset in the same step.  Parity with the reference is distributional only (it uses numpy's
 // global MT19937); bit-exactness is defined against oracle/rng.py.
 // ------------------------------------------------------------------------------------------------
-__host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
-                                              uint32_t out[4]) {
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
 __global__ __launch_bounds__(kBlock) void sample_times_kernel(ClipMeta m, uint64_t seed, uint64_t step, int start,
                                                               const int64_t* __restrict__ index, int64_t n,
                                                               const int64_t* __restrict__ n_dev,

@@ -471,3 +471,57 @@ class AmpDiscriminatorTrainer:
                 self._lib.amp_disc_trainer_destroy(h)
             except Exception:
                 pass
+
+
+# ---------------------------------------------------------------------------------------------------
+# agent-side row stores (skrl RandomMemory: reply_buffer / motion_dataset)
+# ---------------------------------------------------------------------------------------------------
+
+
+class AmpReplayBuffer:
+    """Device ring buffer of AMP observation rows with skrl ``RandomMemory`` semantics [third-party, absent: parity
+    unpinned]: :meth:`add_samples` writes a batch at the write head and wraps around, :meth:`sample` draws
+    ``batch_size`` rows uniformly with replacement from the rows written so far.  Used for skrl AMP's ``reply_buffer``
+    (``amp_replay_buffer_size`` 1 M) and ``motion_dataset`` (``amp_motion_dataset_size`` 200 k,
+    agents/skrl_g1_walk_amp_cfg.yaml:44-58).  Draws are counter-based (Philox keyed by ``seed`` and a per-call draw
+    counter): reproducible and free of host RNG; the row indices are available for inspection."""
+
+    def __init__(self, memory_size: int, row_dim: int, device, seed: int = 0):
+        self.device = nat.require_gpu(device)
+        self._lib = nat.load()
+        self.memory_size, self.row_dim, self.seed = int(memory_size), int(row_dim), int(seed)
+        self._draw = 0
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.amp_ring_create(self.memory_size, self.row_dim, C.byref(h)), "amp_ring_create")
+        self._handle = h
+
+    def __len__(self) -> int:
+        return int(self._lib.amp_ring_size(self._handle))
+
+    @property
+    def memory_index(self) -> int:
+        """Next write position (skrl's attribute name)."""
+        return int(self._lib.amp_ring_head(self._handle))
+
+    def add_samples(self, states: torch.Tensor) -> None:
+        rows = states if states.dim() == 2 else states.reshape(-1, states.shape[-1])
+        ptr, stride = nat.strided_view(rows, self.row_dim, "states")  # any row stride: views are appended without a copy
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.amp_ring_append(self._handle, ptr, rows.shape[0], stride, nat.stream_ptr()), "amp_ring_append")
+
+    def sample(self, batch_size: int, *, out: Optional[torch.Tensor] = None, return_indices: bool = False):
+        """``[batch_size, row_dim]`` rows (into ``out`` if given); each call advances the draw counter."""
+        if out is None:
+            out = torch.empty((batch_size, self.row_dim), device=self.device)
+        idx = torch.empty(batch_size, dtype=torch.int64, device=self.device) if return_indices else None
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.amp_ring_sample(self._handle, self.seed, self._draw, batch_size, nat.dptr(out), int(out.stride(0)),
+                                                nat.dptr(idx), nat.stream_ptr()), "amp_ring_sample")
+        self._draw += 1
+        return (out, idx) if return_indices else out
+
+    def __del__(self):
+        h, self._handle = getattr(self, "_handle", None), None
+        if h is not None and getattr(self, "_lib", None) is not None:
+            self._lib.amp_ring_destroy(h)

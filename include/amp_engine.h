@@ -343,6 +343,23 @@ int amp_disc_trainer_scaler(const AmpDiscTrainer* t, double* mean_out_dev, doubl
 int amp_disc_train_step(AmpDiscTrainer* t, const float* policy_dev, const float* replay_dev, const float* motion_dev,
                         int64_t rows, int64_t row_stride, float* loss_dev, float* grads_dev, amp_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Device ring buffers of AMP observation rows: skrl AMP's `reply_buffer` (1 M rows) and
+ * `motion_dataset` (200 k rows) -- RandomMemory objects [third-party: parity unpinned], sizes
+ * agents/skrl_g1_walk_amp_cfg.yaml:44-58.  add_samples = amp_ring_append (write head wraps), sample(batch) =
+ * amp_ring_sample (uniform with replacement over the rows written so far; counter-based Philox draw keyed by
+ * (seed, draw, row): reproducible, no host RNG).  Appends must be serialised by the caller (one stream).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct AmpRing AmpRing;
+int amp_ring_create(int64_t capacity_rows, int32_t row_dim, AmpRing** out);   /* capacity < 2^32 */
+int amp_ring_destroy(AmpRing* r);
+int64_t amp_ring_size(const AmpRing* r);   /* rows currently valid (min(total appended, capacity)) */
+int64_t amp_ring_head(const AmpRing* r);   /* next write position */
+int amp_ring_append(AmpRing* r, const float* rows_dev, int64_t n, int64_t row_stride, amp_stream_t stream);
+/* out_dev [n, out_stride]; indices_dev [n] optional (the storage rows that were drawn) */
+int amp_ring_sample(const AmpRing* r, uint64_t seed, uint64_t draw, int64_t n, float* out_dev, int64_t out_stride,
+                    int64_t* indices_dev, amp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

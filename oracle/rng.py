@@ -41,3 +41,25 @@ def sample_times(durations: np.ndarray, seed: int, step: int, index: np.ndarray,
     u = ((r1 >> np.uint64(5)).astype(np.float64) * 67108864.0 + (r2 >> np.uint64(6)).astype(np.float64)) / 9007199254740992.0
     times = np.zeros(len(index)) if start else u * np.asarray(durations, dtype=np.float64)[ids]
     return ids, times
+
+
+def ring_sample_indices(size: int, seed: int, draw: int, n: int) -> np.ndarray:
+    """Storage rows csrc/ring.hip::ring_sample_kernel draws: floor(word0(Philox(counter=(i, draw), key=seed)) * size / 2^32)."""
+    i = np.arange(n, dtype=np.uint64)
+    r0, _, _, _ = philox4x32_10(i & MASK, i >> np.uint64(32), draw & 0xFFFFFFFF, (draw >> 32) & 0xFFFFFFFF,
+                                seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    return ((r0 * np.uint64(size)) >> np.uint64(32)).astype(np.int64)
+
+
+class RingOracle:
+    """numpy restatement of skrl RandomMemory.add_samples on one tensor (write head wraps; oldest rows overwritten)."""
+
+    def __init__(self, capacity: int, dim: int):
+        self.rows = np.zeros((capacity, dim), dtype=np.float32)
+        self.capacity, self.head, self.size = capacity, 0, 0
+
+    def add(self, batch: np.ndarray) -> None:
+        for row in batch:
+            self.rows[self.head] = row
+            self.head = (self.head + 1) % self.capacity
+            self.size = min(self.size + 1, self.capacity)

@@ -269,6 +269,17 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
+  if (getenv("XP") && mode == 0) {
+    run_dma<0, 0>(g, M, N, K, false);
+    printf("  ^ layer-1 LDS-DMA kernel, full\n");
+    run_dma<0, 3>(g, M, N, K, false);
+    printf("  ^ no global stores in the epilogue\n");
+    run_dma<0, 4>(g, M, N, K, false);
+    printf("  ^ one k-step only: epilogue + stores\n");
+    run_dma<0, 1>(g, M, N, K, false);
+    printf("  ^ no fills in the loop\n");
+    return 0;
+  }
   if (getenv("XP") && mode == 1) {
     printf("experiments on 128x128x64 w2 (wrong results by construction):\n");
     run<2, 2, 64, 1, 2, 1, 0>(g, M, N, K, false);
