@@ -93,6 +93,17 @@ class AmpEnvBuffers(C.Structure):
     ]
 
 
+class AmpKinModel(C.Structure):
+    _fields_ = [("n_joints", C.c_int32), ("n_dof", C.c_int32), ("n_bodies", C.c_int32), ("reserved", C.c_int32),
+                ("parent", C.c_void_p), ("qidx", C.c_void_p), ("origin_rot", C.c_void_p), ("origin_xyz", C.c_void_p),
+                ("axis", C.c_void_p), ("body_joint", C.c_void_p)]
+
+
+class AmpConvertOutputs(C.Structure):
+    _fields_ = [("dof_positions", C.c_void_p), ("dof_velocities", C.c_void_p), ("body_positions", C.c_void_p),
+                ("body_rotations", C.c_void_p), ("body_linear_velocities", C.c_void_p), ("body_angular_velocities", C.c_void_p)]
+
+
 class AmpDiscInputLayout(C.Structure):
     _fields_ = [("format", C.c_int32), ("padded_dim", C.c_int32), ("mean_dev", C.c_void_p), ("den_dev", C.c_void_p),
                 ("clip", C.c_float), ("plane_scale", C.c_float)]
@@ -143,6 +154,10 @@ SIGNATURES = {
     "amp_disc_trainer_destroy": (C.c_int, [_vp]),
     "amp_disc_trainer_scaler": (C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_double), _vp]),
     "amp_disc_train_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "amp_converter_create": (C.c_int, [C.POINTER(AmpKinModel), C.POINTER(_vp)]),
+    "amp_converter_destroy": (C.c_int, [_vp]),
+    "amp_convert_workspace_bytes": (_i64, [_vp, _i64]),
+    "amp_convert_motion": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, C.POINTER(AmpConvertOutputs), _vp, _vp]),
     "amp_ring_create": (C.c_int, [_i64, _i32, C.POINTER(_vp)]),
     "amp_ring_destroy": (C.c_int, [_vp]),
     "amp_ring_size": (_i64, [_vp]),

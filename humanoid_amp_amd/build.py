@@ -8,7 +8,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["core.hip", "motion.hip", "env_step.hip", "compact.hip", "disc.hip", "disc_train.hip", "ring.hip"]
+SOURCES = ["core.hip", "motion.hip", "env_step.hip", "compact.hip", "disc.hip", "disc_train.hip", "ring.hip", "convert.hip"]
 HEADERS = ["amp_common.hpp", "disc_gemm.hpp", "disc_gemm_f16.hpp", "disc_gemm_f16_dma.hpp", os.path.join("..", "..", "include", "amp_engine.h")]
 LIB = os.path.join(CSRC, "libamp_engine.so")
 # -ffp-contract=off: the reference's fp32 op order (separate mul/sub in sqrt(1 - c*c), rounded quaternion dot)

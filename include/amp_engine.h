@@ -360,6 +360,42 @@ int amp_ring_append(AmpRing* r, const float* rows_dev, int64_t n, int64_t row_st
 int amp_ring_sample(const AmpRing* r, uint64_t seed, uint64_t draw, int64_t n, float* out_dev, int64_t out_stride,
                     int64_t* indices_dev, amp_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * CSV -> npz motion converter  (replaces motions/data_convert.py:161-390: 30 -> 60 fps
+ * up-sampling, forward kinematics, finite-difference + Gaussian-smoothed velocities, quaternion-difference angular
+ * velocities).  The kinematic model is the URDF's joint tree (tools/urdf_to_kinematics.py), host arrays, joints in
+ * parent-before-child order.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct AmpConverter AmpConverter;
+typedef struct {
+  int32_t n_joints;          /* all joints of the tree, fixed ones included (<= 64) */
+  int32_t n_dof;             /* joint-angle columns of the CSV (29 for the G1) */
+  int32_t n_bodies;          /* links to record */
+  int32_t reserved;
+  const int32_t* parent;     /* [n_joints] joint whose child link is this joint's parent link, -1 = root link */
+  const int32_t* qidx;       /* [n_joints] angle column of a revolute joint, -1 = fixed */
+  const double* origin_rot;  /* [n_joints, 9] row-major rotation of the joint origin (URDF rpy) */
+  const double* origin_xyz;  /* [n_joints, 3] */
+  const double* axis;        /* [n_joints, 3] unit axis of a revolute joint */
+  const int32_t* body_joint; /* [n_bodies] joint whose child link is the body, -1 = root link */
+} AmpKinModel;
+typedef struct {             /* device outputs, N = 2 * n_rows - 1 frames (the npz schema, motions/README.md:11-21) */
+  double* dof_positions;           /* [N, n_dof] */
+  double* dof_velocities;          /* [N, n_dof] */
+  float* body_positions;           /* [N, n_bodies, 3] */
+  float* body_rotations;           /* [N, n_bodies, 4] (w, x, y, z) */
+  float* body_linear_velocities;   /* [N, n_bodies, 3] */
+  float* body_angular_velocities;  /* [N, n_bodies, 3] */
+} AmpConvertOutputs;
+int amp_converter_create(const AmpKinModel* model, AmpConverter** out);
+int amp_converter_destroy(AmpConverter* c);
+int64_t amp_convert_workspace_bytes(const AmpConverter* c, int64_t n_rows);
+/* csv_dev [n_rows, 7 + n_dof] float32: root xyz, root quaternion (x, y, z, w), joint angles, sampled at 30 fps.
+ * numpy1_promotion selects which numpy generation's scalar arithmetic the angular-velocity step reproduces
+ * (0: numpy >= 2, the reference's G1_walk.npz; 1: numpy < 2, its custom_motion.npz). */
+int amp_convert_motion(const AmpConverter* c, const float* csv_dev, int64_t n_rows, int32_t n_cols, int32_t fps_out,
+                       int32_t numpy1_promotion, const AmpConvertOutputs* out, void* workspace_dev, amp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
