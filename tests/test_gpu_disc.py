@@ -165,10 +165,13 @@ def test_graph_replay_matches_eager():
 
 
 @pytest.mark.parametrize("precision,bar", [("f16x3", 1e-6), ("f32", 1e-6)])
-@pytest.mark.parametrize("in_dim,rows", [(166, 4096), (830, 777), (162, 70000)])
+@pytest.mark.parametrize("in_dim,rows", [(166, 4096), (830, 777), (162, 70000), (166, 20000), (166, 30001), (830, 49153)])
 def test_gemm_engines_vs_fp64(precision, bar, in_dim, rows):
     """Both GEMM engines (fp16-split default, fp32 MFMA) must be as accurate as an fp32 forward: <= 1e-6 against the
-    fp64 evaluation of the same fp32 weights on O(1) logits, a tenth of the path's 1e-5 budget."""
+    fp64 evaluation of the same fp32 weights on O(1) logits, a tenth of the path's 1e-5 budget.  The row counts walk
+    through every kernel selection of the fp16 engine: 64 x 64 tiles (4 096, 777), 128 x 128 register-staged (20 000),
+    one 256 x 256 LDS-DMA launch with a ragged last tile (30 001), 32 768-row chunks with a short last chunk (49 153,
+    70 000).  Checked rows: the first 2 048 and the LAST 2 048 (ragged tiles / last chunk)."""
     from humanoid_amp_amd.engine import AmpDiscriminator
 
     g = torch.Generator().manual_seed(in_dim + rows)
@@ -180,7 +183,7 @@ def test_gemm_engines_vs_fp64(precision, bar, in_dim, rows):
     d = AmpDiscriminator([(p.cuda(), q.cuda()) for p, q in w], "cuda:0", running_mean=mean, running_variance=var,
                          task_reward_weight=0.5, style_reward_weight=0.5, precision=precision)
     out = d.style_reward(x.cuda(), task.cuda(), want_logits=True)
-    sub = slice(0, min(rows, 4096))
+    sub = torch.cat([torch.arange(0, min(rows, 2048)), torch.arange(max(rows - 2048, 0), rows)]).unique()
     ref = odisc.forward(w, x[sub], mean, var, task=task[sub], task_w=0.5, style_w=0.5)
     with torch.no_grad():
         lg64 = odisc.logits(w, ref["scaled"], dtype=torch.float64)
