@@ -135,38 +135,47 @@ static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * 
 
 // ---- fp16-split path: ranges, plane scales, input split ------------------------------------------------------------
 
-// One workgroup: max |W1|, max_j sum_k |W1[j,k]|, max |b1|, max |W2| -> DiscRange (runs when the weights change).
-__global__ __launch_bounds__(1024) void disc_weight_range_kernel(const float* __restrict__ w1p, int h1, int k1p,
-                                                                 const float* __restrict__ b1, const float* __restrict__ w2,
-                                                                 int h2, DiscRange* __restrict__ out) {
-  __shared__ float red[4][1024];
-  const int t = threadIdx.x;
-  float wmax1 = 0.0f, rsum = 0.0f, bmax = 0.0f, wmax2 = 0.0f;
-  for (int j = t; j < h1; j += 1024) {
+// max |W1|, max_j sum_k |W1[j,k]|, max |b1|, max |W2| -> DiscRange (runs whenever the weights change, i.e. after every
+// training step).  Non-negative floats order like their bit patterns, so the four maxima are atomicMax on uints
+// (order-independent: deterministic) into the record's first four slots, zeroed beforehand; a one-thread kernel then
+// turns max |W| into plane scales in place.  One wave per W1 row, grid-stride over W2.
+__global__ __launch_bounds__(kBlock) void disc_weight_range_kernel(const float* __restrict__ w1p, int h1, int k1p,
+                                                                   const float* __restrict__ b1, const float* __restrict__ w2,
+                                                                   int64_t n2, DiscRange* __restrict__ out) {
+  unsigned* slot = reinterpret_cast<unsigned*>(out);  // [0] max |W1|, [1] max |W2|, [2] max row sum, [3] max |b1|
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
+  float wmax1 = 0.0f, rsum_max = 0.0f, bmax = 0.0f, wmax2 = 0.0f;
+  for (int64_t j = wave; j < h1; j += n_waves) {
     float rs = 0.0f;
-    for (int k = 0; k < k1p; ++k) {
-      const float a = fabsf(w1p[(int64_t)j * k1p + k]);
+    for (int k = lane; k < k1p; k += 64) {
+      const float a = fabsf(w1p[j * k1p + k]);
       wmax1 = fmaxf(wmax1, a);
       rs += a;
     }
-    rsum = fmaxf(rsum, rs);
-    bmax = fmaxf(bmax, fabsf(b1[j]));
-  }
-  for (int64_t e = t; e < (int64_t)h2 * h1; e += 1024) wmax2 = fmaxf(wmax2, fabsf(w2[e]));
-  red[0][t] = wmax1; red[1][t] = rsum; red[2][t] = bmax; red[3][t] = wmax2;
-  __syncthreads();
-  for (int o = 512; o > 0; o >>= 1) {
-    if (t < o)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) red[q][t] = fmaxf(red[q][t], red[q][t + o]);
-    __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) rs += __shfl_xor(rs, o, 64);
+    rsum_max = fmaxf(rsum_max, rs);
+    if (lane == 0) bmax = fmaxf(bmax, fabsf(b1[j]));
   }
-  if (t == 0) {
-    out->s_w1 = plane_scale(red[0][0]);
-    out->s_w2 = plane_scale(red[3][0]);
-    out->wsum1 = red[1][0] * 1.0001f;  // the row sums were rounded: keep the bound a bound
-    out->bmax1 = red[2][0];
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n2; e += (int64_t)gridDim.x * kBlock) wmax2 = fmaxf(wmax2, fabsf(w2[e]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    wmax1 = fmaxf(wmax1, __shfl_xor(wmax1, o, 64));
+    wmax2 = fmaxf(wmax2, __shfl_xor(wmax2, o, 64));
+    bmax = fmaxf(bmax, __shfl_xor(bmax, o, 64));
   }
+  if (lane == 0) {
+    atomicMax(slot + 0, __float_as_uint(wmax1));
+    atomicMax(slot + 1, __float_as_uint(wmax2));
+    atomicMax(slot + 2, __float_as_uint(rsum_max));
+    atomicMax(slot + 3, __float_as_uint(bmax));
+  }
+}
+__global__ void disc_weight_range_finish_kernel(DiscRange* r) {
+  r->s_w1 = plane_scale(r->s_w1);
+  r->s_w2 = plane_scale(r->s_w2);
+  r->wsum1 *= 1.0001f;  // the row sums were rounded (and summed in lane order): keep the bound a bound
 }
 
 __global__ void disc_set_clip_kernel(DiscRange* r, float clip) { r->clip = clip; }
@@ -378,8 +387,10 @@ static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* a
 
 // weights (or the scaler) changed: ranges, plane scales and the fp16 planes of W1 / W2
 static int f16_refresh(AmpDisc* h, hipStream_t st) {
+  AMP_HIP(hipMemsetAsync(h->range, 0, 4 * sizeof(float), st));  // the four maxima (the clamp behind them stays)
   { amp::TraceScope trace__("disc_weight_range_kernel", st);
-    disc_weight_range_kernel<<<1, 1024, 0, st>>>(h->w1p, h->h1, h->k1p, h->b1, h->w2, h->h2, h->range);
+    disc_weight_range_kernel<<<256, kBlock, 0, st>>>(h->w1p, h->h1, h->k1p, h->b1, h->w2, (int64_t)h->h2 * h->h1, h->range);
+    disc_weight_range_finish_kernel<<<1, 1, 0, st>>>(h->range);
   }
   int rc = launch_status("disc_weight_range_kernel");
   if (rc != AMP_OK) return rc;
