@@ -54,7 +54,8 @@ def test_struct_layouts_match_the_header(tmp_path):
 
     structs = {"AmpMotionDesc": nat.AmpMotionDesc, "AmpEnvCfg": nat.AmpEnvCfg, "AmpSimState": nat.AmpSimState,
                "AmpEnvBuffers": nat.AmpEnvBuffers, "AmpDiscDesc": nat.AmpDiscDesc, "AmpDiscInputLayout": nat.AmpDiscInputLayout,
-               "AmpResetArgs": nat.AmpResetArgs, "AmpDiscTrainCfg": nat.AmpDiscTrainCfg}
+               "AmpResetArgs": nat.AmpResetArgs, "AmpDiscTrainCfg": nat.AmpDiscTrainCfg, "AmpKinModel": nat.AmpKinModel,
+               "AmpConvertOutputs": nat.AmpConvertOutputs}
     lines = ["#include <stddef.h>", "#include <stdio.h>", '#include "amp_engine.h"', "int main(void) {"]
     for name, cls in structs.items():
         lines.append(f'  printf("{name} %zu\\n", sizeof({name}));')
