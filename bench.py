@@ -53,6 +53,25 @@ def parse_args():
     return ap.parse_args()
 
 
+def settle(hot, max_seconds=4.0, block=20):
+    """Untimed pre-warm-up: a fresh box (first process after the image is paged in, clocks ramping, other tenants on the
+    host) can run the first seconds at a fraction of the steady rate.  Blocks of `block` steps are run until two
+    consecutive blocks are within 5 % of the fastest block seen (bounded by max_seconds); no collectives, so ranks may
+    leave at different block counts.  The contract's W warm-up steps and K timed steps follow unchanged."""
+    best, t_end, stable = float("inf"), time.perf_counter() + max_seconds, 0
+    while time.perf_counter() < t_end:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(block):
+            hot.step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = min(best, dt)
+        stable = stable + 1 if dt <= 1.05 * best else 0
+        if stable >= 2:
+            break
+
+
 def timed_steps(hot, steps, warmup, world, collective):
     import torch.distributed as dist
 
@@ -199,6 +218,7 @@ def main():
         collective = {"every": args.rollouts, "fn": lambda: [ag.start() for _ in range(args.minibatches)], "join": ag.wait_all}
 
     # ---- timed region: exactly --steps steps, the dominant kernel bracketed by HIP events on its stream --------
+    settle(hot)
     with nat.KernelTrace(capacity=4 * (args.steps + args.warmup) + 8, kernel_filter=dominant) as tr:
         dt = timed_steps(hot, args.steps, args.warmup, world, collective)
     # the engine may run a large shard as several row chunks: launches per step = records / steps over the timed region
@@ -271,6 +291,7 @@ def main():
             hot_s = HotPath(spec, 4096, device, seed=99 + rank)
         if not args.no_graph:
             hot_s.capture()  # a 4096-env step is launch-bound: replay it as one hipGraph
+        settle(hot_s, max_seconds=2.0)
         dts = timed_steps(hot_s, max(args.steps, 50), args.warmup, world, None)
         if rank == 0:
             out["envs_4096"] = {"value": 4096 * world * max(args.steps, 50) / dts, "unit": "env-steps/s",
@@ -283,6 +304,7 @@ def main():
         torch.cuda.empty_cache()
         with contextlib.redirect_stdout(sys.stderr):
             hot_m = HotPath(spec, args.envs, device, seed=1234 + rank, disc_precision="f32")
+        settle(hot_m)
         with nat.KernelTrace(capacity=args.steps + args.warmup + 8, kernel_filter=DOMINANT_KERNEL["f32"]) as trm:
             dtm = timed_steps(hot_m, args.steps, args.warmup, world, None)
         rm = trm.records()[-args.steps:]

@@ -44,6 +44,8 @@ struct AmpDisc {
   int32_t k1h;        // in_dim padded to the fp16 k-tile
   _Float16* w1h;      // [2][h1][k1h] planes of s_w1 * W1
   _Float16* w2h;      // [2][h2][h1]  planes of s_w2 * W2
+  _Float16* w1b;      // the same planes in block layout [h1][k1h / 32][2][32] (LDS-DMA kernels)
+  _Float16* w2b;      // [h2][h1 / 32][2][32]
   DiscRange* range;   // device
 };
 
@@ -317,7 +319,7 @@ static int f16_kernels_init() {
 // resident).  32 768 rows = 134 MB, and 128 x 2 layer-2 tiles = one workgroup per CU.
 constexpr int64_t kChunkRows = 32768;
 static bool f16_use_dma(const AmpDisc* h, int64_t rows) {  // 256 x 256 LDS-DMA kernel: needs >= ~1 tile per CU
-  return h->h2 % kDmaBN == 0 && (rows + kDmaBM - 1) / kDmaBM * (h->h2 / kDmaBN) >= 192;
+  return h->h1 % kDmaBN == 0 && h->h2 % kDmaBN == 0 && (rows + kDmaBM - 1) / kDmaBM * (h->h2 / kDmaBN) >= 192;
 }
 static int64_t f16_chunk_rows(const AmpDisc* h, int64_t rows) {
   return f16_use_dma(h, kChunkRows) && rows > kChunkRows + kChunkRows / 2 ? kChunkRows : rows;
@@ -331,9 +333,9 @@ static int f16_n_tiles(const AmpDisc* h, int64_t rows) {
 static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* amax, int64_t rows, _Float16* H1p, float* partial,
                             float scale, const float* task, float task_w, float style_w, float* logits, float* style,
                             float* combined, hipStream_t st) {
-  // Tile choice measured with tools/gemm_f16_bench.hip (profiles/r01_gemm_f16_variants.txt): layer 1 (k = 192, store
-  // bound) 128 x 128 x 32 at 3 workgroups / CU; layer 2 the 256 x 256 LDS-DMA kernel when a chunk fills the chip,
-  // else 128 x 128 x 64 at 2 workgroups / CU; shards with < 512 such tiles use 64 x 64
+  // Kernel choice measured with tools/gemm_f16_bench.hip (profiles/r01_gemm_f16_variants.txt): the 256 x 256 LDS-DMA
+  // kernels (block-layout operands) for both layers when a chunk fills the chip; else the register-staged kernels on
+  // planar operands: 128 x 128 (x 32 at 3 workgroups / CU for layer 1, x 64 at 2 for layer 2), 64 x 64 below 512 such tiles
   const int64_t chunk = f16_chunk_rows(h, rows);
   const int n_tiles = f16_n_tiles(h, rows);
   int rc = AMP_OK;
@@ -345,7 +347,10 @@ static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* a
     g1.W = h->w1h; g1.plane_w = (int64_t)h->h1 * h->k1h; g1.Kp = h->k1h; g1.N = h->h1;
     g1.bias = h->b1; g1.range = h->range; g1.amax = amax; g1.layer = 1;
     g1.H = H1p + r0 * h->h1; g1.ldh = h->h1; g1.plane_h = rows * h->h1;
-    if (f16_use_dma(h, chunk) && h->h1 % kDmaBN == 0) {
+    const bool dma = f16_use_dma(h, chunk);  // both layers or neither: it decides the hidden layer's layout
+    if (dma) {
+      g1.W = h->w1b;               // block layout; the hidden layer comes out in block layout too (row pitch 2 * h1)
+      g1.H = H1p + 2 * r0 * h->h1;
       g1.n_tiles = h->h1 / kDmaBN;
       g1.m_tiles = (int)((m + kDmaBM - 1) / kDmaBM);
       const unsigned grid = (unsigned)(((int64_t)g1.m_tiles * g1.n_tiles + 7) / 8 * 8);
@@ -364,7 +369,9 @@ static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* a
     g2.W = h->w2h; g2.plane_w = (int64_t)h->h2 * h->h1; g2.Kp = h->h1; g2.N = h->h2;
     g2.bias = h->b2; g2.range = h->range; g2.amax = amax; g2.layer = 2;
     g2.w3 = h->w3; g2.partial = partial + r0 * n_tiles;
-    if (n_tiles == h->h2 / kDmaBN && f16_use_dma(h, chunk)) {  // every chunk (a short last one too): one partial layout
+    if (dma) {  // every chunk (a short last one too): one partial layout
+      g2.A = H1p + 2 * r0 * h->h1;
+      g2.W = h->w2b;
       g2.n_tiles = n_tiles;
       g2.m_tiles = (int)((m + kDmaBM - 1) / kDmaBM);
       const unsigned grid = (unsigned)(((int64_t)g2.m_tiles * g2.n_tiles + 7) / 8 * 8);
@@ -400,6 +407,10 @@ static int f16_refresh(AmpDisc* h, hipStream_t st) {
                                                                                         h->w1h, h->k1h, n1);
     split_rows_f16_kernel<<<(unsigned)((n2 / 4 + kBlock - 1) / kBlock), kBlock, 0, st>>>(h->w2, h->h2, h->h1, h->h1, &h->range->s_w2,
                                                                                         h->w2h, h->h1, n2);
+    split_rows_blocks_kernel<<<(unsigned)((n1 / 4 + kBlock - 1) / kBlock), kBlock, 0, st>>>(h->w1p, h->h1, h->k1p, h->k1p, &h->range->s_w1,
+                                                                                           h->w1b, h->k1h);
+    split_rows_blocks_kernel<<<(unsigned)((n2 / 4 + kBlock - 1) / kBlock), kBlock, 0, st>>>(h->w2, h->h2, h->h1, h->h1, &h->range->s_w2,
+                                                                                           h->w2b, h->h1);
   }
   return launch_status("split_rows_f16_kernel");
 }
@@ -434,6 +445,8 @@ int amp_disc_destroy(AmpDisc* h) {
   (void)hipFree(h->den);
   (void)hipFree(h->w1h);
   (void)hipFree(h->w2h);
+  (void)hipFree(h->w1b);
+  (void)hipFree(h->w2b);
   (void)hipFree(h->range);
   delete h;
   return AMP_OK;
@@ -465,6 +478,8 @@ int amp_disc_create(const AmpDiscDesc* d, amp_stream_t stream, AmpDisc** out) {
   if (e == hipSuccess) e = hipMalloc(&h->den, sizeof(float) * h->k1p);
   if (e == hipSuccess) e = hipMalloc(&h->w1h, sizeof(_Float16) * 2 * (size_t)h->h1 * h->k1h);
   if (e == hipSuccess) e = hipMalloc(&h->w2h, sizeof(_Float16) * 2 * (size_t)h->h2 * h->h1);
+  if (e == hipSuccess) e = hipMalloc(&h->w1b, sizeof(_Float16) * 2 * (size_t)h->h1 * h->k1h);
+  if (e == hipSuccess) e = hipMalloc(&h->w2b, sizeof(_Float16) * 2 * (size_t)h->h2 * h->h1);
   if (e == hipSuccess) e = hipMalloc(&h->range, sizeof(DiscRange));
   if (e == hipSuccess) e = hipMemsetAsync(h->range, 0, sizeof(DiscRange), st);
   if (e == hipSuccess) e = hipMemcpyAsync(h->b1, d->b1, sizeof(float) * h->h1, hipMemcpyDeviceToDevice, st);

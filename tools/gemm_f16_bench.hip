@@ -59,6 +59,64 @@ __global__ __launch_bounds__(256) void store_only_kernel(_Float16* out, int64_t 
   }
 }
 
+// Fill-path probe: one 512-thread workgroup per CU streams its 256-row A slab and the shared 256-row B slab into
+// LDS by LDS-DMA exactly like disc_gemm_f16_dma_kernel (4 x 32-KB ring, counted vmcnt, one barrier per k-step) but
+// computes nothing.  SEG = bytes a piece takes from one row: 32 (k-step 16), 64 or 128.
+template <int SEG>
+__global__ __launch_bounds__(512, 1) void fill_probe_kernel(const _Float16* A, int64_t lda, int64_t plane_a, const _Float16* W, int Kp,
+                                                            int64_t plane_w, int m_tiles, float* sink) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per_xcd = (m_tiles * 2 + 7) / 8;
+  const int v = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (v >= m_tiles * 2) return;
+  const int mt = v >> 1, nt = v & 1;
+  constexpr int ROWS = 1024 / SEG;            // rows per piece
+  constexpr int CH = SEG / 16;                // 16-B chunks per row segment
+  constexpr int KSTEP = SEG / 2;              // halves per row segment = k extent of one ring slot
+  // ring slot = 4 planes x 256 rows x SEG bytes; pieces per plane = 256 / ROWS; 8 waves share them
+  constexpr int PPP = 256 / ROWS, PPW = 4 * PPP / 8;  // pieces per plane / per wave per slot
+  const int nslots = Kp / KSTEP;
+  auto issue = [&](int p, int slot) {
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      const int q = j * 8 + wave, plane = q / PPP, piece = q % PPP;
+      const int r = piece * ROWS + lane / CH, c = lane % CH;
+      const _Float16* src = plane < 2 ? A + plane * plane_a + ((int64_t)mt * 256 + r) * lda + p * KSTEP + 8 * c
+                                      : W + (plane - 2) * plane_w + ((int64_t)nt * 256 + r) * Kp + p * KSTEP + 8 * c;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + (slot % (131072 / (1024 * SEG))) * (1024 * SEG) + q * 1024), 16, 0, 0);
+    }
+  };
+  constexpr int RING = 131072 / (1024 * SEG);  // slots in 128 KB
+  for (int p = 0; p < RING - 1 && p < nslots; ++p) issue(p, p);
+  for (int p = 0; p < nslots; ++p) {
+    if (p + RING - 1 < nslots) issue(p + RING - 1, p + RING - 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  if (tid == 0) sink[blockIdx.x] = reinterpret_cast<float*>(lds)[lane];
+}
+
+template <int SEG>
+static void fill_probe(const _Float16* Ap, int64_t M, int K, const _Float16* Wp, int N, float* sink) {
+  const int m_tiles = (int)(M / 256);
+  const unsigned grid = (unsigned)((m_tiles * 2 + 7) / 8 * 8);
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(fill_probe_kernel<SEG>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a));
+  CK(hipEventCreate(&b));
+  fill_probe_kernel<SEG><<<grid, 512, 131072>>>(Ap, K, M * K, Wp, K, (int64_t)N * K, m_tiles, sink);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(a));
+  for (int i = 0; i < 5; ++i) fill_probe_kernel<SEG><<<grid, 512, 131072>>>(Ap, K, M * K, Wp, K, (int64_t)N * K, m_tiles, sink);
+  CK(hipEventRecord(b));
+  CK(hipEventSynchronize(b));
+  float ms;
+  CK(hipEventElapsedTime(&ms, a, b));
+  const double bytes = (double)m_tiles * 2 * 2.0 * 256 * K * 2 * 2;  // per workgroup: A slab + B slab, 2 planes each
+  printf("fill probe, %3d B per row segment: %8.1f us  %.2f TB/s into LDS (%.0f MB)\n", SEG, ms * 200, bytes / (ms / 5 * 1e-3) / 1e12, bytes / 1e6);
+}
+
 template <int ACCS>
 static void calib(float* out, int blocks_per_cu, int iters) {
   const int grid = 256 * blocks_per_cu;
@@ -111,8 +169,14 @@ static void run(GemmF16Args g, int64_t M, int N, int K, bool quiet) {
   }
 }
 
+static _Float16 *g_Ab = nullptr, *g_Wb = nullptr;
+static bool g_dma_last = false;  // the last kernel run wrote H in block layout (check() must index accordingly)
+
 template <int MODE, int XP = 0>
 static void run_dma(GemmF16Args g, int64_t M, int N, int K, bool quiet) {
+  if (MODE == 1) g.A = g_Ab;  // block layout; MODE 0 reads the (p0, p1) pairs as they are
+  g.W = g_Wb;
+  g_dma_last = true;
   g.n_tiles = N / kDmaBN;
   g.m_tiles = (int)((M + kDmaBM - 1) / kDmaBM);
   const unsigned grid = (unsigned)(((int64_t)g.m_tiles * g.n_tiles + 7) / 8 * 8);
@@ -132,7 +196,7 @@ static void run_dma(GemmF16Args g, int64_t M, int N, int K, bool quiet) {
   g_us = ms * 1e3 / reps;
   if (!quiet) {
     const double tf = 2.0 * M * N * K / (g_us * 1e-6) / 1e12;
-    printf("LDS-DMA 256x256x16, 4 stages, 512 threads            %8.1f us   %6.1f TF(alg)  %.3f of fp16 peak executed\n", g_us, tf, 3 * tf / 2516.6);
+    printf("LDS-DMA 256x256x32 blocks, 2 stages, 512 thr            %8.1f us   %6.1f TF(alg)  %.3f of fp16 peak executed\n", g_us, tf, 3 * tf / 2516.6);
     fflush(stdout);
   }
 }
@@ -164,12 +228,14 @@ int main(int argc, char** argv) {
   const float sh = plane_scale(100.0f);
   float *A, *W, *b, *w3, *P, *one;
   DiscRange* sc;
-  _Float16 *Ap, *Wp, *Hp;
+  _Float16 *Ap, *Wp, *Hp, *Ab, *Wb;  // planar (register-staged kernels) and block layout (LDS-DMA kernels)
   CK(hipMalloc(&A, hA.size() * 4));
   CK(hipMalloc(&W, hW.size() * 4));
   CK(hipMalloc(&Ap, hA.size() * 4));
   CK(hipMalloc(&Wp, hW.size() * 4));
   CK(hipMalloc(&Hp, (size_t)M * N * 4));
+  CK(hipMalloc(&Ab, hA.size() * 4));
+  CK(hipMalloc(&Wb, hW.size() * 4));
   CK(hipMalloc(&b, N * 4));
   CK(hipMalloc(&w3, N * 4));
   CK(hipMalloc(&P, (size_t)M * 16 * 4));
@@ -185,12 +251,17 @@ int main(int argc, char** argv) {
   if (mode == 0) split_rows_pairs_kernel<<<(unsigned)((M * K / 4 + 255) / 256), 256>>>(A, M, K, K, one, (uint32_t*)Ap, K);
   else split_rows_f16_kernel<<<(unsigned)((M * K / 4 + 255) / 256), 256>>>(A, M, K, K, one, Ap, K, M * K);
   split_rows_f16_kernel<<<(unsigned)(((int64_t)N * K / 4 + 255) / 256), 256>>>(W, N, K, K, one + 1, Wp, K, (int64_t)N * K);
+  if (mode == 1) split_rows_blocks_kernel<<<(unsigned)((M * K / 4 + 255) / 256), 256>>>(A, M, K, K, one, Ab, K);
+  split_rows_blocks_kernel<<<(unsigned)(((int64_t)N * K / 4 + 255) / 256), 256>>>(W, N, K, K, one + 1, Wb, K);
   CK(hipDeviceSynchronize());
   GemmF16Args g{};
   g.A = Ap; g.lda = K; g.plane_a = M * K; g.M = M; g.W = Wp; g.plane_w = (int64_t)N * K; g.Kp = K; g.N = N;
   g.bias = b; g.range = sc; g.amax = nullptr; g.layer = mode == 0 ? 1 : 2; g.H = Hp; g.ldh = N; g.plane_h = M * N; g.w3 = w3; g.partial = P;
 
+  g_Ab = Ab; g_Wb = Wb;
   auto check = [&](int n_tiles) {
+    const bool blocks = g_dma_last;
+    g_dma_last = false;
     const int rows = 64;
     double worst = 0, scale = 0;
     if (mode == 1) {
@@ -217,7 +288,9 @@ int main(int argc, char** argv) {
           double d = hb[n];
           for (int k = 0; k < K; ++k) d += (double)hA[m * K + k] * hW[(size_t)n * K + k];
           const double ref = std::max(d, 0.0);
-          const double got = ((double)(float)hh[m * N + n] + (double)(float)hh[(size_t)M * N + m * N + n]) / sh;
+          const size_t o0 = blocks ? (size_t)m * 2 * N + (size_t)(n >> 5) * 64 + (n & 31) : (size_t)m * N + n;
+          const size_t o1 = blocks ? o0 + 32 : (size_t)M * N + m * N + n;
+          const double got = ((double)(float)hh[o0] + (double)(float)hh[o1]) / sh;
           worst = std::max(worst, std::fabs(got - ref));
           scale = std::max(scale, std::fabs(ref));
         }
@@ -269,6 +342,13 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
+  if (getenv("FILL") && mode == 1) {
+    fill_probe<32>(Ap, M, K, Wp, N, P);
+    fill_probe<64>(Ap, M, K, Wp, N, P);
+    fill_probe<128>(Ap, M, K, Wp, N, P);
+    fill_probe<32>(Ap, M, K, Wp, N, P);
+    return 0;
+  }
   if (getenv("XP") && mode == 0) {
     run_dma<0, 0>(g, M, N, K, false);
     printf("  ^ layer-1 LDS-DMA kernel, full\n");
@@ -306,7 +386,7 @@ int main(int argc, char** argv) {
   V(1, 1, 32, 6, 2); check(N / 64);
   V(1, 1, 64, 4, 2); check(N / 64);
   quiet = true;
-  const char* names[8] = {"128x128x32 w3 pf1", "128x128x64 w2 pf1", "128x128x32 w3 pf2", "128x128x32 w2 pf2", "64x64x64 w4 pf1", "64x64x32 w6 pf2", "64x64x64 w4 pf2", "LDS-DMA 256x256x16"};
+  const char* names[8] = {"128x128x32 w3 pf1", "128x128x64 w2 pf1", "128x128x32 w3 pf2", "128x128x32 w2 pf2", "64x64x64 w4 pf1", "64x64x32 w6 pf2", "64x64x64 w4 pf2", "LDS-DMA 256x256x32"};
   std::vector<std::vector<double>> t(8);
   for (int r = 0; r < 5; ++r) {
     V(2, 2, 32, 3, 1); t[0].push_back(g_us);
