@@ -213,9 +213,11 @@ def main():
     if world > 1:
         # the gathered minibatches feed the (out-of-scope) discriminator update, so nothing in the env path waits for
         # them: they are launched asynchronously (RCCL stream) and joined before the timed region ends
+        # one agent update = `minibatches` discriminator minibatches: their replay rows are drawn together and gathered
+        # by ONE collective of [minibatches * replay_minibatch, K*D] per rank (same bytes as one gather per minibatch)
         ag = ReplayAllGather(hot.kernel.amp_observation_buffer.view(args.envs, -1), args.replay_minibatch, seed=rank,
-                             slots=args.minibatches)
-        collective = {"every": args.rollouts, "fn": lambda: [ag.start() for _ in range(args.minibatches)], "join": ag.wait_all}
+                             slots=2, minibatches=args.minibatches)
+        collective = {"every": args.rollouts, "fn": ag.start, "join": ag.wait_all}
 
     # ---- timed region: exactly --steps steps, the dominant kernel bracketed by HIP events on its stream --------
     settle(hot)
@@ -265,9 +267,10 @@ def main():
             "config": {"workload": f"{spec.description}, {args.envs} envs per GPU, synthetic joint states, discriminator "
                                    f"[{spec.K * spec.D},1024,512,1] seed-0 init", "envs_per_gpu": args.envs,
                        "global_envs": args.envs * world, "parallelism": f"env-shard x{world}",
-                       "collective": (f"RCCL all-gather [{args.replay_minibatch},{spec.K * spec.D}] f32 per rank x "
-                                      f"{args.minibatches} every {args.rollouts} steps, async on the RCCL stream, joined inside "
-                                      "the timed region") if world > 1 else "none"},
+                       "collective": (f"one RCCL all-gather of [{args.minibatches} x {args.replay_minibatch},{spec.K * spec.D}] f32 per "
+                                      f"rank (the {args.minibatches} discriminator minibatches of an agent update) every "
+                                      f"{args.rollouts} steps, async on the RCCL stream, joined inside the timed region")
+                       if world > 1 else "none"},
             # achieved = ALGORITHMIC FLOPs / launch time against the dense MFMA peak of the operand type the kernel
             # issues; the fp16-split engine executes 3 MFMA products per algorithmic one (frac_executed counts those)
             "roofline": {"bound": "mfma", "kernel": dominant, "achieved": achieved, "peak": peak,

@@ -56,9 +56,16 @@ class ReplayAllGather:
     ``slots`` independent (shard, output) buffer pairs let that many gathers be in flight: ``start()`` enqueues the
     row draw on the current stream and launches the collective asynchronously on RCCL's stream, so it runs under the
     following env steps / GEMMs; ``wait_all()`` (or the next ``start()`` on a busy slot) joins them.  ``__call__`` is
-    the blocking form."""
+    the blocking form.
 
-    def __init__(self, amp_obs: torch.Tensor, rows: int, seed: int = 0, group=None, slots: int = 1):
+    ``minibatches`` > 1 fuses that many minibatches of one agent update into ONE collective (same bytes, one launch:
+    xGMI links are point-to-point, so fewer and larger messages use them better than twelve 2.7-MB ones): each rank
+    contributes ``[minibatches, rows, C]`` and the gathered tensor is ``[world, minibatches, rows, C]``;
+    :meth:`minibatch_blocks` returns minibatch i as its ``world`` contiguous ``[rows, C]`` blocks."""
+
+    def __init__(self, amp_obs: torch.Tensor, rows: int, seed: int = 0, group=None, slots: int = 1, minibatches: int = 1):
+        self.minibatches, self.rows_per_minibatch = int(minibatches), int(rows)
+        rows = int(rows) * self.minibatches
         self.amp_obs, self.rows, self.group = amp_obs, int(rows), group
         self.gen = torch.Generator(device=amp_obs.device).manual_seed(seed)
         world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -96,6 +103,13 @@ class ReplayAllGather:
             if w is not None:
                 w.wait()
                 self.works[i] = None
+
+    def minibatch_blocks(self, slot: int, i: int):
+        """Minibatch ``i`` of a fused gather: ``world`` contiguous ``[rows, C]`` views, rank order (no copy)."""
+        out = self.result(slot)
+        world = out.shape[0] // self.rows
+        full = out.view(world, self.minibatches, self.rows_per_minibatch, out.shape[1])
+        return [full[r, i] for r in range(world)]
 
     def result(self, slot: int) -> torch.Tensor:
         if self.works[slot] is not None:

@@ -46,6 +46,19 @@ def _worker(rank, world, port, out_dir):
     last = rg3.result(s)
     assert last.shape == (world * 4, 6) and bool(((last[:4] // 1000).long() == 0).all()) and bool(((last[4:] // 1000).long() == 1).all())
 
+    rg4 = ReplayAllGather(table, rows=4, seed=rank, minibatches=3)  # three minibatches fused into one collective
+    slot = rg4.start()
+    rg4.wait_all()
+    assert rg4.result(slot).shape == (world * 12, 6)
+    for i in range(3):
+        blocks = rg4.minibatch_blocks(slot, i)
+        assert len(blocks) == world and all(b.shape == (4, 6) and b.is_contiguous() for b in blocks)
+        for r, b in enumerate(blocks):  # block r holds rank r's rows
+            assert bool(((b // 1000).long() == r).all())
+    # the fused draw is the same row sequence as one long draw of the unfused object
+    ref = ReplayAllGather(table, rows=12, seed=rank)
+    assert torch.equal(ref(), rg4.result(slot))
+
     # (2) env sharding: each rank computes its contiguous env block of the oracle path; rank 0 checks the concatenation
     clips = [os.path.join(ROOT, "humanoid_amp_amd", "motions", "G1_walk.npz")]
     mt = om.load_tables(clips)
