@@ -255,7 +255,8 @@ def main():
         achieved = flops2 / (gemm2_ms * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS[args.disc_precision]
         nprod = MFMA_PER_PRODUCT[args.disc_precision]
-        hbm_kernels = ("collect_reference_kernel", "env_step_kernel", "compact_scatter_kernel")
+        # the env step and the expert-motion sample share one launch (amp_env_step_with_reference)
+        hbm_kernels = ("env_step_reference_kernel", "collect_reference_kernel", "env_step_kernel", "compact_scatter_kernel")
         hbm_us = sum(per_kernel.get(k, 0.0) for k in hbm_kernels)
         alg_bytes = algorithmic_bytes_per_env_step(spec) * args.envs
         out = {

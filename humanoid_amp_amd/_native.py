@@ -139,6 +139,8 @@ SIGNATURES = {
     "amp_policy_obs_size": (_i64, [C.POINTER(AmpEnvCfg)]),
     "amp_actor_history_frame_size": (_i64, [C.POINTER(AmpEnvCfg)]),
     "amp_env_step": (C.c_int, [C.POINTER(AmpEnvCfg), C.POINTER(AmpSimState), C.POINTER(AmpEnvBuffers), _i64, C.c_uint32, _vp]),
+    "amp_env_step_with_reference": (C.c_int, [C.POINTER(AmpEnvCfg), C.POINTER(AmpSimState), C.POINTER(AmpEnvBuffers), _i64, C.c_uint32,
+                                              _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "amp_reset_compact_workspace_bytes": (_i64, [_i64]),
     "amp_reset_compact": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "amp_reset_compact_tiles": (C.c_int, [_vp, _vp, _i32, _i64, _vp, _vp, _vp]),

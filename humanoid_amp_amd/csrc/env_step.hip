@@ -10,6 +10,7 @@
 //   write   every output (AMP buffer rows, policy obs, actor history) is walked flat from the LDS tile, so
 //           stores are contiguous runs of D (or P) floats per env.
 #include "amp_common.hpp"
+#include "motion_kernels.hpp"
 
 namespace amp {
 
@@ -26,9 +27,11 @@ struct EnvPlan {
   float w_track, sigma_sq, thr, val_at_thr, slope;
 };
 
+// `block` = index of the env tile, `smem` = the workgroup's dynamic LDS: a device function so that it can run either
+// as its own kernel or as one half of the horizontally fused launch below.
 template <int kTileEnvs>
-__global__ __launch_bounds__(kBlock) void env_step_kernel(EnvPlan p, AmpSimState st, AmpEnvBuffers bf, int64_t N) {
-  extern __shared__ float smem[];
+__device__ __forceinline__ void env_step_body(const EnvPlan& p, const AmpSimState& st, const AmpEnvBuffers& bf, int64_t N,
+                                              int64_t block, float* smem) {
   const int D = p.D, nd = p.n_dof, ndp = p.dof_pad;
   float* s_obs = smem;                          // [64, D]
   float* s_act = s_obs + kTileEnvs * D;         // [64, ndp]   (reward)
@@ -39,7 +42,7 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(EnvPlan p, AmpSimState
   const int lim_row = 2 * nd + 1;                                // odd stride: conflict-free one-env-per-lane reads
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t tile_base = (int64_t)blockIdx.x * kTileEnvs;
+  const int64_t tile_base = block * kTileEnvs;
   const int n_tile = (int)((N - tile_base) < kTileEnvs ? (N - tile_base) : kTileEnvs);
   const bool do_dones = p.phases & AMP_PHASE_DONES;
   const bool do_rew = p.phases & AMP_PHASE_REWARD;
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(EnvPlan p, AmpSimState
     }
     if (do_dones && bf.reset_tile_counts) {
       const unsigned long long b = __ballot(reset_bit);
-      if (lane == 0) bf.reset_tile_counts[blockIdx.x] = __popcll(b);
+      if (lane == 0) bf.reset_tile_counts[block] = __popcll(b);
     }
   }
   __syncthreads();
@@ -285,6 +288,31 @@ __global__ __launch_bounds__(kBlock) void env_step_kernel(EnvPlan p, AmpSimState
   }
 }
 
+template <int kTileEnvs>
+__global__ __launch_bounds__(kBlock) void env_step_kernel(EnvPlan p, AmpSimState st, AmpEnvBuffers bf, int64_t N) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  env_step_body<kTileEnvs>(p, st, bf, N, (int64_t)blockIdx.x, smem);
+}
+
+// Horizontally fused launch: workgroups [0, env_blocks) run the env step, the rest the expert-motion sample
+// (collect_reference_motions: no data dependence on the env state), so the two byte-moving kernels of a step share one
+// launch and overlap instead of running back to back.  Bit-identical to the two separate launches.
+struct ExpertArgs {
+  MotionView v;
+  const double* times;
+  const int64_t* ids;
+  int64_t n;
+  int32_t K;
+  float* out;
+};
+template <int kTileEnvs>
+__global__ __launch_bounds__(kBlock) void env_step_reference_kernel(EnvPlan p, AmpSimState st, AmpEnvBuffers bf, int64_t N,
+                                                                    unsigned env_blocks, ExpertArgs x) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (blockIdx.x < env_blocks) env_step_body<kTileEnvs>(p, st, bf, N, (int64_t)blockIdx.x, smem);
+  else collect_reference_body(x.v, x.times, x.ids, x.n, x.K, x.out, nullptr, nullptr, (int64_t)(blockIdx.x - env_blocks), smem);
+}
+
 static int make_plan(const AmpEnvCfg* c, uint32_t phases, EnvPlan* p) {
   AMP_REQUIRE(c->n_dof >= 1 && c->n_dof <= 256, "amp_env_step: n_dof %d out of range", c->n_dof);
   AMP_REQUIRE(c->n_key >= 1 && c->n_key <= kMaxKey, "amp_env_step: n_key %d out of range", c->n_key);
@@ -360,8 +388,8 @@ int64_t amp_actor_history_frame_size(const AmpEnvCfg* cfg) {
   return p.per;
 }
 
-int amp_env_step(const AmpEnvCfg* cfg, const AmpSimState* st, const AmpEnvBuffers* bf, int64_t N, uint32_t phases,
-                 amp_stream_t stream) {
+static int env_step_launch(const AmpEnvCfg* cfg, const AmpSimState* st, const AmpEnvBuffers* bf, int64_t N, uint32_t phases,
+                           const ExpertArgs* expert, amp_stream_t stream) {
   AMP_REQUIRE(cfg && st && bf, "amp_env_step: null argument");
   AMP_REQUIRE(N >= 0, "amp_env_step: negative num_envs");
   AMP_REQUIRE(phases != 0 && (phases & ~7u) == 0, "amp_env_step: phases must be a non-empty OR of AMP_PHASE_*");
@@ -403,12 +431,39 @@ int amp_env_step(const AmpEnvCfg* cfg, const AmpSimState* st, const AmpEnvBuffer
                      sizeof(float) * (size_t)(per_env_limits ? tile : 1) * (2 * p.n_dof + 1);
   AMP_REQUIRE(lds <= 64 * 1024, "amp_env_step: observation tile needs %zu B of LDS (> 64 KiB)", lds);
   const unsigned grid = (unsigned)((N + tile - 1) / tile);
+  if (expert && expert->n > 0) {
+    const size_t lds_x = expert_lds(expert->v.D);
+    const size_t lds_f = lds > lds_x ? lds : lds_x;
+    AMP_REQUIRE(lds_f <= 64 * 1024, "amp_env_step_with_reference: tile needs %zu B of LDS (> 64 KiB)", lds_f);
+    const unsigned grid_x = (unsigned)((expert->n * expert->K + kExpertTile - 1) / kExpertTile);
+    amp::TraceScope trace__("env_step_reference_kernel", (hipStream_t)stream);
+    if (tile == 64) env_step_reference_kernel<64><<<grid + grid_x, kBlock, lds_f, (hipStream_t)stream>>>(p, *st, *bf, N, grid, *expert);
+    else if (tile == 32) env_step_reference_kernel<32><<<grid + grid_x, kBlock, lds_f, (hipStream_t)stream>>>(p, *st, *bf, N, grid, *expert);
+    else env_step_reference_kernel<16><<<grid + grid_x, kBlock, lds_f, (hipStream_t)stream>>>(p, *st, *bf, N, grid, *expert);
+    return launch_status("env_step_reference_kernel");
+  }
   { amp::TraceScope trace__("env_step_kernel", (hipStream_t)stream);
     if (tile == 64) env_step_kernel<64><<<grid, kBlock, lds, (hipStream_t)stream>>>(p, *st, *bf, N);
     else if (tile == 32) env_step_kernel<32><<<grid, kBlock, lds, (hipStream_t)stream>>>(p, *st, *bf, N);
     else env_step_kernel<16><<<grid, kBlock, lds, (hipStream_t)stream>>>(p, *st, *bf, N);
   }
   return launch_status("env_step_kernel");
+}
+
+int amp_env_step(const AmpEnvCfg* cfg, const AmpSimState* st, const AmpEnvBuffers* bf, int64_t N, uint32_t phases,
+                 amp_stream_t stream) {
+  return env_step_launch(cfg, st, bf, N, phases, nullptr, stream);
+}
+
+int amp_env_step_with_reference(const AmpEnvCfg* cfg, const AmpSimState* st, const AmpEnvBuffers* bf, int64_t N, uint32_t phases,
+                                const AmpMotion* motion, const double* times_dev, const int64_t* motion_ids_dev, int64_t n_samples,
+                                int32_t K, float* expert_out_dev, amp_stream_t stream) {
+  AMP_REQUIRE(motion, "amp_env_step_with_reference: null motion handle");
+  AMP_REQUIRE(motion->has_layout, "amp_env_step_with_reference: call amp_motion_set_obs_layout first");
+  AMP_REQUIRE(n_samples >= 0 && K >= 1, "amp_env_step_with_reference: bad sample count / K");
+  AMP_REQUIRE(n_samples == 0 || (times_dev && expert_out_dev), "amp_env_step_with_reference: null buffer");
+  ExpertArgs x{motion->v, times_dev, motion_ids_dev, n_samples, K, expert_out_dev};
+  return env_step_launch(cfg, st, bf, N, phases, &x, stream);
 }
 
 }  // extern "C"

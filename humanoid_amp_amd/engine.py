@@ -142,8 +142,11 @@ class EnvStepKernel:
 
     def launch(self, phases: int, *, joint_pos=None, joint_vel=None, joint_acc=None, actions=None, root_pos=None,
                root_quat=None, root_lin_vel=None, root_ang_vel=None, body_pos=None, key_body_indexes: Sequence[int] = (),
-               soft_limits=None, episode_length=None, command=None, last_actions=None) -> None:
-        """One ``amp_env_step`` launch.  State arguments are torch views straight off the simulator:
+               soft_limits=None, episode_length=None, command=None, last_actions=None, reference=None) -> None:
+        """One ``amp_env_step`` launch.  ``reference=(motion_loader, times, motion_ids, out)`` makes it the
+        horizontally fused launch ``amp_env_step_with_reference``: the expert-motion sample
+        (``motion_loader.collect_reference(times, motion_ids, K, out=out)``) runs in the same kernel, on its own
+        workgroups, bit-identical to the separate call.  State arguments are torch views straight off the simulator:
         ``[N, n_dof]`` rows (any env stride), ``[N, 3|4]`` root views (e.g. ``body_pos_w[:, ref]``),
         ``body_pos`` = ``[N, B, 3]`` with ``key_body_indexes`` into B, ``soft_limits`` ``[N, n_dof, 2]`` or ``[n_dof, 2]``."""
         cfg, N = self.cfg, self.num_envs
@@ -192,8 +195,19 @@ class EnvStepKernel:
                 raise nat.AmpEngineError(f"{name} must have shape {shape}, got {tuple(t.shape)}")
         b = self._buffers()
         with torch.cuda.device(self.device):
-            nat.check(self._lib.amp_env_step(C.byref(self._c), C.byref(s), C.byref(b), N, int(phases), nat.stream_ptr()),
-                      "amp_env_step")
+            if reference is None:
+                nat.check(self._lib.amp_env_step(C.byref(self._c), C.byref(s), C.byref(b), N, int(phases), nat.stream_ptr()),
+                          "amp_env_step")
+            else:
+                loader, times, ids, out = reference
+                n, K = int(times.shape[0]), cfg.num_amp_observations
+                if times.dtype != torch.float64 or ids.dtype != torch.int64 or ids.shape[0] != n:
+                    raise nat.AmpEngineError("reference times / ids must be float64 / int64 device tensors of equal length")
+                if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != n * K * cfg.amp_frame_size:
+                    raise nat.AmpEngineError(f"reference output must be a contiguous float32 [{n}, {K * cfg.amp_frame_size}] tensor")
+                nat.check(self._lib.amp_env_step_with_reference(C.byref(self._c), C.byref(s), C.byref(b), N, int(phases),
+                                                                loader._handle, nat.dptr(times), nat.dptr(ids), n, K, nat.dptr(out),
+                                                                nat.stream_ptr()), "amp_env_step_with_reference")
 
     def compact_resets(self):
         """Ascending reset ids from ``reset_mask`` using the tile counts of the last DONES launch.

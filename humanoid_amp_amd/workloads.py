@@ -86,13 +86,16 @@ class HotPath:
 
     def __init__(self, spec: WorkloadSpec, num_envs: int, device, seed: int = 0, log_reward_terms: bool = False,
                  overlap: bool = False, fused_scaler: bool = True, disc_precision: str = "f16x3",
-                 expert_stream: bool = False):
+                 expert_stream: bool = False, fused_expert: bool = True):
         """``overlap``: run the discriminator on a second HIP stream so that the HBM-bound kernels of step t+1
         (motion sample, env step, compaction) execute under the MFMA-bound GEMMs of step t.  The style reward is
         consumed asynchronously in AMP (skrl reads it at the agent update), so nothing waits for it inside a step;
         ``synchronize()`` / ``torch.cuda.synchronize()`` joins both streams.  Bit-identical to the serial schedule
         (tests/test_gpu_disc.py).  Measured on MI355X it is a wash (+1.5 % at 65 536 envs, -10 % at 4 096): the GEMM
         workgroups already hold every wave slot, so the two streams time-slice instead of overlapping -> default off.
+
+        ``fused_expert`` (default): the expert-motion sample shares the env step's launch (horizontal fusion:
+        ``amp_env_step_with_reference``), so the two byte-moving kernels overlap instead of running back to back.
 
         ``expert_stream``: the expert-motion sample (``collect_reference``: the motion dataset's rows, no data
         dependence on the env state) runs on a side stream forked at the start of the step and joined at its end, i.e.
@@ -138,6 +141,7 @@ class HotPath:
                 self._sim.pop(k)
         self.last = None
         self._n = 0
+        self.fused_expert = bool(fused_expert) and not expert_stream
         self._expert_stream = None
         if expert_stream:
             self._expert_stream = torch.cuda.Stream(device=self.device)
@@ -166,7 +170,10 @@ class HotPath:
         if self.overlap and self._n > 0:
             # the previous discriminator call must have read amp_obs / reward before this step shifts / rewrites them
             env_stream.wait_event(self._consumed[(self._n - 1) & 1])
-        if self._expert_stream is None:
+        reference = None
+        if self.fused_expert:
+            reference = (self.motion, s["motion_times"], s["motion_ids"], self.expert_obs)
+        elif self._expert_stream is None:
             self.motion.collect_reference(s["motion_times"], s["motion_ids"], self.spec.K, out=self.expert_obs)
         else:
             self._fork.record(env_stream)
@@ -174,7 +181,7 @@ class HotPath:
                 self._expert_stream.wait_event(self._fork)
                 self.motion.collect_reference(s["motion_times"], s["motion_ids"], self.spec.K, out=self.expert_obs)
                 self._join.record(self._expert_stream)
-        k.launch(nat.AMP_PHASE_ALL, key_body_indexes=[0, 1, 2, 3], **self._sim)
+        k.launch(nat.AMP_PHASE_ALL, key_body_indexes=[0, 1, 2, 3], reference=reference, **self._sim)
         k.compact_resets()
         amp = k.amp_observation_buffer.view(self.num_envs, -1)
         if self.fused_scaler:

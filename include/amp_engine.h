@@ -215,6 +215,14 @@ typedef struct {
 
 enum { AMP_PHASE_DONES = 1, AMP_PHASE_REWARD = 2, AMP_PHASE_OBS = 4 };
 
+/* amp_env_step + amp_collect_reference (dst_rows = NULL) as ONE launch: some workgroups run the env step, the others
+ * the expert-motion sample for (times_dev, motion_ids_dev) [n_samples] -> expert_out_dev [n_samples, K * D].  The two
+ * have no data dependence; sharing a launch lets them overlap.  Results are bit-identical to the separate calls. */
+int amp_env_step_with_reference(const AmpEnvCfg* cfg, const AmpSimState* state, const AmpEnvBuffers* bufs, int64_t num_envs,
+                                uint32_t phases, const AmpMotion* motion, const double* times_dev,
+                                const int64_t* motion_ids_dev, int64_t n_samples, int32_t K, float* expert_out_dev,
+                                amp_stream_t stream);
+
 /* Envs per workgroup tile amp_env_step uses for a shard of num_envs (16, 32 or 64): the granularity of
  * reset_tile_counts. */
 int32_t amp_env_step_tile_envs(int64_t num_envs);

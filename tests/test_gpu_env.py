@@ -206,3 +206,26 @@ def test_env_step_full_size_properties(N):
     assert int(count) == want.numel() == int(a.reset_tile_counts.sum()) and torch.equal(ids[: want.numel()], want)
     assert torch.equal(a.reset_mask, a.died | a.time_out)
     assert 0.05 < float(a.died.float().mean()) < 0.4
+
+
+@pytest.mark.parametrize("workload,envs", [("g1_walk", 3000), ("g1_dance", 500), ("humanoid3", 70000)])
+def test_fused_expert_launch_is_bit_identical(workload, envs):
+    """amp_env_step_with_reference (env step + expert-motion sample as one launch, on disjoint workgroups) must
+    reproduce the two separate launches bit for bit: every env output and the expert rows, over several steps."""
+    import contextlib
+    import io
+
+    from humanoid_amp_amd.workloads import WORKLOADS, HotPath
+
+    res = {}
+    for fused in (False, True):
+        with contextlib.redirect_stdout(io.StringIO()):
+            hot = HotPath(WORKLOADS[workload], envs, "cuda:0", seed=11, fused_expert=fused)
+        for _ in range(hot.spec.K + 1):
+            hot.step()
+        hot.synchronize()
+        k = hot.kernel
+        res[fused] = [t.clone() for t in (hot.expert_obs, k.amp_observation_buffer, k.policy_obs, k.reward, k.died, k.time_out,
+                                          k.reset_ids, k.reset_count, hot.last["style"])]
+    for a, b in zip(res[False], res[True]):
+        assert torch.equal(a, b)
