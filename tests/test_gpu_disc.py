@@ -229,3 +229,26 @@ def test_f16_engine_without_clamp_uses_dynamic_bound():
     scale = lg64.abs().clamp(min=1.0)
     assert float((err[:599] / scale[:599]).max()) <= 1e-6 + float((err32[:599] / scale[:599]).max())
     assert float(err[599] / scale[599]) <= 2e-6
+
+
+def test_lds_dma_kernels_agree_with_the_fp32_engine_over_many_launches():
+    """Short race screen of the LDS-DMA GEMM kernels (tools/race_screen.py is the long form: 3.8e5 launches clean): many
+    launches at random ragged shard sizes, repeated on the same input, against the fp32-MFMA engine (register staging,
+    a different kernel family).  A mis-ordered LDS-DMA read is a wrong TILE -- an error of order one."""
+    from humanoid_amp_amd.engine import AmpDiscriminator
+
+    w = odisc.make_weights(166, seed=8)
+    kw = dict(running_mean=torch.zeros(166, dtype=torch.float64), running_variance=torch.ones(166, dtype=torch.float64))
+    fast = AmpDiscriminator([(p.cuda(), q.cuda()) for p, q in w], "cuda:0", precision="f16x3", **kw)
+    slow = AmpDiscriminator([(p.cuda(), q.cuda()) for p, q in w], "cuda:0", precision="f32", **kw)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    sizes = torch.randint(24576, 80000, (40,), generator=torch.Generator().manual_seed(2)).tolist()
+    for rows in sizes:
+        x = torch.randn(rows, 166, device="cuda", generator=g) * 1.5
+        ref = slow.style_reward(x, want_logits=True)["logits"]
+        first = None
+        for _ in range(4):
+            got = fast.style_reward(x, want_logits=True)["logits"]
+            assert float((got - ref).abs().max()) <= 5e-6
+            first = got if first is None else first
+            assert torch.equal(got, first)  # launches on the same input are bit-identical

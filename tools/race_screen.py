@@ -1,0 +1,32 @@
+"""Race screen for the LDS-DMA GEMM kernels: many launches at many (ragged) shard sizes, each compared row by row with
+the fp32-MFMA engine (a different kernel family with ordinary register staging).  A mis-ordered LDS-DMA read shows up
+as a wrong tile -- errors of order one, not 1e-6 -- possibly only once in many launches."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from humanoid_amp_amd.engine import AmpDiscriminator
+from humanoid_amp_amd.workloads import make_disc_weights
+
+seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+torch.manual_seed(0)
+worst, launches, t_end = 0.0, 0, time.time() + seconds
+for in_dim in (166, 830, 162):
+    w = make_disc_weights(in_dim, 0)
+    kw = dict(running_mean=torch.zeros(in_dim, dtype=torch.float64), running_variance=torch.ones(in_dim, dtype=torch.float64))
+    fast = AmpDiscriminator(w, "cuda:0", precision="f16x3", **kw)
+    slow = AmpDiscriminator(w, "cuda:0", precision="f32", **kw)
+    g = torch.Generator(device="cuda").manual_seed(in_dim)
+    deadline = time.time() + seconds / 3
+    while time.time() < deadline:
+        rows = int(torch.randint(24576, 90000, (1,)).item())
+        x = torch.randn(rows, in_dim, device="cuda", generator=g) * 1.5
+        ref = slow.style_reward(x, want_logits=True)["logits"]
+        for _ in range(4):  # the same input several times: a race would make the launches disagree
+            got = fast.style_reward(x, want_logits=True)["logits"]
+            err = float((got - ref).abs().max())
+            worst = max(worst, err)
+            launches += 1
+            if err > 1e-4:
+                print(f"MISMATCH rows={rows} in_dim={in_dim} err={err}")
+                sys.exit(1)
+print(f"race screen: {launches} forward passes at random shard sizes, worst |f16x3 - f32| = {worst:.3e}: clean")
