@@ -172,23 +172,24 @@ static void run(GemmF16Args g, int64_t M, int N, int K, bool quiet) {
 static _Float16 *g_Ab = nullptr, *g_Wb = nullptr;
 static bool g_dma_last = false;  // the last kernel run wrote H in block layout (check() must index accordingly)
 
-template <int MODE, int XP = 0>
+template <int MODE, int XP = 0, int TM = 4, int TN = 2>
 static void run_dma(GemmF16Args g, int64_t M, int N, int K, bool quiet) {
+  using T = DmaTile<TM, TN>;
   if (MODE == 1) g.A = g_Ab;  // block layout; MODE 0 reads the (p0, p1) pairs as they are
   g.W = g_Wb;
   g_dma_last = true;
-  g.n_tiles = N / kDmaBN;
-  g.m_tiles = (int)((M + kDmaBM - 1) / kDmaBM);
+  g.n_tiles = N / T::BN;
+  g.m_tiles = (int)((M + T::BM - 1) / T::BM);
   const unsigned grid = (unsigned)(((int64_t)g.m_tiles * g.n_tiles + 7) / 8 * 8);
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gemm_f16_dma_kernel<MODE, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLdsBytes));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gemm_f16_dma_kernel<MODE, XP, TM, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, T::kLds));
   hipEvent_t a, b;
   CK(hipEventCreate(&a));
   CK(hipEventCreate(&b));
-  for (int i = 0; i < 3; ++i) disc_gemm_f16_dma_kernel<MODE, XP><<<grid, kDmaThreads, kDmaLdsBytes>>>(g);
+  for (int i = 0; i < 3; ++i) disc_gemm_f16_dma_kernel<MODE, XP, TM, TN><<<grid, kDmaThreads, T::kLds>>>(g);
   CK(hipDeviceSynchronize());
   const int reps = 10;
   CK(hipEventRecord(a));
-  for (int i = 0; i < reps; ++i) disc_gemm_f16_dma_kernel<MODE, XP><<<grid, kDmaThreads, kDmaLdsBytes>>>(g);
+  for (int i = 0; i < reps; ++i) disc_gemm_f16_dma_kernel<MODE, XP, TM, TN><<<grid, kDmaThreads, T::kLds>>>(g);
   CK(hipEventRecord(b));
   CK(hipEventSynchronize(b));
   float ms;
@@ -196,7 +197,8 @@ static void run_dma(GemmF16Args g, int64_t M, int N, int K, bool quiet) {
   g_us = ms * 1e3 / reps;
   if (!quiet) {
     const double tf = 2.0 * M * N * K / (g_us * 1e-6) / 1e12;
-    printf("LDS-DMA 256x256x32 blocks, 2 stages, 512 thr            %8.1f us   %6.1f TF(alg)  %.3f of fp16 peak executed\n", g_us, tf, 3 * tf / 2516.6);
+    printf("LDS-DMA %3dx%3dx32 blocks, 2 stages, 512 thr            %8.1f us   %6.1f TF(alg)  %.3f of fp16 peak executed\n", T::BM, T::BN, g_us, tf,
+           3 * tf / 2516.6);
     fflush(stdout);
   }
 }
@@ -347,6 +349,22 @@ int main(int argc, char** argv) {
     fill_probe<64>(Ap, M, K, Wp, N, P);
     fill_probe<128>(Ap, M, K, Wp, N, P);
     fill_probe<32>(Ap, M, K, Wp, N, P);
+    return 0;
+  }
+  if (getenv("TILES")) {
+    for (int rep = 0; rep < 3; ++rep) {
+      if (mode == 0) {
+        run_dma<0, 0, 4, 2>(g, M, N, K, false); check(N / 256);
+        run_dma<0, 0, 2, 2>(g, M, N, K, false); check(N / 256);
+        run_dma<0, 0, 2, 1>(g, M, N, K, false); check(N / 128);
+        run_dma<0, 0, 4, 1>(g, M, N, K, false); check(N / 128);
+      } else {
+        run_dma<1, 0, 4, 2>(g, M, N, K, false); check(N / 256);
+        run_dma<1, 0, 2, 2>(g, M, N, K, false); check(N / 256);
+        run_dma<1, 0, 2, 1>(g, M, N, K, false); check(N / 128);
+        run_dma<1, 0, 4, 1>(g, M, N, K, false); check(N / 128);
+      }
+    }
     return 0;
   }
   if (getenv("XP") && mode == 0) {
