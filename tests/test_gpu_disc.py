@@ -252,3 +252,29 @@ def test_lds_dma_kernels_agree_with_the_fp32_engine_over_many_launches():
             assert float((got - ref).abs().max()) <= 5e-6
             first = got if first is None else first
             assert torch.equal(got, first)  # launches on the same input are bit-identical
+
+
+@pytest.mark.parametrize("w1_scale,w2_scale,b_scale", [(50.0, 0.02, 10.0), (1e-3, 300.0, 1e-3), (700.0, 1.0, 100.0)])
+@pytest.mark.parametrize("rows", [3000, 40000])
+def test_f16_engine_plane_scales_follow_the_weights(w1_scale, w2_scale, b_scale, rows):
+    """The fp16 planes are scaled from bounds on the weights / hidden layer: badly scaled layers (hidden activations of
+    order 1e4 or 1e-3) must neither overflow fp16 nor lose accuracy -- relative 1e-6 against fp64, like an fp32 forward."""
+    from humanoid_amp_amd.engine import AmpDiscriminator
+
+    g = torch.Generator().manual_seed(int(w1_scale * 7 + rows))
+    w = odisc.make_weights(166, seed=21)
+    w = [(w[0][0] * w1_scale, w[0][1] * b_scale), (w[1][0] * w2_scale, w[1][1] * b_scale), w[2]]
+    x = torch.randn(rows, 166, generator=g) * 2.0
+    mean = torch.zeros(166, dtype=torch.float64)
+    var = torch.ones(166, dtype=torch.float64)
+    d = AmpDiscriminator([(p.cuda(), q.cuda()) for p, q in w], "cuda:0", running_mean=mean, running_variance=var)
+    got = d.style_reward(x.cuda(), want_logits=True)["logits"].cpu().double()
+    sub = torch.cat([torch.arange(0, 1024), torch.arange(rows - 1024, rows)])
+    with torch.no_grad():
+        xs = odisc.scale_states(x[sub], mean, var)
+        lg64 = odisc.logits(w, xs, dtype=torch.float64)
+        lg32 = odisc.logits(w, xs, dtype=torch.float32).double()
+    assert torch.isfinite(got).all()
+    scale = float(lg64.abs().max())
+    err, err32 = float((got[sub] - lg64).abs().max()), float((lg32 - lg64).abs().max())
+    assert err <= 2e-6 * scale + 1e-6, (err, err32, scale)
