@@ -354,7 +354,7 @@ static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* a
       g1.n_tiles = h->h1 / kDmaBN;
       g1.m_tiles = (int)((m + kDmaBM - 1) / kDmaBM);
       const unsigned grid = (unsigned)(((int64_t)g1.m_tiles * g1.n_tiles + 7) / 8 * 8);
-      amp::TraceScope trace__("disc_gemm_f16_kernel<0>", st);
+      amp::TraceScope trace__("disc_gemm_f16_dma_kernel<0>", st);
       disc_gemm_f16_dma_kernel<0><<<grid, kDmaThreads, kDmaLdsBytes, st>>>(g1);
       rc = launch_status("disc_gemm_f16_dma_kernel<0>");
     } else if (big_tiles(h->h1)) {
@@ -375,7 +375,7 @@ static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* a
       g2.n_tiles = n_tiles;
       g2.m_tiles = (int)((m + kDmaBM - 1) / kDmaBM);
       const unsigned grid = (unsigned)(((int64_t)g2.m_tiles * g2.n_tiles + 7) / 8 * 8);
-      amp::TraceScope trace__("disc_gemm_f16_kernel<1>", st);
+      amp::TraceScope trace__("disc_gemm_f16_dma_kernel<1>", st);
       disc_gemm_f16_dma_kernel<1><<<grid, kDmaThreads, kDmaLdsBytes, st>>>(g2);
       rc = launch_status("disc_gemm_f16_dma_kernel");
     } else if (n_tiles == h->h2 / 128) {
