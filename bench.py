@@ -251,7 +251,7 @@ def main():
             # keys are "kernel<template args>@workgroups"; layer 2 at this shard size = ceil(envs / 128) * 4 workgroups
             # keys are "kernel<template args>@workgroups" (workgroups of one launch)
             rows = args.envs // per_step
-            key = {"f16x3": f"disc_gemm_f16_dma_kernel<1, 0>@{(rows + 255) // 256 * 2}",
+            key = {"f16x3": f"disc_gemm_f16_dma_kernel<1, 0, 4, 2>@{(rows + 255) // 256 * 2}",
                    "f32": f"disc_gemm_kernel<128, 128, 16, 1, 1, 4>@{(rows + 127) // 128 * 4}"}[args.disc_precision]
             traffic = tj[key]["hbm_bytes"] if args.envs >= 16384 else None
         except Exception:
