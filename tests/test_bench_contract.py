@@ -1,0 +1,34 @@
+"""CPU: the bench.py contract -- flags the driver passes, and the shape of the JSON line (checked on the line committed
+under profiles/ by the last profiled run, which bench.py itself printed on an MI355X)."""
+
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_flags_the_driver_passes_exist():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert re.search(r'add_argument\("%s", type=int' % flag, src), flag
+
+
+def test_committed_json_line_has_the_contract_fields():
+    lines = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_bench_plain.json"))
+    d = json.load(open(os.path.join(ROOT, "profiles", lines[-1])))
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert d["unit"] == "env-steps/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["data"] == "synthetic"
+    assert d["vs_baseline"] is None                      # BASELINE.md publishes no number for this metric
+    assert d["metric"].split()[0] == base["metric"].split()[0]
+    assert d["n_gpus"] == 1 and d["steps"] > 0 and d["warmup"] >= 0
+    assert abs(d["value"] - d["config"]["global_envs"] * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-9 and 0.0 < r["frac"] < 1.0
+    assert r["traffic"] is None or r["traffic"] > 0
+    # achieved = algorithmic FLOPs per launch / average launch duration
+    assert abs(r["achieved"] - r["flops_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12) <= 1e-6 * r["achieved"]
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
