@@ -539,3 +539,47 @@ class AmpReplayBuffer:
         h, self._handle = getattr(self, "_handle", None), None
         if h is not None and getattr(self, "_lib", None) is not None:
             self._lib.amp_ring_destroy(h)
+
+
+class AmpDiscriminatorUpdate:
+    """The discriminator half of skrl ``AMP._update`` as a device-side data flow [skrl is third-party and absent:
+    restated, parity unpinned; hyper-parameters agents/skrl_g1_walk_amp_cfg.yaml:64-66,91-95]:
+
+    * per learning epoch the rollout's AMP states are shuffled and split into ``mini_batches`` minibatches
+      (``memory.sample_all``); the first ``batch_size`` rows of a minibatch are the policy batch;
+    * each minibatch trains against ``batch_size`` rows drawn from the replay buffer (the policy batch itself while the
+      buffer is empty) and ``batch_size`` rows drawn from the motion dataset (:class:`AmpReplayBuffer` rings);
+    * after the update the rollout's rows are appended to the replay buffer.
+
+    Every draw is on the device (ring draws: counter-based; the shuffle: a seeded ``torch.randperm``); nothing is
+    read back.  With ``torch.distributed`` the replay rows of all ranks can be exchanged first
+    (``humanoid_amp_amd.distributed.ReplayAllGather``)."""
+
+    def __init__(self, trainer: AmpDiscriminatorTrainer, replay: AmpReplayBuffer, motion_dataset: AmpReplayBuffer, *,
+                 learning_epochs: int = 6, mini_batches: int = 2, seed: int = 0, record_batches: bool = False):
+        self.trainer, self.replay, self.motion_dataset = trainer, replay, motion_dataset
+        self.learning_epochs, self.mini_batches = int(learning_epochs), int(mini_batches)
+        self.gen = torch.Generator(device=trainer.device).manual_seed(seed)
+        self.record_batches = bool(record_batches)
+        self.batches = []  # (policy, replay, motion) of every trainer step of the last update, when recording
+
+    def update(self, rollout_amp_states: torch.Tensor):
+        rows = rollout_amp_states.reshape(-1, rollout_amp_states.shape[-1])
+        bs = self.trainer.batch_size
+        if rows.shape[0] < bs * self.mini_batches:
+            raise nat.AmpEngineError(f"the rollout has {rows.shape[0]} rows; {self.mini_batches} minibatches of {bs} are needed")
+        if len(self.motion_dataset) == 0:
+            raise nat.AmpEngineError("the motion dataset is empty: fill it with collect_reference rows first")
+        losses, self.batches = [], []
+        per = rows.shape[0] // self.mini_batches
+        for _ in range(self.learning_epochs):
+            perm = torch.randperm(rows.shape[0], generator=self.gen, device=rows.device)
+            for mb in range(self.mini_batches):
+                policy = rows.index_select(0, perm[mb * per: mb * per + bs])
+                replay = self.replay.sample(bs) if len(self.replay) > 0 else policy
+                motion = self.motion_dataset.sample(bs)
+                losses.append(self.trainer.step(policy, replay, motion)["loss"])
+                if self.record_batches:
+                    self.batches.append((policy.clone(), replay.clone(), motion.clone()))
+        self.replay.add_samples(rows)
+        return losses
