@@ -349,8 +349,9 @@ static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* a
     g1.H = H1p + r0 * h->h1; g1.ldh = h->h1; g1.plane_h = rows * h->h1;
     const bool dma = f16_use_dma(h, chunk);  // both layers or neither: it decides the hidden layer's layout
     if (dma) {
-      g1.W = h->w1b;               // block layout; the hidden layer comes out in block layout too (row pitch 2 * h1)
-      g1.H = H1p + 2 * r0 * h->h1;
+      g1.W = h->w1b;  // block layout; the hidden layer comes out in block layout too (row pitch 2 * h1)
+      g1.H = H1p;     // every chunk reuses the SAME 134 MB: rewritten while still dirty in the Infinity Cache, the hidden
+                      // layer is (mostly) never written back to HBM, and the lines it evicts are not dirty either
       g1.n_tiles = h->h1 / kDmaBN;
       g1.m_tiles = (int)((m + kDmaBM - 1) / kDmaBM);
       const unsigned grid = (unsigned)(((int64_t)g1.m_tiles * g1.n_tiles + 7) / 8 * 8);
@@ -370,7 +371,7 @@ static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* a
     g2.bias = h->b2; g2.range = h->range; g2.amax = amax; g2.layer = 2;
     g2.w3 = h->w3; g2.partial = partial + r0 * n_tiles;
     if (dma) {  // every chunk (a short last one too): one partial layout
-      g2.A = H1p + 2 * r0 * h->h1;
+      g2.A = H1p;
       g2.W = h->w2b;
       g2.n_tiles = n_tiles;
       g2.m_tiles = (int)((m + kDmaBM - 1) / kDmaBM);

@@ -27,6 +27,9 @@ struct EnvPlan {
   float w_track, sigma_sq, thr, val_at_thr, slope;
 };
 
+// Row index of flat element e of a [rows, width] block (e * width^-1 is far from an integer boundary: e < 2^16).
+__device__ __forceinline__ int row_of(int e, float inv_width) { return (int)(((float)e + 0.5f) * inv_width); }
+
 // `block` = index of the env tile, `smem` = the workgroup's dynamic LDS: a device function so that it can run either
 // as its own kernel or as one half of the horizontally fused launch below.
 template <int kTileEnvs>
@@ -288,10 +291,298 @@ __device__ __forceinline__ void env_step_body(const EnvPlan& p, const AmpSimStat
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fast tile body -- the hot-path configuration: all three phases, K == 2, no actor history, a whole tile, per-DoF
+// inputs whose [T, n_dof] blocks are contiguous and 16-B aligned (all checked on the host; anything else runs the
+// generic body above).  Same arithmetic, bit for bit; what differs is how the bytes move:
+//   * every HBM read of the tile is issued before the first wait (16-B flat loads of the per-DoF blocks, wave 0's
+//     per-env values, the old history slot of the columns a lane owns, the scaler statistics);
+//   * the tile's new AMP rows are assembled as an LDS image [T, 2*D] -- exactly the tile's contiguous span of the AMP
+//     buffer -- and streamed out with 16-B stores; the discriminator input and the policy observation are written
+//     two columns per lane (8-B stores, one row/column split per pair).
+// The generic body spends ~40 VALU instructions per output float on index arithmetic and 4-B stores and is
+// VALU-bound (no stores at all: 36 us of 58 at 65 536 envs); this one is bounded by the memory system.
+// ------------------------------------------------------------------------------------------------
+constexpr int kFastVec = 2;  // 16-B loads per lane per [T, n_dof] block: T * n_dof <= 2 * 4 * kBlock
+
+template <int T>
+__device__ __forceinline__ void env_step_fast_body(const EnvPlan& p, const AmpSimState& st, const AmpEnvBuffers& bf,
+                                                   int64_t N, int64_t block, float* smem) {
+  constexpr int kHist = (T * 96) / kBlock;  // history columns per lane (D <= 96)
+  const int D = p.D, nd = p.n_dof, ndp = p.dof_pad, KD = 2 * p.D;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t tile_base = block * T;
+  const bool g1 = p.reward_mode == 1;
+  const bool extra = p.use_last_actions;  // policy obs = [obs[:Db] | last_actions | command]
+  const bool has_cmd = extra && p.use_command;
+  const bool per_env_limits = g1 && st.soft_limits_stride != 0;
+  const bool fused = bf.disc_input != nullptr;
+  const bool scaled = fused && bf.scaler_mean != nullptr;
+  const int lim_row = 2 * nd + 1;
+
+  float* s_img = smem;                    // [T, 2*D]  the tile's new AMP rows: slot 0 = this step, slot 1 = old slot 0
+  float* s_act = s_img + T * KD;          // [T, ndp]  (reward)
+  float* s_acc = s_act + T * ndp;         // [T, ndp]  (reward)
+  float* s_la = s_acc + T * ndp;          // [T, nd]   last_actions rows (policy obs)
+  float* s_cmd = s_la + T * nd;           // [T, 2]    command rows
+  float* s_red = s_cmd + T * 2;           // [4, T]    reward partial sums
+  float* s_mu = s_red + 4 * T;            // [2*D]     scaler mean
+  float* s_dn = s_mu + KD;                // [2*D]     scaler sqrt(var) + eps
+  float* s_lim = s_dn + KD;               // [T | 1, 2*nd + 1]
+
+  // ---- issue every HBM read of the tile ---------------------------------------------------------------
+  const int nvec = T * nd / 4;
+  f4 v_pos[kFastVec], v_vel[kFastVec], v_act[kFastVec], v_acc[kFastVec], v_last[kFastVec], v_cmd;
+  {
+    const f4* g_pos = reinterpret_cast<const f4*>(st.joint_pos + tile_base * nd);
+    const f4* g_vel = reinterpret_cast<const f4*>(st.joint_vel + tile_base * nd);
+    const f4* g_act = reinterpret_cast<const f4*>(st.actions + tile_base * nd);
+    const f4* g_acc = reinterpret_cast<const f4*>(st.joint_acc + tile_base * nd);
+    const f4* g_last = reinterpret_cast<const f4*>(st.last_actions + tile_base * nd);
+#pragma unroll
+    for (int v = 0; v < kFastVec; ++v) {
+      const int i = tid + v * kBlock;
+      if (i < nvec) {
+        v_pos[v] = g_pos[i];
+        v_vel[v] = g_vel[i];
+        if (g1) { v_act[v] = g_act[i]; v_acc[v] = g_acc[i]; }
+        if (extra) v_last[v] = g_last[i];
+      }
+    }
+    if (has_cmd && tid < T / 2) v_cmd = reinterpret_cast<const f4*>(st.command + tile_base * 2)[tid];
+  }
+  const bool env_lane = wave == 0 && lane < T;
+  const int64_t env = tile_base + lane;
+  int64_t ep_len;
+  float rp[3], rq[4], rl[3], ra[3], kb[kMaxKey][3], cmd[2];
+  if (env_lane) {
+    ep_len = st.episode_length[env];
+    const float* g = st.root_pos + env * st.root_pos_stride;
+    rp[0] = g[0]; rp[1] = g[1]; rp[2] = g[2];
+    const float* gq = st.root_quat + env * st.root_quat_stride;
+    rq[0] = gq[0]; rq[1] = gq[1]; rq[2] = gq[2]; rq[3] = gq[3];
+    const float* gl = st.root_lin_vel + env * st.root_lin_vel_stride;
+    rl[0] = gl[0]; rl[1] = gl[1]; rl[2] = gl[2];
+    const float* ga = st.root_ang_vel + env * st.root_ang_vel_stride;
+    ra[0] = ga[0]; ra[1] = ga[1]; ra[2] = ga[2];
+    const float* bp = st.body_pos + env * st.body_pos_stride;
+#pragma unroll
+    for (int k = 0; k < kMaxKey; ++k)
+      if (k < p.n_key) {
+        const float* kp = bp + (int64_t)st.key_body[k] * 3;
+        kb[k][0] = kp[0]; kb[k][1] = kp[1]; kb[k][2] = kp[2];
+      }
+    if (g1 && p.use_command) { cmd[0] = st.command[env * 2 + 0]; cmd[1] = st.command[env * 2 + 1]; }
+  }
+  float* const buf = bf.amp_obs_buffer + tile_base * KD;
+  const float inv_d = 1.0f / (float)D;
+  float h[kHist];
+#pragma unroll
+  for (int u = 0; u < kHist; ++u) {
+    const int e = tid + u * kBlock;
+    if (e < T * D) {
+      const int s = row_of(e, inv_d);
+      h[u] = buf[s * KD + (e - s * D)];
+    }
+  }
+  float mu_c, dn_c;
+  if (scaled && tid < KD) { mu_c = bf.scaler_mean[tid]; dn_c = bf.scaler_den[tid]; }  // KD <= 192 < kBlock
+
+  // ---- registers -> LDS ----------------------------------------------------------------------------------
+  const float inv_nd = 1.0f / (float)nd;
+#pragma unroll
+  for (int v = 0; v < kFastVec; ++v) {
+    const int i = tid + v * kBlock;
+    if (i < nvec) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int e = 4 * i + c;
+        const int s = row_of(e, inv_nd), j = e - s * nd;
+        s_img[s * KD + j] = v_pos[v][c];
+        s_img[s * KD + nd + j] = v_vel[v][c];
+        if (g1) { s_act[s * ndp + j] = v_act[v][c]; s_acc[s * ndp + j] = v_acc[v][c]; }
+      }
+      if (extra) reinterpret_cast<f4*>(s_la)[i] = v_last[v];
+    }
+  }
+  if (has_cmd && tid < T / 2) reinterpret_cast<f4*>(s_cmd)[tid] = v_cmd;
+  if (g1) {
+    const int lim_rows = per_env_limits ? T : 1;
+    for (int e = tid; e < lim_rows * 2 * nd; e += kBlock) {
+      const int s = e / (2 * nd), c = e - s * 2 * nd;
+      s_lim[s * lim_row + c] = st.soft_limits[(tile_base + s) * st.soft_limits_stride + c];
+    }
+  }
+  int died = 0;
+  if (wave == 0) {
+    int reset_bit = 0;
+    if (env_lane) {
+      // g1_amp_env.py:321-330
+      const int tout = ep_len >= p.max_episode_length - 1;
+      died = p.early_termination ? (rp[2] < p.termination_height) : 0;
+      bf.died[env] = (uint8_t)died;
+      bf.time_out[env] = (uint8_t)tout;
+      reset_bit = died | tout;
+      if (bf.reset_mask) bf.reset_mask[env] = (uint8_t)reset_bit;
+      // compute_obs features that are not plain copies (g1_amp_env.py:545-555)
+      const Quat q{rq[0], rq[1], rq[2], rq[3]};
+      const Vec3 tg = quat_apply_ref(q, Vec3{1.0f, 0.0f, 0.0f});
+      const Vec3 nm = quat_apply_ref(q, Vec3{0.0f, 0.0f, 1.0f});
+      float* o = s_img + lane * KD + 2 * nd;
+      o[0] = rp[2];
+      o[1] = tg.x; o[2] = tg.y; o[3] = tg.z;
+      o[4] = nm.x; o[5] = nm.y; o[6] = nm.z;
+      o[7] = rl[0]; o[8] = rl[1]; o[9] = rl[2];
+      o[10] = ra[0]; o[11] = ra[1]; o[12] = ra[2];
+#pragma unroll
+      for (int k = 0; k < kMaxKey; ++k)
+        if (k < p.n_key) {
+          o[13 + 3 * k + 0] = kb[k][0] - rp[0];
+          o[13 + 3 * k + 1] = kb[k][1] - rp[1];
+          o[13 + 3 * k + 2] = kb[k][2] - rp[2];
+        }
+    }
+    if (bf.reset_tile_counts) {
+      const unsigned long long b = __ballot(reset_bit);
+      if (lane == 0) bf.reset_tile_counts[block] = __popcll(b);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < kHist; ++u) {
+    const int e = tid + u * kBlock;
+    if (e < T * D) {
+      const int s = row_of(e, inv_d);
+      s_img[s * KD + D + (e - s * D)] = h[u];  // slot 1 <- old slot 0 (g1_amp_env.py:187-190)
+    }
+  }
+  if (scaled && tid < KD) { s_mu[tid] = mu_c; s_dn[tid] = dn_c; }
+  __syncthreads();
+
+  // ---- task reward -------------------------------------------------------------------------------
+  if (!g1) {
+    if (env_lane) bf.reward[env] = 1.0f;  // humanoid_amp_env.py:128-129
+  } else {
+    // compute_rewards (g1_amp_env.py:564-606): wave w reduces term w of env `lane` over the DoFs
+    float acc = 0.0f;
+    if (lane < T) {
+      if (wave == 0) {
+        for (int j = 0; j < nd; ++j) { const float a = s_act[lane * ndp + j]; acc += a * a; }
+      } else if (wave == 1) {
+        const float* lim = s_lim + (per_env_limits ? lane * lim_row : 0);
+        for (int j = 0; j < nd; ++j) {
+          const float x = s_img[lane * KD + j];
+          float o = -fminf(x - lim[2 * j], 0.0f);
+          o += fmaxf(x - lim[2 * j + 1], 0.0f);
+          acc += o;
+        }
+      } else if (wave == 2) {
+        for (int j = 0; j < nd; ++j) { const float a = s_acc[lane * ndp + j]; acc += a * a; }
+      } else {
+        for (int j = 0; j < nd; ++j) { const float a = s_img[lane * KD + nd + j]; acc += a * a; }
+      }
+      s_red[wave * T + lane] = acc;
+    }
+    __syncthreads();
+    if (env_lane) {
+      const float r_term = p.s_term * (float)died;
+      const float r_act = p.s_act * s_red[lane];
+      const float r_lim = p.s_lim * s_red[T + lane];
+      const float r_acc = p.s_acc * s_red[2 * T + lane];
+      const float r_vel = p.s_vel * s_red[3 * T + lane];
+      const float basic = (((r_term + r_act) + r_lim) + r_acc) + r_vel;
+      float track = 0.0f, err = 0.0f;
+      if (p.use_command) {
+        // g1_amp_env.py:249-265: planar body-frame velocity error, exp reward with linear floor (:500-532)
+        const Vec3 vb = quat_rotate_inverse_ref(Quat{rq[0], rq[1], rq[2], rq[3]}, Vec3{rl[0], rl[1], rl[2]});
+        const float dx = vb.x - cmd[0];
+        const float dy = vb.y - cmd[1];
+        err = sqrtf(dx * dx + dy * dy);
+        const float e2 = err * err;
+        const float lin = p.val_at_thr - p.slope * (e2 - p.thr);
+        const float ex = p.w_track * expf(-e2 / p.sigma_sq);
+        track = e2 > p.thr ? lin : ex;
+      }
+      const float total = basic + track;
+      bf.reward[env] = total;
+      if (bf.reward_terms) {
+        float* t = bf.reward_terms + env;
+        t[0 * N] = total; t[1 * N] = track; t[2 * N] = err; t[3 * N] = r_term;
+        t[4 * N] = r_act; t[5 * N] = r_lim; t[6 * N] = r_acc; t[7 * N] = r_vel;
+      }
+    }
+  }
+
+  // ---- outputs: LDS image -> HBM ----------------------------------------------------------------------------
+  {  // AMP buffer: the tile's rows are one contiguous 16-B aligned span
+    const f4* img4 = reinterpret_cast<const f4*>(s_img);
+    f4* dst4 = reinterpret_cast<f4*>(buf);
+    for (int i = tid; i < T * KD / 4; i += kBlock) dst4[i] = img4[i];
+  }
+  if (fused) {
+    // the same rows, scaled, as the discriminator's input: two columns per lane (rows hold an even number of them)
+    const bool pairs = bf.disc_input_format == AMP_DISC_INPUT_F16_PAIRS;
+    uint32_t* const xs = reinterpret_cast<uint32_t*>(bf.disc_input) + tile_base * bf.disc_input_stride;
+    const float s_x = bf.disc_plane_scale, clip = bf.scaler_clip;
+    const float inv_ch = 1.0f / (float)D;  // D column pairs per row
+#pragma unroll 4
+    for (int it = tid; it < T * D; it += kBlock) {
+      const int s = row_of(it, inv_ch), c = 2 * (it - s * D);
+      const float2 v = *reinterpret_cast<const float2*>(s_img + s * KD + c);
+      float x0 = v.x, x1 = v.y;
+      if (scaled) {  // same operations, in the same order, as disc.hip's scaler passes
+        const float2 m = *reinterpret_cast<const float2*>(s_mu + c);
+        const float2 d = *reinterpret_cast<const float2*>(s_dn + c);
+        x0 = (x0 - m.x) / d.x;  // skrl RunningStandardScaler, exact fp32 divide
+        x1 = (x1 - m.y) / d.y;
+        x0 = fminf(fmaxf(x0, -clip), clip);
+        x1 = fminf(fmaxf(x1, -clip), clip);
+      }
+      uint2 o;
+      o.x = pairs ? plane_pair(x0 * s_x) : __float_as_uint(x0);
+      o.y = pairs ? plane_pair(x1 * s_x) : __float_as_uint(x1);
+      *reinterpret_cast<uint2*>(xs + s * bf.disc_input_stride + c) = o;
+    }
+  }
+  {  // policy observation (g1_amp_env.py:195-242; humanoid_amp_env.py:126), P == Pcur (no actor history here)
+    const int P = p.P, Db = p.Db;
+    float* pol = bf.policy_obs + tile_base * P;
+    auto value = [&](int s, int c) -> float {
+      if (!extra || c < Db) return s_img[s * KD + c];
+      if (c < Db + nd) return s_la[s * nd + (c - Db)];
+      return s_cmd[s * 2 + (c - Db - nd)];
+    };
+    if ((P & 1) == 0) {
+      const int half = P >> 1;
+      const float inv_half = 1.0f / (float)half;
+#pragma unroll 4
+      for (int it = tid; it < T * half; it += kBlock) {
+        const int s = row_of(it, inv_half), c = 2 * (it - s * half);
+        float2 o;
+        o.x = value(s, c);
+        o.y = value(s, c + 1);
+        *reinterpret_cast<float2*>(pol + (int64_t)s * P + c) = o;
+      }
+    } else {
+      const float inv_p = 1.0f / (float)P;
+      for (int e = tid; e < T * P; e += kBlock) {
+        const int s = row_of(e, inv_p);
+        pol[e] = value(s, e - s * P);
+      }
+    }
+  }
+}
+
 template <int kTileEnvs>
-__global__ __launch_bounds__(kBlock) void env_step_kernel(EnvPlan p, AmpSimState st, AmpEnvBuffers bf, int64_t N) {
+__global__ __launch_bounds__(kBlock) void env_step_kernel(EnvPlan p, AmpSimState st, AmpEnvBuffers bf, int64_t N,
+                                                          unsigned block0) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  env_step_body<kTileEnvs>(p, st, bf, N, (int64_t)blockIdx.x, smem);
+  env_step_body<kTileEnvs>(p, st, bf, N, (int64_t)(block0 + blockIdx.x), smem);
+}
+
+template <int T>
+__global__ __launch_bounds__(kBlock) void env_step_fast_kernel(EnvPlan p, AmpSimState st, AmpEnvBuffers bf, int64_t N) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  env_step_fast_body<T>(p, st, bf, N, (int64_t)blockIdx.x, smem);
 }
 
 // Horizontally fused launch: workgroups [0, env_blocks) run the env step, the rest the expert-motion sample
@@ -310,6 +601,13 @@ __global__ __launch_bounds__(kBlock) void env_step_reference_kernel(EnvPlan p, A
                                                                     unsigned env_blocks, ExpertArgs x) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (blockIdx.x < env_blocks) env_step_body<kTileEnvs>(p, st, bf, N, (int64_t)blockIdx.x, smem);
+  else collect_reference_body(x.v, x.times, x.ids, x.n, x.K, x.out, nullptr, nullptr, (int64_t)(blockIdx.x - env_blocks), smem);
+}
+template <int T>
+__global__ __launch_bounds__(kBlock) void env_step_fast_reference_kernel(EnvPlan p, AmpSimState st, AmpEnvBuffers bf, int64_t N,
+                                                                         unsigned env_blocks, ExpertArgs x) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (blockIdx.x < env_blocks) env_step_fast_body<T>(p, st, bf, N, (int64_t)blockIdx.x, smem);
   else collect_reference_body(x.v, x.times, x.ids, x.n, x.K, x.out, nullptr, nullptr, (int64_t)(blockIdx.x - env_blocks), smem);
 }
 
@@ -371,7 +669,6 @@ int32_t amp_env_step_tile_envs(int64_t num_envs) {
   // measured (MI355X, G1 K=2): 65 536 envs 72 / 78 / 91 us with 64 / 32 / 16-env tiles; 16 384 envs 39 / 27 / 23 us
   // envs per workgroup: 64 when that still gives >= 1024 workgroups (4 per CU), else smaller tiles so that a small
   // shard is spread over the whole chip (the kernel is latency-bound there: one 64-env tile takes ~25 us alone)
-  if (num_envs >= 64 * 1024) return 64;
   if (num_envs >= 32 * 1024) return 32;
   return 16;
 }
@@ -431,23 +728,56 @@ static int env_step_launch(const AmpEnvCfg* cfg, const AmpSimState* st, const Am
                      sizeof(float) * (size_t)(per_env_limits ? tile : 1) * (2 * p.n_dof + 1);
   AMP_REQUIRE(lds <= 64 * 1024, "amp_env_step: observation tile needs %zu B of LDS (> 64 KiB)", lds);
   const unsigned grid = (unsigned)((N + tile - 1) / tile);
-  if (expert && expert->n > 0) {
-    const size_t lds_x = expert_lds(expert->v.D);
+  const bool with_expert = expert && expert->n > 0;
+  const size_t lds_x = with_expert ? expert_lds(expert->v.D) : 0;
+  const unsigned grid_x = with_expert ? (unsigned)((expert->n * expert->K + kExpertTile - 1) / kExpertTile) : 0;
+  AMP_REQUIRE(lds_x <= 64 * 1024, "amp_env_step_with_reference: tile needs %zu B of LDS (> 64 KiB)", lds_x);
+  const char* label = with_expert ? "env_step_reference_kernel" : "env_step_kernel";
+
+  // The hot-path configuration runs the fast tile body on every whole tile (see env_step_fast_body); a ragged last
+  // tile, and every other configuration, runs the generic body.
+  auto aligned = [](const void* ptr, uintptr_t a) { return (reinterpret_cast<uintptr_t>(ptr) & (a - 1)) == 0; };
+  auto rows16 = [&](const float* ptr, int64_t stride) { return stride == p.n_dof && aligned(ptr, 16); };
+  const size_t lds_fast = sizeof(float) * ((size_t)tile * 2 * p.D + 2 * (size_t)tile * p.dof_pad + (size_t)tile * p.n_dof + 6 * (size_t)tile +
+                                           4 * (size_t)p.D + (size_t)(per_env_limits ? tile : 1) * (2 * p.n_dof + 1));
+  bool fast = phases == (AMP_PHASE_DONES | AMP_PHASE_REWARD | AMP_PHASE_OBS) && p.K == 2 && p.n_actor == 1 && p.D <= 96 && tile <= 32 && N >= tile &&
+              (int64_t)tile * p.n_dof <= (int64_t)kFastVec * 4 * kBlock && lds_fast <= 64 * 1024;
+  fast = fast && rows16(st->joint_pos, st->joint_pos_stride) && rows16(st->joint_vel, st->joint_vel_stride);
+  if (fast && p.reward_mode == 1) fast = rows16(st->actions, st->actions_stride) && rows16(st->joint_acc, st->joint_acc_stride);
+  if (fast && p.use_last_actions) fast = aligned(st->last_actions, 16) && (!p.use_command || aligned(st->command, 16));
+  fast = fast && aligned(bf->amp_obs_buffer, 16) && aligned(bf->policy_obs, 8);
+  if (fast && bf->disc_input) fast = aligned(bf->disc_input, 8) && (bf->disc_input_stride & 1) == 0;
+  if (fast) {
+    const unsigned full = (unsigned)(N / tile);
+    const size_t lds_f = lds_fast > lds_x ? lds_fast : lds_x;
+    {
+      amp::TraceScope trace__(label, (hipStream_t)stream);
+      if (with_expert) {
+        if (tile == 32) env_step_fast_reference_kernel<32><<<full + grid_x, kBlock, lds_f, (hipStream_t)stream>>>(p, *st, *bf, N, full, *expert);
+        else env_step_fast_reference_kernel<16><<<full + grid_x, kBlock, lds_f, (hipStream_t)stream>>>(p, *st, *bf, N, full, *expert);
+      } else {
+        if (tile == 32) env_step_fast_kernel<32><<<full, kBlock, lds_fast, (hipStream_t)stream>>>(p, *st, *bf, N);
+        else env_step_fast_kernel<16><<<full, kBlock, lds_fast, (hipStream_t)stream>>>(p, *st, *bf, N);
+      }
+    }
+    if (full != grid) {  // ragged last tile
+      if (tile == 32) env_step_kernel<32><<<1, kBlock, lds, (hipStream_t)stream>>>(p, *st, *bf, N, full);
+      else env_step_kernel<16><<<1, kBlock, lds, (hipStream_t)stream>>>(p, *st, *bf, N, full);
+    }
+    return launch_status(label);
+  }
+  if (with_expert) {
     const size_t lds_f = lds > lds_x ? lds : lds_x;
-    AMP_REQUIRE(lds_f <= 64 * 1024, "amp_env_step_with_reference: tile needs %zu B of LDS (> 64 KiB)", lds_f);
-    const unsigned grid_x = (unsigned)((expert->n * expert->K + kExpertTile - 1) / kExpertTile);
-    amp::TraceScope trace__("env_step_reference_kernel", (hipStream_t)stream);
-    if (tile == 64) env_step_reference_kernel<64><<<grid + grid_x, kBlock, lds_f, (hipStream_t)stream>>>(p, *st, *bf, N, grid, *expert);
-    else if (tile == 32) env_step_reference_kernel<32><<<grid + grid_x, kBlock, lds_f, (hipStream_t)stream>>>(p, *st, *bf, N, grid, *expert);
+    amp::TraceScope trace__(label, (hipStream_t)stream);
+    if (tile == 32) env_step_reference_kernel<32><<<grid + grid_x, kBlock, lds_f, (hipStream_t)stream>>>(p, *st, *bf, N, grid, *expert);
     else env_step_reference_kernel<16><<<grid + grid_x, kBlock, lds_f, (hipStream_t)stream>>>(p, *st, *bf, N, grid, *expert);
-    return launch_status("env_step_reference_kernel");
+    return launch_status(label);
   }
-  { amp::TraceScope trace__("env_step_kernel", (hipStream_t)stream);
-    if (tile == 64) env_step_kernel<64><<<grid, kBlock, lds, (hipStream_t)stream>>>(p, *st, *bf, N);
-    else if (tile == 32) env_step_kernel<32><<<grid, kBlock, lds, (hipStream_t)stream>>>(p, *st, *bf, N);
-    else env_step_kernel<16><<<grid, kBlock, lds, (hipStream_t)stream>>>(p, *st, *bf, N);
+  { amp::TraceScope trace__(label, (hipStream_t)stream);
+    if (tile == 32) env_step_kernel<32><<<grid, kBlock, lds, (hipStream_t)stream>>>(p, *st, *bf, N, 0u);
+    else env_step_kernel<16><<<grid, kBlock, lds, (hipStream_t)stream>>>(p, *st, *bf, N, 0u);
   }
-  return launch_status("env_step_kernel");
+  return launch_status(label);
 }
 
 int amp_env_step(const AmpEnvCfg* cfg, const AmpSimState* st, const AmpEnvBuffers* bf, int64_t N, uint32_t phases,

@@ -178,7 +178,7 @@ def test_env_step_full_size_properties(N):
     from humanoid_amp_amd import _native as nat
 
     nd, K = 29, 2
-    assert nat.load().amp_env_step_tile_envs(N) == {65536: 64, 40000: 32, 4097: 16}[N]
+    assert nat.load().amp_env_step_tile_envs(N) == {65536: 32, 40000: 32, 4097: 16}[N]
     g = torch.Generator(device="cuda").manual_seed(3)
     r = lambda *s: torch.randn(*s, generator=g, device="cuda")  # noqa: E731
     cfg = EnvStepConfig(n_dof=nd, num_amp_observations=K, max_episode_length=300, rew_termination=-1.0, rew_action_l2=-0.1,
