@@ -2,7 +2,7 @@
 // in-place K-frame history shift, policy observation (+ optional actor history with reset warm-start).
 // One pass, any subset of the three phases.  gfx950 only; -ffp-contract=off.
 //
-// Work decomposition: a workgroup (256 lanes) owns a TILE of 64 consecutive envs.
+// Work decomposition: a workgroup (256 lanes) owns a TILE of 32 / 16 consecutive envs (amp_env_step_tile_envs).
 //   stage   the tile's [64, n_dof] rows of joint_pos / joint_vel (/ actions / joint_acc) are contiguous in
 //           HBM: lanes walk them flat (coalesced) into the LDS observation tile.
 //   per-env wave 0, one env per lane: root-body features (quat_apply x2), done bits, wave ballot ->
@@ -666,9 +666,9 @@ using namespace amp;
 extern "C" {
 
 int32_t amp_env_step_tile_envs(int64_t num_envs) {
-  // measured (MI355X, G1 K=2): 65 536 envs 72 / 78 / 91 us with 64 / 32 / 16-env tiles; 16 384 envs 39 / 27 / 23 us
-  // envs per workgroup: 64 when that still gives >= 1024 workgroups (4 per CU), else smaller tiles so that a small
-  // shard is spread over the whole chip (the kernel is latency-bound there: one 64-env tile takes ~25 us alone)
+  // envs per workgroup.  Generic body, measured (MI355X, G1 K=2): 65 536 envs 72 / 78 / 91 us with 64 / 32 / 16-env
+  // tiles; 16 384 envs 39 / 27 / 23 us.  The fast body (32-env tile: 34 KB of LDS, 4 workgroups per CU) takes 42 us at
+  // 65 536 envs, so large shards use 32; small shards are spread over the whole chip with 16 (latency-bound there).
   if (num_envs >= 32 * 1024) return 32;
   return 16;
 }
