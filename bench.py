@@ -256,6 +256,13 @@ def main():
             traffic = tj[key]["hbm_bytes"] if args.envs >= 16384 else None
         except Exception:
             traffic = None
+        # fabric-side bytes of the env-step + expert-sample launch from the same PMC passes (it also writes the
+        # discriminator's scaled input, which the algorithmic count of SURVEY 8d does not include)
+        hbm_traffic = None
+        try:
+            hbm_traffic = tj[f"env_step_fast_reference_kernel<32>@{args.envs // 32 + args.envs * spec.K // 64}"]["hbm_bytes"]
+        except Exception:
+            hbm_traffic = None
         flops2 = (2.0 * args.envs * 1024 * 512 + 2.0 * args.envs * 512) / per_step   # layer 2 + the fused 512 -> 1 dot, per launch
         achieved = flops2 / (gemm2_ms * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS[args.disc_precision]
@@ -287,7 +294,10 @@ def main():
                          "vs_fp32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS},
             "roofline_hbm": {"bound": "hbm", "kernels": list(hbm_kernels), "achieved": alg_bytes / (hbm_us * 1e-6) / 1e9 if hbm_us else None,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (alg_bytes / (hbm_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if hbm_us else None,
-                             "bytes_per_env_step": algorithmic_bytes_per_env_step(spec), "us": hbm_us},
+                             "bytes_per_env_step": algorithmic_bytes_per_env_step(spec), "us": hbm_us,
+                             "traffic": hbm_traffic,
+                             "frac_moved": (hbm_traffic / (per_kernel["env_step_reference_kernel"] * 1e-6) / 1e9 / HBM_PEAK_GBS)
+                             if hbm_traffic and per_kernel.get("env_step_reference_kernel") else None},
             "kernel_us_per_step": per_kernel,
             "disc_flops_per_env_step": disc_flops_per_row(spec.K * spec.D),
         }
