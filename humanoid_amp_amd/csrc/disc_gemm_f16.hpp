@@ -87,6 +87,21 @@ __device__ __forceinline__ void split_planes4(const fv4 v, h4& p0, h4& p1) {
   }
 }
 
+// Hidden-layer epilogue for four accumulator values: the planes of max(acc * descale + bias, 0) * s_h.  descale and s_h
+// are powers of two, so this equals max(fma(acc, descale * s_h, bias * s_h), 0) bit for bit (scaling by a power of two
+// commutes with rounding) -- `ds` = descale * s_h, `bs` = bias * s_h; and v - p0 is exact in fp32, so the low plane is one
+// mixed-precision fma rounded once to fp16.  4 VALU operations per value instead of 10: at K = 192 the epilogue's
+// conversions cost as many SIMD cycles as the layer's MFMAs.
+__device__ __forceinline__ void relu_split4(const fv4 acc, const float ds, const fv4 bs, h4& p0, h4& p1) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float v = fmaxf(__builtin_fmaf(acc[i], ds, bs[i]), 0.0f);
+    const _Float16 a = (_Float16)v;
+    p0[i] = a;
+    p1[i] = (_Float16)__builtin_fmaf((float)a, -1.0f, v);
+  }
+}
+
 // planes of scale[0] * src[rows, cols] (row pitch ld_src floats) -> dst + p * plane, rows of ld_dst halves; columns in
 // [cols, ld_dst) are zero.  One thread per four columns.
 __global__ __launch_bounds__(kBlock) void split_rows_f16_kernel(const float* __restrict__ src, int64_t rows, int cols,
@@ -309,13 +324,12 @@ __global__ __launch_bounds__(kBlock, MINW) void disc_gemm_f16_kernel(GemmF16Args
       for (int b = 0; b < TN; ++b)
 #pragma unroll
         for (int grp = 0; grp < 4; ++grp) {
-          const fv4 bs = bias4[b * 8 + grp * 2];
+          const fv4 bs = bias4[b * 8 + grp * 2] * s_h;
           fv4 v;
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            v[i] = fmaxf(acc[a][b][4 * grp + i] * descale + bs[i], 0.0f) * s_h;
+          for (int i = 0; i < 4; ++i) v[i] = acc[a][b][4 * grp + i];
           h4 p0, p1;
-          split_planes4(v, p0, p1);
+          relu_split4(v, descale * s_h, bs, p0, p1);
           const int col = b * 32 + 8 * grp + 4 * lh;
           *reinterpret_cast<h4*>(&ep[li * EPL + col]) = p0;
           *reinterpret_cast<h4*>(&ep[32 * EPL + li * EPL + col]) = p1;

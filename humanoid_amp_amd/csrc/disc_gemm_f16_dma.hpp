@@ -241,12 +241,12 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN>::kWgPerCu)) void disc
       for (int b = 0; b < TN; ++b)
 #pragma unroll
         for (int grp4 = 0; grp4 < 4; ++grp4) {
-          const fv4 bs = bias4[b * 8 + grp4 * 2];
+          const fv4 bs = bias4[b * 8 + grp4 * 2] * s_h;
           fv4 v;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = fmaxf(acc[a][b][4 * grp4 + i] * descale + bs[i], 0.0f) * s_h;
+          for (int i = 0; i < 4; ++i) v[i] = acc[a][b][4 * grp4 + i];
           h4 p0, p1;
-          split_planes4(v, p0, p1);
+          relu_split4(v, descale * s_h, bs, p0, p1);
           const int col = b * 32 + 8 * grp4 + 4 * lh;
           *reinterpret_cast<h4*>(&ep[li * EPL + col]) = p0;
           *reinterpret_cast<h4*>(&ep[32 * EPL + li * EPL + col]) = p1;

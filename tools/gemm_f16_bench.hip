@@ -59,6 +59,20 @@ __global__ __launch_bounds__(256) void store_only_kernel(_Float16* out, int64_t 
   }
 }
 
+// The same bytes in the GEMM epilogue's ORDER: a workgroup writes a 256-row x 1-KB column slab of the block-layout
+// hidden layer (row pitch `pitch` bytes), a wave one 1-KB row segment per instruction.
+__global__ __launch_bounds__(256) void store_tiles_kernel(unsigned char* out, int64_t rows, int64_t pitch) {
+  const int slabs = (int)(pitch / 1024);
+  const int64_t mt = blockIdx.x / slabs;
+  const int nt = blockIdx.x % slabs;
+  if (mt * 256 >= rows) return;
+  uv4 v;
+  v[0] = v[1] = v[2] = v[3] = threadIdx.x;
+  unsigned char* base = out + mt * 256 * pitch + (int64_t)nt * 1024 + (threadIdx.x & 63) * 16;
+#pragma unroll 8
+  for (int i = 0; i < 64; ++i) *reinterpret_cast<uv4*>(base + (int64_t)(i * 4 + (threadIdx.x >> 6)) * pitch) = v;
+}
+
 // Fill-path probe: one 512-thread workgroup per CU streams its 256-row A slab and the shared 256-row B slab into
 // LDS by LDS-DMA exactly like disc_gemm_f16_dma_kernel (4 x 32-KB ring, counted vmcnt, one barrier per k-step) but
 // computes nothing.  SEG = bytes a piece takes from one row: 32 (k-step 16), 64 or 128.
@@ -327,7 +341,7 @@ int main(int argc, char** argv) {
     calib<4>((float*)Hp, 1, 2048);   // ~200 us
     calib<4>((float*)Hp, 2, 2048);
     calib<4>((float*)Hp, 1, 16384);  // ~1.7 ms
-    for (int grid : {2048, 8192, 65536}) {
+    for (int grid : {256, 512, 1024, 2048, 8192, 65536}) {  // 256 threads each: 256 -> one 4-wave workgroup per CU
       hipEvent_t a, b;
       CK(hipEventCreate(&a));
       CK(hipEventCreate(&b));
@@ -340,6 +354,22 @@ int main(int argc, char** argv) {
       float ms;
       CK(hipEventElapsedTime(&ms, a, b));
       printf("store-only %lld x 1024 x 2 planes (%.0f MB), grid %d: %.1f us  %.2f TB/s\n", (long long)M, M * 4096.0 / 1e6, grid, ms * 200,
+             M * 4096.0 / (ms / 5 * 1e-3) / 1e12);
+    }
+    {
+      hipEvent_t a, b;
+      CK(hipEventCreate(&a));
+      CK(hipEventCreate(&b));
+      const unsigned grid = (unsigned)((M + 255) / 256 * 4);
+      store_tiles_kernel<<<grid, 256>>>((unsigned char*)Hp, M, 4096);
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(a));
+      for (int i = 0; i < 5; ++i) store_tiles_kernel<<<grid, 256>>>((unsigned char*)Hp, M, 4096);
+      CK(hipEventRecord(b));
+      CK(hipEventSynchronize(b));
+      float ms;
+      CK(hipEventElapsedTime(&ms, a, b));
+      printf("store-only, tile order (256-row x 1-KB slabs, 4-KB row pitch), grid %u: %.1f us  %.2f TB/s\n", grid, ms * 200,
              M * 4096.0 / (ms / 5 * 1e-3) / 1e12);
     }
     return 0;
