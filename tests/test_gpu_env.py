@@ -229,3 +229,44 @@ def test_fused_expert_launch_is_bit_identical(workload, envs):
                                           k.reset_ids, k.reset_count, hot.last["style"])]
     for a, b in zip(res[False], res[True]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("N", [4097, 40000])  # 16- and 32-env tiles, the first with a ragged last tile
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_fast_tile_body_matches_generic_body(N, precision):
+    """The hot-path configuration (all phases, K = 2, contiguous inputs) runs env_step_fast_body; the same values handed
+    over as row-strided views take the generic body.  Every output, including the discriminator's fused scaled input
+    (fp16 plane pairs / fp32 rows), must agree bit for bit."""
+    from humanoid_amp_amd.engine import AmpDiscriminator, EnvStepConfig, EnvStepKernel
+    from humanoid_amp_amd import _native as nat
+    from humanoid_amp_amd.workloads import make_disc_weights
+
+    nd, K = 29, 2
+    g = torch.Generator(device="cuda").manual_seed(5)
+    r = lambda *s: torch.randn(*s, generator=g, device="cuda")  # noqa: E731
+    cfg = EnvStepConfig(n_dof=nd, num_amp_observations=K, max_episode_length=300, rew_termination=-1.0, rew_action_l2=-0.1,
+                        rew_joint_pos_limits=-10.0, rew_joint_acc_l2=-1e-6, rew_joint_vel_l2=-1e-3, rew_track_vel=1.0)
+    D = cfg.amp_frame_size
+    disc = AmpDiscriminator(make_disc_weights(K * D, seed=0), "cuda:0", running_mean=torch.randn(K * D, dtype=torch.float64) * 0.1,
+                            running_variance=torch.rand(K * D, dtype=torch.float64) + 0.5, precision=precision)
+    st = dict(joint_pos=r(N, nd), joint_vel=r(N, nd), joint_acc=r(N, nd) * 30, actions=r(N, nd) * 0.5,
+              root_pos=torch.cat([r(N, 2), torch.rand(N, 1, generator=g, device="cuda") * 0.6 + 0.35], 1).contiguous(),
+              root_quat=torch.nn.functional.normalize(r(N, 4), dim=1), root_lin_vel=r(N, 3), root_ang_vel=r(N, 3),
+              body_pos=r(N, 4, 3), key_body_indexes=[0, 1, 2, 3],
+              soft_limits=torch.tensor([[-1.41, 1.41]] * nd, device="cuda"),
+              episode_length=torch.randint(0, 300, (N,), generator=g, device="cuda"), command=r(N, 2), last_actions=r(N, nd))
+    strided = dict(st)
+    for name in ("joint_pos", "joint_vel", "joint_acc", "actions"):  # [N, nd] views of [N, nd + 3] rows: not flat
+        wide = torch.zeros(N, nd + 3, device="cuda")
+        wide[:, :nd] = st[name]
+        strided[name] = wide[:, :nd]
+    a, b = EnvStepKernel(cfg, N, "cuda:0"), EnvStepKernel(cfg, N, "cuda:0")
+    init = r(N, K, D)
+    for k in (a, b):
+        k.amp_observation_buffer.copy_(init)
+        k.attach_discriminator(disc)
+    a.launch(nat.AMP_PHASE_ALL, **st)
+    b.launch(nat.AMP_PHASE_ALL, **strided)
+    for name in ("amp_observation_buffer", "policy_obs", "reward", "died", "time_out", "reset_mask", "reset_tile_counts", "disc_input"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert a.disc_input.abs().sum() > 0
