@@ -381,6 +381,17 @@ int main(int argc, char** argv) {
     fill_probe<32>(Ap, M, K, Wp, N, P);
     return 0;
   }
+  if (getenv("SMALL")) {  // rectangular register-staged tiles for shards that 64 x 64 tiles spread thin
+    for (int r = 0; r < 2; ++r) {
+      V(1, 1, 64, 4, 1); check(N / 64);
+      V(2, 1, 64, 2, 1); check(N / 64);
+      V(1, 2, 64, 2, 1); check(N / 128);
+      V(2, 1, 32, 3, 1); check(N / 64);
+      V(1, 2, 32, 3, 1); check(N / 128);
+      V(2, 1, 64, 3, 1); check(N / 64);
+    }
+    return 0;
+  }
   if (getenv("TILES")) {
     for (int rep = 0; rep < 3; ++rep) {
       if (mode == 0) {
