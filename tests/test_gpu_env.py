@@ -231,9 +231,9 @@ def test_fused_expert_launch_is_bit_identical(workload, envs):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("N", [4097, 40000])  # 16- and 32-env tiles, the first with a ragged last tile
+@pytest.mark.parametrize("N,K", [(4097, 2), (40000, 2), (1000, 10)])  # 16- / 32-env tiles, ragged last tiles; K = 10: generic both ways
 @pytest.mark.parametrize("precision", ["f16x3", "f32"])
-def test_fast_tile_body_matches_generic_body(N, precision):
+def test_fast_tile_body_matches_generic_body(N, K, precision):
     """The hot-path configuration (all phases, K = 2, contiguous inputs) runs env_step_fast_body; the same values handed
     over as row-strided views take the generic body.  Every output, including the discriminator's fused scaled input
     (fp16 plane pairs / fp32 rows), must agree bit for bit."""
@@ -241,7 +241,7 @@ def test_fast_tile_body_matches_generic_body(N, precision):
     from humanoid_amp_amd import _native as nat
     from humanoid_amp_amd.workloads import make_disc_weights
 
-    nd, K = 29, 2
+    nd = 29
     g = torch.Generator(device="cuda").manual_seed(5)
     r = lambda *s: torch.randn(*s, generator=g, device="cuda")  # noqa: E731
     cfg = EnvStepConfig(n_dof=nd, num_amp_observations=K, max_episode_length=300, rew_termination=-1.0, rew_action_l2=-0.1,
