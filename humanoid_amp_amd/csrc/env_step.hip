@@ -43,6 +43,10 @@ __device__ __forceinline__ void env_step_body(const EnvPlan& p, const AmpSimStat
   int* s_flag = reinterpret_cast<int*>(s_red + 4 * kTileEnvs);  // [64] just_reset
   float* s_lim = reinterpret_cast<float*>(s_flag + kTileEnvs);  // [64 | 1, 2*nd + 1] soft joint limits (reward)
   const int lim_row = 2 * nd + 1;                                // odd stride: conflict-free one-env-per-lane reads
+  // scaler statistics of the fused discriminator input, staged once: the write loops then read LDS instead of waiting on
+  // two global loads per element
+  float* s_mu = s_lim + ((p.phases & AMP_PHASE_REWARD) && p.reward_mode == 1 && st.soft_limits_stride != 0 ? kTileEnvs : 1) * lim_row;
+  float* s_dn = s_mu + p.K * D;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t tile_base = block * kTileEnvs;
@@ -52,6 +56,8 @@ __device__ __forceinline__ void env_step_body(const EnvPlan& p, const AmpSimStat
   const bool do_obs = p.phases & AMP_PHASE_OBS;
   const bool g1_rew = do_rew && p.reward_mode == 1;
 
+  if (do_obs && bf.disc_input != nullptr && bf.scaler_mean != nullptr)
+    for (int c = tid; c < p.K * D; c += kBlock) { s_mu[c] = bf.scaler_mean[c]; s_dn[c] = bf.scaler_den[c]; }
   // ---- stage the contiguous per-DoF rows of the tile into LDS -----------------------------------
   if (do_obs || g1_rew) {
     for (int e = tid; e < n_tile * nd; e += kBlock) {
@@ -202,12 +208,11 @@ __device__ __forceinline__ void env_step_body(const EnvPlan& p, const AmpSimStat
     const bool fused = bf.disc_input != nullptr;
     uint32_t* const xs = reinterpret_cast<uint32_t*>(bf.disc_input) + tile_base * bf.disc_input_stride;
     const float s_x = bf.disc_plane_scale;
-    const float* const mu = bf.scaler_mean;
-    const float* const dn = bf.scaler_den;
+    const bool scaled = bf.scaler_mean != nullptr;
     const float clip = bf.scaler_clip;
     auto emit = [&](int64_t off, float v, int c) {  // same operations, in the same order, as disc.hip's scaler passes
-      if (mu) {
-        v = (v - mu[c]) / dn[c];  // skrl RunningStandardScaler, exact fp32 divide
+      if (scaled) {
+        v = (v - s_mu[c]) / s_dn[c];  // skrl RunningStandardScaler, exact fp32 divide
         v = fminf(fmaxf(v, -clip), clip);
       }
       xs[off] = pairs ? plane_pair(v * s_x) : __float_as_uint(v);
@@ -725,7 +730,8 @@ static int env_step_launch(const AmpEnvCfg* cfg, const AmpSimState* st, const Am
   const bool per_env_limits = g1_rew && st->soft_limits_stride != 0;
   const int tile = amp_env_step_tile_envs(N);
   const size_t lds = sizeof(float) * ((size_t)tile * p.D + 2 * (size_t)tile * p.dof_pad + 4 * tile) + sizeof(int) * tile +
-                     sizeof(float) * (size_t)(per_env_limits ? tile : 1) * (2 * p.n_dof + 1);
+                     sizeof(float) * (size_t)(per_env_limits ? tile : 1) * (2 * p.n_dof + 1) +
+                     sizeof(float) * 2 * (size_t)p.K * p.D;  // + the scaler statistics of the fused discriminator input
   AMP_REQUIRE(lds <= 64 * 1024, "amp_env_step: observation tile needs %zu B of LDS (> 64 KiB)", lds);
   const unsigned grid = (unsigned)((N + tile - 1) / tile);
   const bool with_expert = expert && expert->n > 0;
