@@ -167,11 +167,18 @@ __global__ __launch_bounds__(kBlock) void disc_weight_range_kernel(const float* 
     wmax2 = fmaxf(wmax2, __shfl_xor(wmax2, o, 64));
     bmax = fmaxf(bmax, __shfl_xor(bmax, o, 64));
   }
+  // one atomic per workgroup and slot: atomics on one address serialise in the L2 (~50 ns each; 1 024 of them per slot
+  // made this kernel 51 us)
+  __shared__ float red[4][kBlock / kWave];
   if (lane == 0) {
-    atomicMax(slot + 0, __float_as_uint(wmax1));
-    atomicMax(slot + 1, __float_as_uint(wmax2));
-    atomicMax(slot + 2, __float_as_uint(rsum_max));
-    atomicMax(slot + 3, __float_as_uint(bmax));
+    const int w = threadIdx.x >> 6;
+    red[0][w] = wmax1; red[1][w] = wmax2; red[2][w] = rsum_max; red[3][w] = bmax;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    float m = 0.0f;
+    for (int w = 0; w < kBlock / kWave; ++w) m = fmaxf(m, red[threadIdx.x][w]);
+    atomicMax(slot + threadIdx.x, __float_as_uint(m));
   }
 }
 __global__ void disc_weight_range_finish_kernel(DiscRange* r) {
@@ -397,7 +404,7 @@ static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* a
 static int f16_refresh(AmpDisc* h, hipStream_t st) {
   AMP_HIP(hipMemsetAsync(h->range, 0, 4 * sizeof(float), st));  // the four maxima (the clamp behind them stays)
   { amp::TraceScope trace__("disc_weight_range_kernel", st);
-    disc_weight_range_kernel<<<256, kBlock, 0, st>>>(h->w1p, h->h1, h->k1p, h->b1, h->w2, (int64_t)h->h2 * h->h1, h->range);
+    disc_weight_range_kernel<<<128, kBlock, 0, st>>>(h->w1p, h->h1, h->k1p, h->b1, h->w2, (int64_t)h->h2 * h->h1, h->range);
     disc_weight_range_finish_kernel<<<1, 1, 0, st>>>(h->range);
   }
   int rc = launch_status("disc_weight_range_kernel");
