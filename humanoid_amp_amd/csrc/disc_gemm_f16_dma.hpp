@@ -74,7 +74,8 @@ __global__ __launch_bounds__(kBlock) void split_rows_blocks_kernel(const float* 
 // Args: A = activations, row pitch 2 * lda halves (MODE 0: lda pairs per row; MODE 1: block layout of lda values);
 // W = weights in block layout, row pitch 2 * Kp halves; MODE 0 output H in block layout, row pitch 2 * ldh halves.
 // XP != 0: ablations for tools/gemm_f16_bench.hip (wrong results): 1 = no fills in the loop, 2 = also no fragment reads,
-// 3 = MODE 0 without the global stores of the epilogue, 4 = MODE 0 epilogue only (one k-block)
+// 3 = MODE 0 without the global stores of the epilogue, 4 = MODE 0 epilogue only (one k-block), 5 = no ping-pong (free-running
+// waves, one barrier per k-block; correct results: 106 us against 80 us at 32 768 rows of layer 2)
 template <int MODE, int XP = 0, int TM = 4, int TN = 2>
 __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN>::kWgPerCu)) void disc_gemm_f16_dma_kernel(GemmF16Args g) {
   using T = DmaTile<TM, TN>;
@@ -205,6 +206,40 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN>::kWgPerCu)) void disc
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();  // k-block 0 is visible to every wave
+  if (XP == 5) {
+    // ablation / experiment: no ping-pong -- every wave runs reads -> MFMAs -> reads -> MFMAs freely, ONE barrier per k-block
+    auto mfmas = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[b], x1[a], acc[a][b], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[b], x0[a], acc[a][b], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[b], x0[a], acc[a][b], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int q = 0; q < nq; ++q) {
+      const unsigned char* sb = lds + (q & 1) * kStage;
+      if (q >= 1 && q + 1 < nq) fill(q + 1, (q + 1) & 1);  // its last reads were retired in front of the barrier below
+      read_frags(sb, 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      mfmas();
+      read_frags(sb, 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      mfmas();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
   if (grp == 1) __builtin_amdgcn_s_barrier();
   for (int q = 0; q < nq; ++q) {
     const unsigned char* sb = lds + (q & 1) * kStage;
@@ -221,6 +256,7 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN>::kWgPerCu)) void disc
     matrix_segment(grp == 0);  // group 0's pieces: behind its MFMAs
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
+  }
   __syncthreads();  // every wave is done with the stages: the scratch below reuses them
 
   // ---- epilogue: register r of lane half lh is output column (r & 3) + 8 (r >> 2) + 4 lh of the 32-wide block,

@@ -427,6 +427,8 @@ int main(int argc, char** argv) {
     printf("  ^ no global loads / LDS writes (barriers kept)\n");
     run<2, 2, 64, 1, 2, 1, 2>(g, M, N, K, false);
     printf("  ^ no global loads / LDS writes / barriers: ds_read + MFMA only\n");
+    run_dma<1, 5>(g, M, N, K, false); check(N / 256);
+    puts("  ^ no ping-pong: free-running waves, one barrier per k-block");
     run_dma<1, 0>(g, M, N, K, false);
     printf("  ^ LDS-DMA kernel, full\n");
     run_dma<1, 1>(g, M, N, K, false);
