@@ -13,12 +13,13 @@ import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libamp_engine.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 AMP_DISC_F16X3, AMP_DISC_FP32 = 0, 1
 AMP_DISC_INPUT_F32_ROWS, AMP_DISC_INPUT_F16_PAIRS = 0, 1
 AMP_PHASE_DONES, AMP_PHASE_REWARD, AMP_PHASE_OBS = 1, 2, 4
 AMP_PHASE_ALL = 7
+AMP_COMMAND_TICK, AMP_COMMAND_RESET = 0, 1
 TILE_ENVS = 64
 
 
@@ -41,6 +42,15 @@ class AmpResetArgs(C.Structure):
         ("start", C.c_int32), ("K", C.c_int32), ("env_origins", C.c_void_p), ("z_lift", C.c_float), ("reserved", C.c_int32),
         ("root_state", C.c_void_p), ("dof_pos", C.c_void_p), ("dof_vel", C.c_void_p), ("amp_obs_buffer", C.c_void_p),
         ("motion_ids", C.c_void_p), ("motion_times", C.c_void_p),
+        ("env_motion_ids", C.c_void_p), ("env_motion_start_times", C.c_void_p), ("env_offset", C.c_int64),
+    ]
+
+
+class AmpCommandArgs(C.Structure):
+    _fields_ = [
+        ("command", C.c_void_p), ("time_left", C.c_void_p), ("step_dt", C.c_float), ("vel_lo", C.c_float), ("vel_span", C.c_float),
+        ("t_lo", C.c_float), ("t_span", C.c_float), ("reserved", C.c_int32), ("seed", C.c_uint64), ("step", C.c_uint64),
+        ("env_offset", C.c_int64), ("reset_mask", C.c_void_p), ("env_ids", C.c_void_p), ("count", C.c_void_p), ("n_ids", C.c_int64),
     ]
 
 
@@ -141,12 +151,15 @@ SIGNATURES = {
     "amp_env_step": (C.c_int, [C.POINTER(AmpEnvCfg), C.POINTER(AmpSimState), C.POINTER(AmpEnvBuffers), _i64, C.c_uint32, _vp]),
     "amp_env_step_with_reference": (C.c_int, [C.POINTER(AmpEnvCfg), C.POINTER(AmpSimState), C.POINTER(AmpEnvBuffers), _i64, C.c_uint32,
                                               _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "amp_command_step": (C.c_int, [C.POINTER(AmpCommandArgs), _i64, _i32, _vp]),
+    "amp_reward_log_means": (C.c_int, [_vp, _i32, _i64, _vp, _vp]),
     "amp_reset_compact_workspace_bytes": (_i64, [_i64]),
     "amp_reset_compact": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "amp_reset_compact_tiles": (C.c_int, [_vp, _vp, _i32, _i64, _vp, _vp, _vp]),
     "amp_env_step_tile_envs": (_i32, [_i64]),
     "amp_disc_create": (C.c_int, [C.POINTER(AmpDiscDesc), _vp, C.POINTER(_vp)]),
     "amp_disc_destroy": (C.c_int, [_vp]),
+    "amp_disc_set_weights": (C.c_int, [_vp, C.POINTER(AmpDiscDesc), _vp]),
     "amp_disc_set_scaler": (C.c_int, [_vp, _vp, _vp, _f32, _f32, _vp]),
     "amp_disc_set_precision": (C.c_int, [_vp, _i32, _vp]),
     "amp_disc_workspace_bytes": (_i64, [_vp, _i64]),

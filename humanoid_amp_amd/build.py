@@ -8,8 +8,17 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["core.hip", "motion.hip", "env_step.hip", "compact.hip", "disc.hip", "disc_train.hip", "ring.hip", "convert.hip"]
-HEADERS = ["amp_common.hpp", "disc_gemm.hpp", "disc_gemm_f16.hpp", "disc_gemm_f16_dma.hpp", os.path.join("..", "..", "include", "amp_engine.h")]
+SOURCES = ["core.hip", "motion.hip", "env_step.hip", "compact.hip", "command.hip", "disc.hip", "disc_train.hip", "ring.hip", "convert.hip"]
+
+
+
+def _headers():
+    """Every header a source may include: all of csrc/*.hpp (globbed, so a new header cannot be forgotten) + the ABI."""
+    import glob
+
+    return sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + [os.path.join(HERE, "..", "include", "amp_engine.h")]
+
+
 LIB = os.path.join(CSRC, "libamp_engine.so")
 # -ffp-contract=off: the reference's fp32 op order (separate mul/sub in sqrt(1 - c*c), rounded quaternion dot)
 # is part of the parity contract (SURVEY.md section 7); never -ffast-math.
@@ -28,7 +37,7 @@ def is_stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + _headers() + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -36,7 +45,28 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
     """Compile every HIP source into libamp_engine.so; returns its path."""
     if not force and not is_stale():
         return LIB
-    cmd = [_hipcc()] + FLAGS + ["-o", LIB + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
+    # one object per source, compiled in parallel (objects live under csrc/build/, git-ignored), then one link
+    from concurrent.futures import ThreadPoolExecutor
+
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    cflags = [f for f in FLAGS if f != "-shared"] + ["-c"]
+    hdr_time = max(os.path.getmtime(h) for h in _headers() + [os.path.abspath(__file__)])
+
+    def compile_one(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        path = os.path.join(CSRC, src)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_time):
+            return obj
+        cmd = [_hipcc()] + cflags + ["-o", obj, path]
+        if verbose:
+            print("[humanoid_amp_amd.build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs
     if verbose:
         print("[humanoid_amp_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)

@@ -1,0 +1,124 @@
+// Velocity-command timers of the G1 env and the lazily read reward-log means.
+//
+//   command_kernel   G1AmpEnv._pre_physics_step (g1_amp_env.py:146-167): time_left -= step_dt; envs whose timer expired
+//                    get command ~ U(lo, hi)^2 and time_left ~ U(t_lo, t_hi) -- and the reset-side resample of
+//                    _reset_strategy_random (g1_amp_env.py:421-439): the same draw for the reset envs, or the fixed command
+//                    (lo, 0) with an infinite timer when the range is empty.  The reference draws with torch.rand on the
+//                    global CUDA generator after a nonzero() host sync; here the draw is counter-based (Philox4x32-10 keyed
+//                    by seed, counter = (global env id, step), domain-separated from the reset-time draw of
+//                    sample_times_kernel by the key's high word), so an env's command depends on (seed, step, env) only:
+//                    no sync, no dependence on how the envs are sharded.  Parity with the reference is distributional by
+//                    construction; bit-exact against oracle/rng.py::command_draw.
+//   reward_log_means_kernel  the six to eight `.mean().item()` of _get_rewards (g1_amp_env.py:291-305) as ONE launch over
+//                    reward_terms [T, N] -> means [T] on the device (fp64 accumulation, fixed order: deterministic); the
+//                    host reads them only when extras["log"] is actually looked at.
+#include "amp_common.hpp"
+
+namespace amp {
+
+constexpr uint32_t kCommandDomain = 0xA14C0000u;  // xor-ed into the key's high word: tick = +0, reset = +1
+
+__device__ __forceinline__ float u01_24(uint32_t r) { return (float)(r >> 8) * 5.9604644775390625e-08f; }  // [0, 1), 24 bits
+
+__device__ __forceinline__ void draw_command(uint64_t seed, uint64_t step, uint64_t env, uint32_t mode, float vel_lo,
+                                             float vel_span, float t_lo, float t_span, float& cx, float& cy, float& tl) {
+  uint32_t r[4];
+  philox4x32_10((uint32_t)env, (uint32_t)(env >> 32), (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)seed,
+                (uint32_t)(seed >> 32) ^ (kCommandDomain + mode), r);
+  // torch.rand(...) * (hi - lo) + lo: one fp32 multiply, one fp32 add (contraction is off)
+  cx = u01_24(r[0]) * vel_span + vel_lo;
+  cy = u01_24(r[1]) * vel_span + vel_lo;
+  tl = u01_24(r[2]) * t_span + t_lo;
+}
+
+__global__ __launch_bounds__(kBlock) void command_kernel(AmpCommandArgs a, int64_t N, int mode) {
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  int64_t env = i;
+  if (mode == AMP_COMMAND_RESET && a.env_ids) {
+    int64_t n = a.n_ids;
+    if (a.count) n = *a.count < n ? *a.count : n;
+    if (i >= n) return;
+    env = a.env_ids[i];
+    if (env < 0 || env >= N) return;
+  } else if (i >= N) {
+    return;
+  }
+  const bool ranged = a.vel_span > 0.0f;
+  if (mode == AMP_COMMAND_TICK) {
+    const float left = a.time_left[env] - a.step_dt;  // command_time_left -= step_dt
+    if (left <= 0.0f && ranged) {
+      float cx, cy, tl;
+      draw_command(a.seed, a.step, (uint64_t)(a.env_offset + env), 0u, a.vel_lo, a.vel_span, a.t_lo, a.t_span, cx, cy, tl);
+      a.command[2 * env] = cx;
+      a.command[2 * env + 1] = cy;
+      a.time_left[env] = tl;
+    } else {
+      a.time_left[env] = left;
+    }
+    return;
+  }
+  if (!a.env_ids && !(a.reset_mask && a.reset_mask[env])) return;
+  if (ranged) {
+    float cx, cy, tl;
+    draw_command(a.seed, a.step, (uint64_t)(a.env_offset + env), 1u, a.vel_lo, a.vel_span, a.t_lo, a.t_span, cx, cy, tl);
+    a.command[2 * env] = cx;
+    a.command[2 * env + 1] = cy;
+    a.time_left[env] = tl;
+  } else {  // fixed command (g1_amp_env.py:436-439)
+    a.command[2 * env] = a.vel_lo;
+    a.command[2 * env + 1] = 0.0f;
+    a.time_left[env] = __builtin_inff();
+  }
+}
+
+// one workgroup per term: thread t sums elements t, t + 256, ... in fp64, then a fixed binary tree over the 256 threads
+__global__ __launch_bounds__(kBlock) void reward_log_means_kernel(const float* __restrict__ terms, int64_t N,
+                                                                  float* __restrict__ means) {
+  __shared__ double red[kBlock];
+  const float* row = terms + (int64_t)blockIdx.x * N;
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < N; i += kBlock) s += (double)row[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) means[blockIdx.x] = (float)(red[0] / (double)N);
+}
+
+}  // namespace amp
+
+using namespace amp;
+
+extern "C" {
+
+int amp_command_step(const AmpCommandArgs* a, int64_t num_envs, int32_t mode, amp_stream_t stream) {
+  AMP_REQUIRE(a, "amp_command_step: null argument");
+  AMP_REQUIRE(num_envs >= 0, "amp_command_step: negative num_envs");
+  AMP_REQUIRE(mode == AMP_COMMAND_TICK || mode == AMP_COMMAND_RESET, "amp_command_step: mode must be AMP_COMMAND_TICK (0) or AMP_COMMAND_RESET (1)");
+  if (num_envs == 0) return AMP_OK;
+  AMP_REQUIRE(a->command && a->time_left, "amp_command_step: null buffer");
+  AMP_REQUIRE(mode == AMP_COMMAND_TICK || a->reset_mask || a->env_ids, "amp_command_step: the reset mode needs reset_mask or env_ids");
+  AMP_REQUIRE(!(a->vel_span > 0.0f) || a->t_span >= 0.0f, "amp_command_step: negative resampling-time span");
+  AMP_REQUIRE(a->env_ids == nullptr || a->n_ids >= 0, "amp_command_step: negative n_ids");
+  const int64_t threads = (mode == AMP_COMMAND_RESET && a->env_ids) ? a->n_ids : num_envs;
+  if (threads == 0) return AMP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  { amp::TraceScope trace__("command_kernel", st);
+    command_kernel<<<(unsigned)((threads + kBlock - 1) / kBlock), kBlock, 0, st>>>(*a, num_envs, mode);
+  }
+  return launch_status("command_kernel");
+}
+
+int amp_reward_log_means(const float* reward_terms, int32_t n_terms, int64_t num_envs, float* means, amp_stream_t stream) {
+  AMP_REQUIRE(reward_terms && means, "amp_reward_log_means: null buffer");
+  AMP_REQUIRE(n_terms >= 1 && n_terms <= 64 && num_envs >= 1, "amp_reward_log_means: need 1..64 terms and >= 1 env");
+  hipStream_t st = (hipStream_t)stream;
+  { amp::TraceScope trace__("reward_log_means_kernel", st);
+    reward_log_means_kernel<<<(unsigned)n_terms, kBlock, 0, st>>>(reward_terms, num_envs, means);
+  }
+  return launch_status("reward_log_means_kernel");
+}
+
+}  // extern "C"

@@ -309,15 +309,18 @@ static int launch_f16(GemmF16Args g, int64_t rows, int N, const char* name, hipS
 }
 // kernels whose LDS tile exceeds the 64 KB default need the limit raised once (not capturable: done at create)
 static int f16_kernels_init() {
-  static bool done = false;
-  if (done) return AMP_OK;
+  // the attribute is per DEVICE: a process that creates discriminators on several GPUs raises the limit on each
+  static bool done[64] = {};
+  int dev = 0;
+  AMP_HIP(hipGetDevice(&dev));
+  if (dev >= 0 && dev < 64 && done[dev]) return AMP_OK;
   AMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gemm_f16_kernel<2, 2, 64, 1, 2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, gemm_f16_lds_bytes<2, 2, 64>()));
   AMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gemm_f16_dma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               kDmaLdsBytes));
   AMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gemm_f16_dma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               kDmaLdsBytes));
-  done = true;
+  if (dev >= 0 && dev < 64) done[dev] = true;
   return AMP_OK;
 }
 // Row chunking of a large shard: layer 1 writes the hidden layer of a chunk (4 KB / row) and layer 2 reads it back
@@ -513,6 +516,29 @@ int amp_disc_create(const AmpDiscDesc* d, amp_stream_t stream, AmpDisc** out) {
   }
   *out = h;
   return AMP_OK;
+}
+
+int amp_disc_set_weights(AmpDisc* h, const AmpDiscDesc* d, amp_stream_t stream) {
+  AMP_REQUIRE(h && d, "amp_disc_set_weights: null argument");
+  AMP_REQUIRE(d->in_dim == h->in_dim && d->h1 == h->h1 && d->h2 == h->h2,
+              "amp_disc_set_weights: shape [%d,%d,%d] does not match the handle's [%d,%d,%d]", d->in_dim, d->h1, d->h2, h->in_dim,
+              h->h1, h->h2);
+  AMP_REQUIRE(d->w1 && d->b1 && d->w2 && d->b2 && d->w3 && d->b3, "amp_disc_set_weights: null weight pointer");
+  hipStream_t st = (hipStream_t)stream;
+  // device-to-device copies into the handle's own buffers: no allocation, no sync; scaler, precision and every device
+  // pointer handed out earlier (amp_disc_input_layout, a trainer's view of the weights) stay valid
+  AMP_HIP(hipMemcpyAsync(h->b1, d->b1, sizeof(float) * h->h1, hipMemcpyDeviceToDevice, st));
+  AMP_HIP(hipMemcpyAsync(h->w2, d->w2, sizeof(float) * (size_t)h->h2 * h->h1, hipMemcpyDeviceToDevice, st));
+  AMP_HIP(hipMemcpyAsync(h->b2, d->b2, sizeof(float) * h->h2, hipMemcpyDeviceToDevice, st));
+  AMP_HIP(hipMemcpyAsync(h->w3, d->w3, sizeof(float) * h->h2, hipMemcpyDeviceToDevice, st));
+  AMP_HIP(hipMemcpyAsync(h->b3, d->b3, sizeof(float), hipMemcpyDeviceToDevice, st));
+  const int64_t total = (int64_t)h->h1 * h->k1p;
+  { amp::TraceScope trace__("disc_pad_rows_kernel", st);
+    disc_pad_rows_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(d->w1, h->h1, h->in_dim, h->k1p, h->w1p);
+  }
+  int rc = launch_status("disc_pad_rows_kernel");
+  if (rc != AMP_OK) return rc;
+  return f16_refresh(h, st);
 }
 
 int amp_disc_set_scaler(AmpDisc* h, const double* mean, const double* var, float eps, float clip, amp_stream_t stream) {

@@ -212,19 +212,26 @@ __global__ __launch_bounds__(kBlock) void reset_state_kernel(MotionView v, const
 __global__ __launch_bounds__(kBlock) void sample_times_kernel(ClipMeta m, uint64_t seed, uint64_t step, int start,
                                                               const int64_t* __restrict__ index, int64_t n,
                                                               const int64_t* __restrict__ n_dev,
-                                                              int64_t* __restrict__ o_ids, double* __restrict__ o_t) {
+                                                              int64_t* __restrict__ o_ids, double* __restrict__ o_t,
+                                                              int64_t* __restrict__ env_ids_out,
+                                                              float* __restrict__ env_t_out, int64_t ctr_offset) {
   if (n_dev) n = *n_dev < n ? *n_dev : n;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const uint64_t idx = (uint64_t)(index ? index[i] : i);
+  const uint64_t ctr = idx + (uint64_t)ctr_offset;  // global env id of a shard's local env: the draw is shard-invariant
   uint32_t r[4];
-  philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)seed,
+  philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)seed,
                 (uint32_t)(seed >> 32), r);
   const int64_t clip = (int64_t)(((uint64_t)r[0] * (uint64_t)m.n_clips) >> 32);  // uniform in [0, n_clips)
   // 53-bit uniform in [0, 1) from two words, numpy's random_sample construction
   const double u = ((double)(r[1] >> 5) * 67108864.0 + (double)(r[2] >> 6)) / 9007199254740992.0;
+  const double t = start ? 0.0 : u * m.dur[clip];
   o_ids[i] = clip;
-  o_t[i] = start ? 0.0 : u * m.dur[clip];
+  o_t[i] = t;
+  // per-env mirrors (self.motion_ids[env_ids] = ..., self.motion_start_times[env_ids] = ..., g1_amp_env.py:377-382)
+  if (env_ids_out) env_ids_out[idx] = clip;
+  if (env_t_out) env_t_out[idx] = (float)t;
 }
 
 static inline unsigned grid_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
@@ -397,7 +404,7 @@ int amp_motion_sample_times(const AmpMotion* h, uint64_t seed, uint64_t step, in
   AMP_REQUIRE(motion_ids && times, "amp_motion_sample_times: null buffer");
   { amp::TraceScope trace__("sample_times_kernel", (hipStream_t)stream);
     sample_times_kernel<<<grid_for(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(h->v.clips, seed, step, start, index, n, n_dev,
-                                                                              motion_ids, times);
+                                                                              motion_ids, times, nullptr, nullptr, 0);
   }
   return launch_status("sample_times_kernel");
 }
@@ -412,7 +419,8 @@ int amp_reset_apply(const AmpMotion* h, const AmpResetArgs* a, amp_stream_t stre
   const int64_t n = a->max_n;
   { amp::TraceScope trace__("sample_times_kernel", st);
     sample_times_kernel<<<grid_for(n, kBlock), kBlock, 0, st>>>(h->v.clips, a->seed, a->step, a->start, a->env_ids, n, a->count,
-                                                             a->motion_ids, a->motion_times);
+                                                             a->motion_ids, a->motion_times, a->env_motion_ids,
+                                                             a->env_motion_start_times, a->env_offset);
   }
   int rc = launch_status("sample_times_kernel");
   if (rc != AMP_OK) return rc;

@@ -235,6 +235,82 @@ def reset_compact(mask: torch.Tensor):
     return ids, count
 
 
+def command_step(command: torch.Tensor, time_left: torch.Tensor, *, mode: int, step_dt: float, vel_range, time_range,
+                 seed: int, step: int, env_offset: int = 0, reset_mask: Optional[torch.Tensor] = None,
+                 env_ids: Optional[torch.Tensor] = None, count: Optional[torch.Tensor] = None) -> None:
+    """``amp_command_step``: the velocity-command timers of ``G1AmpEnv._pre_physics_step`` (``mode`` =
+    ``AMP_COMMAND_TICK``, g1_amp_env.py:146-167) or the reset-side resample (``AMP_COMMAND_RESET`` for the envs of
+    ``reset_mask`` or of ``env_ids[:count]``, g1_amp_env.py:421-439), in place, one launch, no host sync.  Draws are
+    counter-based: (seed, step, env_offset + env)."""
+    lib = nat.load()
+    dev = nat.require_gpu(command.device)
+    N = int(time_left.shape[0])
+    if tuple(command.shape) != (N, 2):
+        raise nat.AmpEngineError(f"command must be [N, 2] for time_left [N]; got {tuple(command.shape)} / {tuple(time_left.shape)}")
+    a = nat.AmpCommandArgs()
+    a.command, a.time_left = nat.dptr(command, torch.float32, "command").value, nat.dptr(time_left, torch.float32, "time_left").value
+    lo, hi = float(vel_range[0]), float(vel_range[1])
+    t_lo, t_hi = float(time_range[0]), float(time_range[1])
+    # the reference multiplies torch.rand by the python float (hi - lo): the span is formed in fp64, then rounded once
+    a.step_dt, a.vel_lo, a.vel_span, a.t_lo, a.t_span = float(step_dt), lo, hi - lo, t_lo, t_hi - t_lo
+    a.seed, a.step, a.env_offset = int(seed) & (2**64 - 1), int(step) & (2**64 - 1), int(env_offset)
+    if reset_mask is not None:
+        if reset_mask.dtype not in (torch.bool, torch.uint8) or reset_mask.numel() != N:
+            raise nat.AmpEngineError("reset_mask must be a bool / uint8 tensor with one entry per env")
+        a.reset_mask = nat.dptr(reset_mask, None, "reset_mask").value
+    if env_ids is not None:
+        a.env_ids, a.n_ids = nat.dptr(env_ids, torch.int64, "env_ids").value, int(env_ids.numel())
+        a.count = nat.dptr(count, torch.int64, "count").value
+    with torch.cuda.device(dev):
+        nat.check(lib.amp_command_step(C.byref(a), N, int(mode), nat.stream_ptr()), "amp_command_step")
+
+
+class LazyRewardLog(dict):
+    """``extras["log"]`` of the G1 env (g1_amp_env.py:291-305) without the per-step host sync: holds the DEVICE tensor
+    of term means (``amp_reward_log_means``, enqueued with the step) and reads it back the first time any entry is
+    looked at.  A plain ``dict`` of python floats from then on, which is what the reference hands to skrl."""
+
+    def __init__(self, names, means_dev: torch.Tensor, drop=()):
+        super().__init__()
+        self._names, self._means, self._drop = tuple(names), means_dev, frozenset(drop)
+
+    def _fill(self):
+        m, self._means = self._means, None
+        if m is not None:
+            for k, v in zip(self._names, m.tolist()):  # the one read-back, paid by whoever looks
+                if k not in self._drop:
+                    dict.__setitem__(self, k, v)
+
+    @property
+    def materialized(self) -> bool:
+        return self._means is None
+
+    def __getitem__(self, k): self._fill(); return dict.__getitem__(self, k)
+    def __iter__(self): self._fill(); return dict.__iter__(self)
+    def __len__(self): self._fill(); return dict.__len__(self)
+    def __contains__(self, k): self._fill(); return dict.__contains__(self, k)
+    def __repr__(self): self._fill(); return dict.__repr__(self)
+    def __eq__(self, o): self._fill(); return dict.__eq__(self, o)
+    def keys(self): self._fill(); return dict.keys(self)
+    def values(self): self._fill(); return dict.values(self)
+    def items(self): self._fill(); return dict.items(self)
+    def get(self, k, d=None): self._fill(); return dict.get(self, k, d)
+    def copy(self): self._fill(); return dict(self)
+    __hash__ = None
+
+
+def reward_log_means(reward_terms: torch.Tensor) -> torch.Tensor:
+    """Means over the envs of ``reward_terms [T, N]`` -> device tensor ``[T]`` (``amp_reward_log_means``; no sync)."""
+    lib = nat.load()
+    dev = nat.require_gpu(reward_terms.device)
+    T, N = reward_terms.shape
+    out = torch.empty(T, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        nat.check(lib.amp_reward_log_means(nat.dptr(reward_terms, torch.float32, "reward_terms"), int(T), int(N), nat.dptr(out),
+                                           nat.stream_ptr()), "amp_reward_log_means")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------
 # discriminator
 # ---------------------------------------------------------------------------------------------------
@@ -243,7 +319,8 @@ def reset_compact(mask: torch.Tensor):
 class AmpDiscriminator:
     """Inference half of skrl's AMP agent: ``amp_state_preprocessor`` -> discriminator MLP -> style reward
     (shape agents/skrl_g1_walk_amp_cfg.yaml:31-39; scales :88-95).  Weights are copied into the engine at
-    construction; ``load_state_dict``-style updates go through :meth:`set_weights`."""
+    construction; ``load_state_dict``-style updates go through :meth:`set_weights` (in place: ``amp_disc_set_weights``
+    keeps the handle, the scaler and attached kernels / trainers valid)."""
 
     def __init__(self, weights: Sequence, device, *, running_mean: Optional[torch.Tensor] = None,
                  running_variance: Optional[torch.Tensor] = None, epsilon: float = 1e-8, clip_threshold: float = 5.0,
@@ -280,10 +357,19 @@ class AmpDiscriminator:
         d = nat.AmpDiscDesc()
         d.in_dim, d.h1, d.h2 = int(w1.shape[1]), int(w1.shape[0]), int(w2.shape[0])
         d.w1, d.b1, d.w2, d.b2, d.w3, d.b3 = (t.data_ptr() for t in flat)
+        if self._handle is not None:
+            # in place: the handle, its scaler and every device pointer it handed out (attach_discriminator layouts,
+            # an attached trainer) stay valid; `flat` is read in stream order on the current stream
+            if (d.in_dim, d.h1, d.h2) != (self.in_dim, self._h1, self._h2):
+                raise ValueError(f"set_weights: layer shapes {(d.in_dim, d.h1, d.h2)} differ from the discriminator's "
+                                 f"{(self.in_dim, self._h1, self._h2)}; build a new AmpDiscriminator")
+            with torch.cuda.device(self.device):
+                nat.check(self._lib.amp_disc_set_weights(self._handle, C.byref(d), nat.stream_ptr()), "amp_disc_set_weights")
+            self._keepalive = flat  # until the next update: the copies above are asynchronous
+            return
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             nat.check(self._lib.amp_disc_create(C.byref(d), nat.stream_ptr(), C.byref(h)), "amp_disc_create")
-        self._destroy()
         self._handle = h
         self.in_dim, self._h1, self._h2 = d.in_dim, d.h1, d.h2
         with torch.cuda.device(self.device):

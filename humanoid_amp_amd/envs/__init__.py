@@ -15,7 +15,15 @@ def make(task_id: str, num_envs: int | None = None, device: str | None = None, *
         cfg.scene.num_envs = int(num_envs)
     if device is not None:
         cfg.sim.device = device
-    return {"G1AmpEnv": G1AmpEnv, "HumanoidAmpEnv": HumanoidAmpEnv}[cls_name](cfg, **kwargs)
+    try:
+        return {"G1AmpEnv": G1AmpEnv, "HumanoidAmpEnv": HumanoidAmpEnv}[cls_name](cfg, **kwargs)
+    except (ValueError, FileNotFoundError) as e:
+        if "No files found" in str(e) or isinstance(e, FileNotFoundError):
+            # same exception type as the reference's resolver (motion_loader.py:55,84), with the way out spelled out
+            raise ValueError(f"{task_id}: motion clip(s) {cfg.motion_file!r} are not shipped with this package "
+                             "(the reference does not distribute them either); pass your own via cfg.motion_file -- "
+                             f"{e}") from e
+        raise
 
 
 __all__ = ["G1AmpEnv", "HumanoidAmpEnv", "DirectRLEnv", "SyntheticArticulation", "TASKS", "make", "G1AmpEnvCfg",

@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 from .. import _native as nat
-from ..engine import EnvStepConfig, EnvStepKernel, REWARD_TERMS
+from ..engine import EnvStepConfig, EnvStepKernel, LazyRewardLog, REWARD_TERMS, command_step, reward_log_means
 from ..motions import MotionLoader
 from ..robots import G1_BODY_NAMES, G1_JOINT_NAMES, G1_KEY_BODY_NAMES, HUMANOID_KEY_BODY_NAMES
 from .direct_rl_env import DirectRLEnv
@@ -45,13 +45,17 @@ class _AmpEnv(DirectRLEnv):
     IS_G1 = True
 
     def __init__(self, cfg, render_mode: str | None = None, robot=None, log_rewards: bool = True,
-                 device_reset: bool = False, reset_seed: int = 0, **kwargs):
+                 device_reset: bool = False, reset_seed: int = 0, env_offset: int = 0, **kwargs):
         """``device_reset=True`` keeps the whole reset on the device (ids + count from the compaction kernel feed
         ``amp_reset_apply``; clip / time come from the engine's counter-based RNG keyed by ``reset_seed``): no host
-        sync and no numpy RNG inside ``step()``.  Needs a state provider with ``write_reset_compact`` (the synthetic
-        articulation has one); the reference's exact host-RNG sequence is then not reproduced (distribution is)."""
+        sync and no numpy RNG inside ``step()`` (``tests/test_gpu_reset_device.py`` steps under
+        ``torch.cuda.set_sync_debug_mode("error")``).  Needs a state provider with ``write_reset_compact`` (the
+        synthetic articulation has one); the reference's exact host-RNG sequence is then not reproduced (distribution
+        is).  ``env_offset``: global id of this shard's env 0 -- every counter-based draw is keyed by the GLOBAL env id,
+        so a sharded run draws what the unsharded run draws."""
         self._log_rewards = bool(log_rewards)
         self.device_reset, self._reset_seed, self._reset_out = bool(device_reset), int(reset_seed), None
+        self.env_offset = int(env_offset)
         super().__init__(cfg, render_mode, robot=robot, **kwargs)
         nat.require_gpu(self.device)
         data = self.robot.data
@@ -174,8 +178,11 @@ class _AmpEnv(DirectRLEnv):
         self._reset_out = self._motion_loader.reset_apply(
             ids, count, self.cfg.num_amp_observations, seed=self._reset_seed, step=self.common_step_counter,
             start="start" in self.cfg.reset_strategy, env_origins=self.scene.env_origins, z_lift=self.Z_LIFT,
-            amp_observation_buffer=self.amp_observation_buffer, out=self._reset_out)
+            amp_observation_buffer=self.amp_observation_buffer, out=self._reset_out,
+            env_motion_ids=self.motion_ids, env_motion_start_times=self.motion_start_times, env_offset=self.env_offset)
         o, mask = self._reset_out, self._kernel.reset_mask
+        if hasattr(self.robot, "reset_masked"):
+            self.robot.reset_masked(mask)
         self.robot.write_reset_compact(ids, count, o["root_state"], o["dof_pos"], o["dof_vel"])
         self.episode_length_buf.masked_fill_(mask, 0)
         self._after_reset_masked(mask)
@@ -225,44 +232,37 @@ class G1AmpEnv(_AmpEnv):
         return SyntheticArticulation(self.num_envs, G1_JOINT_NAMES, G1_BODY_NAMES, self.device, root_body="pelvis",
                                      dt=self.physics_dt)
 
+    def _command_step(self, mode: int, **which):
+        command_step(self.command_target_speed, self.command_time_left, mode=mode, step_dt=self.step_dt,
+                     vel_range=self.cfg.track_vel_range, time_range=self.cfg.command_resampling_time_range,
+                     seed=self._reset_seed, step=self.common_step_counter, env_offset=self.env_offset, **which)
+
     def _pre_physics_step(self, actions: torch.Tensor):
         self.actions = actions.clone()
-        self.command_time_left -= self.step_dt   # g1_amp_env.py:146-167
-        lo, hi = self.cfg.track_vel_range
-        if hi > lo:
-            expired = (self.command_time_left <= 0.0).nonzero(as_tuple=False).flatten()
-            if len(expired) > 0:
-                self._resample_commands(expired, on_reset=False)
+        # timers + resample of the expired envs (g1_amp_env.py:146-167): one launch, no nonzero() sync
+        self._command_step(nat.AMP_COMMAND_TICK)
 
     def _apply_action(self):
         super()._apply_action()
         self.last_actions = self.actions.clone()
 
     def _resample_commands(self, env_ids, on_reset: bool):
-        lo, hi = self.cfg.track_vel_range
-        t_lo, t_hi = self.cfg.command_resampling_time_range
-        n = len(env_ids)
-        if hi > lo:
-            self.command_target_speed[env_ids] = torch.rand((n, 2), device=self.device) * (hi - lo) + lo
-            self.command_time_left[env_ids] = torch.rand(n, device=self.device) * (t_hi - t_lo) + t_lo
-        elif on_reset:  # fixed command (g1_amp_env.py:436-439)
-            self.command_target_speed[env_ids, 0] = lo
-            self.command_target_speed[env_ids, 1] = 0.0
-            self.command_time_left[env_ids] = float("inf")
+        # reset-side resample (g1_amp_env.py:421-439) for an explicit id list (the host-driven reset path)
+        if on_reset and len(env_ids) > 0:
+            self._command_step(nat.AMP_COMMAND_RESET, env_ids=env_ids.to(torch.int64).contiguous())
 
     def _get_rewards(self) -> torch.Tensor:
         d = self.robot.data
         self._kernel.launch(nat.AMP_PHASE_REWARD, joint_acc=d.joint_acc, actions=self.actions,
                             soft_limits=d.soft_joint_pos_limits, command=self.command_target_speed, **self._sim_views())
         if self._log_rewards:
-            # one device reduction + one read-back instead of the reference's 6-8 .mean().item() syncs (:291-305)
-            means = self._kernel.reward_terms.mean(dim=1).tolist()
-            log = dict(zip(REWARD_TERMS, means))
-            if not self.cfg.rew_track_vel > 0.0:
-                log.pop("rew_track_vel"), log.pop("error_track_vel")
+            # the reference's 6-8 .mean().item() syncs (:291-305) become one reduction launch; the read-back happens
+            # only when somebody looks at extras["log"] (LazyRewardLog), so step() itself never waits for the device
+            drop = () if self.cfg.rew_track_vel > 0.0 else ("rew_track_vel", "error_track_vel")
+            log = LazyRewardLog(REWARD_TERMS, reward_log_means(self._kernel.reward_terms), drop)
             self.extras["log"] = log
             agent = getattr(self, "_skrl_agent", None)
-            if agent is not None:
+            if agent is not None:  # the reference records to TensorBoard every step when an agent is attached
                 try:
                     for k, v in log.items():
                         agent.track_data(f"Reward / {k}", v)
@@ -279,17 +279,7 @@ class G1AmpEnv(_AmpEnv):
         self.last_actions.masked_fill_(mask[:, None], 0.0)
         if getattr(self.cfg, "num_actor_observations", 1) > 1:
             self._just_reset_mask |= mask
-        lo, hi = self.cfg.track_vel_range
-        t_lo, t_hi = self.cfg.command_resampling_time_range
-        if hi > lo:  # same distribution as _resample_commands, drawn for every env and kept where the mask is set
-            cmd = torch.rand((self.num_envs, 2), device=self.device) * (hi - lo) + lo
-            left = torch.rand(self.num_envs, device=self.device) * (t_hi - t_lo) + t_lo
-            self.command_target_speed.copy_(torch.where(mask[:, None], cmd, self.command_target_speed))
-            self.command_time_left.copy_(torch.where(mask, left, self.command_time_left))
-        else:
-            fixed = torch.tensor([lo, 0.0], device=self.device)
-            self.command_target_speed.copy_(torch.where(mask[:, None], fixed, self.command_target_speed))
-            self.command_time_left.masked_fill_(mask, float("inf"))
+        self._command_step(nat.AMP_COMMAND_RESET, reset_mask=mask)
 
 
 class HumanoidAmpEnv(_AmpEnv):

@@ -51,6 +51,10 @@ class SyntheticArticulation:
         ids = self._ALL_INDICES if env_ids is None else env_ids
         self.data.joint_acc[ids] = 0.0
 
+    def reset_masked(self, mask: torch.Tensor):
+        """``reset(env_ids)`` for a device-side bool mask (no id list, no sync)."""
+        self.data.joint_acc.masked_fill_(mask[:, None], 0.0)
+
     def set_joint_position_target(self, target: torch.Tensor):
         self._target = target
 

@@ -309,10 +309,13 @@ class MotionLoader:
 
     def reset_apply(self, env_ids: torch.Tensor, count: torch.Tensor, num_amp_observations: int, *, seed: int, step: int,
                     start: bool, env_origins: torch.Tensor | None, z_lift: float, amp_observation_buffer: torch.Tensor,
-                    out: dict | None = None) -> dict:
+                    out: dict | None = None, env_motion_ids: torch.Tensor | None = None,
+                    env_motion_start_times: torch.Tensor | None = None, env_offset: int = 0) -> dict:
         """The whole reference-state reset (g1_amp_env.py:371-419) on the device-side output of the reset compaction:
         for i < count, env = env_ids[i]: draw (clip, t), write root_state[i] / dof_pos[i] / dof_vel[i] and the K expert
-        frames into ``amp_observation_buffer[env]``.  Returns the (reusable) compact output tensors."""
+        frames into ``amp_observation_buffer[env]``.  Returns the (reusable) compact output tensors.
+        ``env_motion_ids`` / ``env_motion_start_times`` ([num_envs] int64 / float32) receive the draw per env (the env's
+        ``motion_ids`` / ``motion_start_times`` attributes); draws are keyed by ``env_offset + env`` (shard-invariant)."""
         h = self._need_handle()
         if self._layout is None:
             raise nat.AmpEngineError("call set_obs_layout first")
@@ -330,6 +333,9 @@ class MotionLoader:
         a.root_state, a.dof_pos, a.dof_vel = (out[k].data_ptr() for k in ("root_state", "dof_pos", "dof_vel"))
         a.amp_obs_buffer = nat.dptr(amp_observation_buffer, torch.float32, "amp_observation_buffer").value
         a.motion_ids, a.motion_times = out["motion_ids"].data_ptr(), out["motion_times"].data_ptr()
+        a.env_motion_ids = nat.dptr(env_motion_ids, torch.int64, "env_motion_ids").value
+        a.env_motion_start_times = nat.dptr(env_motion_start_times, torch.float32, "env_motion_start_times").value
+        a.env_offset = int(env_offset)
         with torch.cuda.device(self._tdev):
             nat.check(self._lib.amp_reset_apply(h, C.byref(a), nat.stream_ptr()), "amp_reset_apply")
         return out

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define AMP_ABI_VERSION 5
+#define AMP_ABI_VERSION 6
 
 typedef void* amp_stream_t; /* hipStream_t */
 typedef void* amp_event_t;  /* hipEvent_t  */
@@ -122,7 +122,7 @@ int amp_motion_sample_times(const AmpMotion* h, uint64_t seed, uint64_t step, in
 
 /* The whole reference-state reset of G1AmpEnv._reset_strategy_random (g1_amp_env.py:371-419) driven by the DEVICE-side
  * output of amp_reset_compact* -- no count read-back, no host RNG: for i < *count, env = env_ids[i]:
- * (clip, t) drawn with (seed, step, env); root_state / dof rows i; amp_obs_buffer[env] = K expert frames. */
+ * (clip, t) drawn with (seed, step, env_offset + env); root_state / dof rows i; amp_obs_buffer[env] = K expert frames. */
 typedef struct {
   const int64_t* env_ids;   /* dev [max_n] ascending reset ids */
   const int64_t* count;     /* dev [1] */
@@ -139,6 +139,10 @@ typedef struct {
   float* amp_obs_buffer;    /* dev [num_envs, K, D], rows env_ids[i] overwritten; may be NULL */
   int64_t* motion_ids;      /* dev [max_n] compact out */
   double* motion_times;     /* dev [max_n] compact out */
+  /* optional per-env mirrors of the draw, rows env_ids[i] (the env attributes g1_amp_env.py:377-382 keeps) */
+  int64_t* env_motion_ids;      /* dev [num_envs] or NULL */
+  float* env_motion_start_times; /* dev [num_envs] fp32 or NULL */
+  int64_t env_offset;           /* global id of env 0 of this shard: draws are keyed by env_offset + env_ids[i] */
 } AmpResetArgs;
 int amp_reset_apply(const AmpMotion* h, const AmpResetArgs* args, amp_stream_t stream);
 
@@ -237,6 +241,40 @@ int amp_env_step(const AmpEnvCfg* cfg, const AmpSimState* state, const AmpEnvBuf
                  uint32_t phases, amp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Velocity-command timers (replaces the body of G1AmpEnv._pre_physics_step, g1_amp_env.py:146-167, and the command
+ * resample of _reset_strategy_random, g1_amp_env.py:421-439; ranges g1_amp_env_cfg.py:96-100).
+ *   AMP_COMMAND_TICK   every env: time_left -= step_dt; where it drops to <= 0 and vel_span > 0:
+ *                      command ~ U(vel_lo, vel_lo + vel_span)^2, time_left ~ U(t_lo, t_lo + t_span).
+ *   AMP_COMMAND_RESET  the envs of reset_mask (any non-zero byte), or env_ids[i] for i < min(n_ids, *count): the same
+ *                      draw; with vel_span <= 0 the fixed command (vel_lo, 0) and an infinite timer.
+ * The reference draws with torch.rand behind a nonzero() host sync; here every draw is Philox4x32-10 keyed by
+ * (seed, step, env_offset + env) -- no sync, and the command of an env does not depend on how envs are sharded.
+ * Parity with the reference is distributional only; bit-exact against oracle/rng.py.
+ * ------------------------------------------------------------------------------------------------ */
+enum { AMP_COMMAND_TICK = 0, AMP_COMMAND_RESET = 1 };
+typedef struct {
+  float* command;            /* dev [N, 2] in/out  (command_target_speed) */
+  float* time_left;          /* dev [N] in/out     (command_time_left) */
+  float step_dt;             /* sim.dt * decimation */
+  float vel_lo, vel_span;    /* track_vel_range[0], (float)(track_vel_range[1] - track_vel_range[0]) */
+  float t_lo, t_span;        /* command_resampling_time_range likewise */
+  int32_t reserved;
+  uint64_t seed, step;
+  int64_t env_offset;        /* global id of env 0 of this shard */
+  const uint8_t* reset_mask; /* RESET: dev [N], or NULL when env_ids is given */
+  const int64_t* env_ids;    /* RESET: dev [n_ids] local env ids, or NULL */
+  const int64_t* count;      /* RESET: dev [1] optional cap on n_ids (the compaction's count), or NULL */
+  int64_t n_ids;
+} AmpCommandArgs;
+int amp_command_step(const AmpCommandArgs* args, int64_t num_envs, int32_t mode, amp_stream_t stream);
+
+/* Means over the envs of the rows of reward_terms [n_terms, N] (AmpEnvBuffers.reward_terms) -> means_dev [n_terms]:
+ * the `.mean().item()` chain of G1AmpEnv._get_rewards (g1_amp_env.py:291-305) as one launch with no read-back (fp64
+ * accumulation in a fixed order). */
+int amp_reward_log_means(const float* reward_terms_dev, int32_t n_terms, int64_t num_envs, float* means_dev,
+                         amp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Reset-index compaction  (replaces reset_buf.nonzero(as_tuple=False).squeeze(-1) of DirectRLEnv.step,
  * consumed by G1AmpEnv._reset_idx, g1_amp_env.py:332-358).  Ascending int64 ids, bit-exact.
  * ------------------------------------------------------------------------------------------------ */
@@ -267,6 +305,11 @@ typedef struct {
 
 int amp_disc_create(const AmpDiscDesc* desc, amp_stream_t stream, AmpDisc** out);
 int amp_disc_destroy(AmpDisc* h);
+/* load_state_dict-style update (skrl checkpoints, play.py:205-208): device-to-device copies of new weights of the SAME
+ * shape into the handle's own buffers + refresh of the derived fp16 planes, asynchronous on `stream`, no allocation
+ * (capturable).  The handle, its scaler, its precision mode and every device pointer it handed out
+ * (amp_disc_input_layout, an attached trainer) stay valid.  The source buffers are read on `stream` only. */
+int amp_disc_set_weights(AmpDisc* h, const AmpDiscDesc* desc, amp_stream_t stream);
 /* RunningStandardScaler statistics (fp64 on device, as skrl keeps them); NULL mean disables scaling. */
 int amp_disc_set_scaler(AmpDisc* h, const double* running_mean_dev, const double* running_variance_dev,
                         float epsilon, float clip_threshold, amp_stream_t stream);

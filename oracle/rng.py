@@ -63,3 +63,53 @@ class RingOracle:
             self.rows[self.head] = row
             self.head = (self.head + 1) % self.capacity
             self.size = min(self.size + 1, self.capacity)
+
+
+COMMAND_DOMAIN = 0xA14C0000  # csrc/command.hip::kCommandDomain
+
+
+def command_draw(seed: int, step: int, env: np.ndarray, mode: int, vel_lo: float, vel_span: float, t_lo: float, t_span: float):
+    """(command [n, 2] float32, time_left [n] float32) exactly as csrc/command.hip::draw_command draws them for the
+    GLOBAL env ids ``env``: Philox4x32-10(counter = (env, step), key = (seed_lo, seed_hi ^ (COMMAND_DOMAIN + mode))),
+    u = (word >> 8) * 2^-24 in fp32, then the reference's ``torch.rand(...) * (hi - lo) + lo`` as one fp32 multiply and
+    one fp32 add (g1_amp_env.py:152-166,421-434).  mode 0 = timer expiry, 1 = reset."""
+    env = np.asarray(env, dtype=np.uint64)
+    k1 = ((seed >> 32) & 0xFFFFFFFF) ^ ((COMMAND_DOMAIN + mode) & 0xFFFFFFFF)
+    r0, r1, r2, _ = philox4x32_10(env & MASK, env >> np.uint64(32), step & 0xFFFFFFFF, (step >> 32) & 0xFFFFFFFF,
+                                  seed & 0xFFFFFFFF, k1)
+    f = np.float32
+    u = [(r >> np.uint64(8)).astype(np.float32) * f(2.0 ** -24) for r in (r0, r1, r2)]
+    cx = u[0] * f(vel_span) + f(vel_lo)
+    cy = u[1] * f(vel_span) + f(vel_lo)
+    tl = u[2] * f(t_span) + f(t_lo)
+    return np.stack([cx, cy], axis=1).astype(np.float32), tl.astype(np.float32)
+
+
+def command_tick(command: np.ndarray, time_left: np.ndarray, step_dt: float, vel_range, time_range, seed: int, step: int,
+                 env_offset: int = 0):
+    """G1AmpEnv._pre_physics_step's timer update (g1_amp_env.py:146-167) with the engine's counter-based draw in place
+    of torch.rand: returns new (command, time_left)."""
+    command, time_left = command.astype(np.float32).copy(), time_left.astype(np.float32).copy()
+    time_left = (time_left - np.float32(step_dt)).astype(np.float32)
+    lo, hi = float(vel_range[0]), float(vel_range[1])
+    expired = np.nonzero(time_left <= 0.0)[0]
+    if len(expired) > 0 and hi > lo:
+        c, t = command_draw(seed, step, expired + env_offset, 0, lo, hi - lo, float(time_range[0]),
+                            float(time_range[1]) - float(time_range[0]))
+        command[expired], time_left[expired] = c, t
+    return command, time_left
+
+
+def command_reset(command: np.ndarray, time_left: np.ndarray, env_ids: np.ndarray, vel_range, time_range, seed: int, step: int,
+                  env_offset: int = 0):
+    """The command resample of G1AmpEnv._reset_strategy_random (g1_amp_env.py:421-439) for ``env_ids``."""
+    command, time_left = command.astype(np.float32).copy(), time_left.astype(np.float32).copy()
+    lo, hi = float(vel_range[0]), float(vel_range[1])
+    env_ids = np.asarray(env_ids, dtype=np.int64)
+    if hi > lo:
+        c, t = command_draw(seed, step, env_ids + env_offset, 1, lo, hi - lo, float(time_range[0]),
+                            float(time_range[1]) - float(time_range[0]))
+        command[env_ids], time_left[env_ids] = c, t
+    else:
+        command[env_ids, 0], command[env_ids, 1], time_left[env_ids] = lo, 0.0, np.inf
+    return command, time_left

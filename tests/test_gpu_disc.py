@@ -278,3 +278,50 @@ def test_f16_engine_plane_scales_follow_the_weights(w1_scale, w2_scale, b_scale,
     scale = float(lg64.abs().max())
     err, err32 = float((got[sub] - lg64).abs().max()), float((lg32 - lg64).abs().max())
     assert err <= 2e-6 * scale + 1e-6, (err, err32, scale)
+
+
+def test_set_weights_in_place():
+    """amp_disc_set_weights: 12 load_state_dict-style updates of ONE handle with a scaler set, an EnvStepKernel layout
+    attached and a trainer attached.  After every update the handle must equal a FRESH handle built from the same
+    weights + scaler bit for bit (logits, style), the layout's device pointers must not move (no re-allocation: the
+    fused-scaler launch keeps reading valid memory), and the attached trainer must see the new weights."""
+    from humanoid_amp_amd.engine import AmpDiscriminator, AmpDiscriminatorTrainer, EnvStepConfig, EnvStepKernel
+
+    in_dim, rows = 166, 700
+    g = torch.Generator().manual_seed(77)
+    mean = torch.randn(in_dim, generator=g, dtype=torch.float64) * 0.2
+    var = torch.rand(in_dim, generator=g, dtype=torch.float64) + 0.1
+    x = (torch.randn(rows, in_dim, generator=g) * 2.0).cuda()
+    task = torch.randn(rows, 1, generator=g).cuda()
+    dev = lambda w: [(p.cuda(), q.cuda()) for p, q in w]  # noqa: E731
+    disc = AmpDiscriminator(dev(odisc.make_weights(in_dim, seed=0)), "cuda:0", running_mean=mean, running_variance=var,
+                            task_reward_weight=0.5, style_reward_weight=0.5)
+    kern = EnvStepKernel(EnvStepConfig(n_dof=29, num_amp_observations=2, max_episode_length=300), 64, "cuda:0")
+    kern.attach_discriminator(disc)
+    lay0 = disc.input_layout()
+    ptrs0 = (lay0.mean_dev, lay0.den_dev, lay0.format, lay0.padded_dim)
+    trainer = AmpDiscriminatorTrainer(disc, batch_size=256, running_mean=mean, running_variance=var, apply_update=False,
+                                      update_scaler=False)
+    handle0 = disc._handle.value
+    for it in range(12):
+        w = odisc.make_weights(in_dim, seed=100 + it)
+        disc.set_weights(dev(w))
+        assert disc._handle.value == handle0
+        lay = disc.input_layout()
+        assert (lay.mean_dev, lay.den_dev, lay.format, lay.padded_dim) == ptrs0, "scaler pointers / layout moved"
+        got = disc.style_reward(x, task, want_logits=True)
+        fresh = AmpDiscriminator(dev(w), "cuda:0", running_mean=mean, running_variance=var, task_reward_weight=0.5,
+                                 style_reward_weight=0.5).style_reward(x, task, want_logits=True)
+        for k in ("logits", "style", "combined"):
+            assert torch.equal(got[k], fresh[k]), (it, k)
+        # the scaler survived (a dropped scaler would feed raw inputs): compare with the oracle as well
+        ref = odisc.forward(w, x.cpu(), mean, var, task=task.cpu(), task_w=0.5, style_w=0.5)
+        assert float((got["style"].cpu() - ref["style"]).abs().max()) <= TOL
+        for (tw, tb), (ow, ob) in zip(trainer.weights(), w):
+            assert torch.equal(tw.cpu(), ow) and torch.equal(tb.cpu(), ob), "trainer does not see the new weights"
+    # the attached trainer still steps on live memory
+    b = x[:256]
+    out = trainer.step(b, b.flip(0), b * 0.5)
+    assert torch.isfinite(out["loss"]).item()
+    with pytest.raises(ValueError):
+        disc.set_weights(dev(odisc.make_weights(162, seed=1)))

@@ -147,5 +147,14 @@ def test_make_and_errors():
     bad.scene.num_envs = 8
     with pytest.raises(ValueError, match="Unknown reset strategy"):
         G1AmpEnv(bad).reset()
-    with pytest.raises(ValueError):
+    with pytest.raises(ValueError, match="not shipped"):
         make("Isaac-G1-AMP-Custom-Direct-v0", num_envs=8)  # custom_motion.npz is not shipped: "No files found"
+    # the Deploy task runs on the bundled motion_config.yaml (the reference's own list points at private recordings)
+    dep = make("Isaac-G1-AMP-Deploy-Direct-v0", num_envs=32)
+    obs, extras = dep.reset(seed=0)
+    assert obs["policy"].shape == (32, dep.cfg.observation_space) and extras["amp_obs"].shape == (32, dep.amp_observation_size)
+    obs, rew, term, tout, extras = dep.step(torch.zeros(32, 29, device="cuda"))
+    assert torch.isfinite(obs["policy"]).all() and torch.isfinite(rew).all()
+    # fixed command of the Deploy cfg (track_vel_range lo == hi): reset writes (lo, 0) and an infinite timer
+    assert torch.equal(dep.command_target_speed, torch.tensor([[1.0, 0.0]], device="cuda").expand(32, 2))
+    assert torch.isinf(dep.command_time_left).all()
