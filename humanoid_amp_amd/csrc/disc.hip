@@ -65,7 +65,12 @@ __global__ __launch_bounds__(kBlock) void disc_finalize_kernel(const float* __re
   if (i >= M) return;
   const float* p = partial + i * n_tiles;
   float s = 0.0f;
-  if (n_tiles == 4) {
+  if (n_tiles == 16) {  // the f16 engine's canonical 32-column block sums (h2 = 512): one fixed balanced tree
+    const f4 a = *reinterpret_cast<const f4*>(p), b = *reinterpret_cast<const f4*>(p + 4),
+             c = *reinterpret_cast<const f4*>(p + 8), d = *reinterpret_cast<const f4*>(p + 12);
+    s = (((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3]))) +
+        (((c[0] + c[1]) + (c[2] + c[3])) + ((d[0] + d[1]) + (d[2] + d[3])));
+  } else if (n_tiles == 4) {
     s = (p[0] + p[1]) + (p[2] + p[3]);
   } else if (n_tiles == 8) {
     s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
@@ -334,6 +339,7 @@ static bool f16_use_dma(const AmpDisc* h, int64_t rows) {  // 256 x 256 LDS-DMA 
 static int64_t f16_chunk_rows(const AmpDisc* h, int64_t rows) {
   return f16_use_dma(h, kChunkRows) && rows > kChunkRows + kChunkRows / 2 ? kChunkRows : rows;
 }
+// column tiles of the layer-2 launch (the partial-logit layout does not depend on it: h2 / 32 block sums per row)
 static int f16_n_tiles(const AmpDisc* h, int64_t rows) {
   const int64_t chunk = f16_chunk_rows(h, rows);
   if (f16_use_dma(h, chunk)) return h->h2 / kDmaBN;
@@ -348,6 +354,7 @@ static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* a
   // planar operands: 128 x 128 (x 32 at 3 workgroups / CU for layer 1, x 64 at 2 for layer 2), 64 x 64 below 512 such tiles
   const int64_t chunk = f16_chunk_rows(h, rows);
   const int n_tiles = f16_n_tiles(h, rows);
+  const int n_blocks = h->h2 / 32;  // canonical partial logits: one per (row, 32-column block)
   int rc = AMP_OK;
   for (int64_t r0 = 0; r0 < rows && rc == AMP_OK; r0 += chunk) {
     const int64_t m = rows - r0 < chunk ? rows - r0 : chunk;
@@ -379,7 +386,7 @@ static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* a
     g2.A = H1p + r0 * h->h1; g2.lda = h->h1; g2.plane_a = rows * h->h1; g2.M = m;
     g2.W = h->w2h; g2.plane_w = (int64_t)h->h2 * h->h1; g2.Kp = h->h1; g2.N = h->h2;
     g2.bias = h->b2; g2.range = h->range; g2.amax = amax; g2.layer = 2;
-    g2.w3 = h->w3; g2.partial = partial + r0 * n_tiles;
+    g2.w3 = h->w3; g2.partial = partial + r0 * n_blocks;
     if (dma) {  // every chunk (a short last one too): one partial layout
       g2.A = H1p;
       g2.W = h->w2b;
@@ -397,7 +404,7 @@ static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* a
   }
   if (rc != AMP_OK) return rc;
   { amp::TraceScope trace__("disc_finalize_kernel", st);
-    disc_finalize_kernel<<<(unsigned)((rows + kBlock - 1) / kBlock), kBlock, 0, st>>>(partial, n_tiles, h->b3, rows, scale, task,
+    disc_finalize_kernel<<<(unsigned)((rows + kBlock - 1) / kBlock), kBlock, 0, st>>>(partial, n_blocks, h->b3, rows, scale, task,
                                                                                    task_w, style_w, logits, style, combined);
   }
   return launch_status("disc_finalize_kernel");
@@ -594,7 +601,7 @@ static DiscWorkspace disc_workspace(const AmpDisc* h, int64_t rows, void* base) 
   w.header = (float*)p; p += kWsHeader;
   w.xs = p; p += round_up(4 * rows * (h->k1h > h->k1p ? h->k1h : h->k1p), 256);
   w.h1 = p; p += round_up(4 * rows * h->h1, 256);
-  w.partial = (float*)p; p += round_up((int64_t)sizeof(float) * rows * (h->h2 / 64), 256);
+  w.partial = (float*)p; p += round_up((int64_t)sizeof(float) * rows * (h->h2 / 32), 256);
   w.task_copy = (float*)p; p += round_up((int64_t)sizeof(float) * rows, 256);
   w.bytes = p - (char*)base;
   return w;

@@ -350,13 +350,18 @@ __global__ __launch_bounds__(kBlock, MINW) void disc_gemm_f16_kernel(GemmF16Args
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
   } else {
-    float* red = reinterpret_cast<float*>(smem);  // [2][BM]
+    // CANONICAL partial logits: one value per (row, 32-column block) = (lane half 0's sequential sum over its 16
+    // registers) + (lane half 1's), written to partial[row][block] with `n_blocks` = N / 32 blocks per row.  Every f16
+    // kernel, whatever its tile, produces the same 16 values per row bit for bit (the accumulators are identical: same k
+    // order, same three products per k-step), and disc_finalize_kernel adds them in one fixed tree -- so a row's logit
+    // does not depend on the tile shape the shard size selected (shard equivalence, tests/test_gpu_shard_equivalence.py).
+    float* red = reinterpret_cast<float*>(smem);  // [2 TN][BM]
     const fv4* w34 = reinterpret_cast<const fv4*>(g.w3 + n0 + wn * (TN * 32) + 4 * lh);
-    float sum[TM];
+    float sum[TM][TN];
 #pragma unroll
-    for (int a = 0; a < TM; ++a) sum[a] = 0.0f;
+    for (int b = 0; b < TN; ++b) {
 #pragma unroll
-    for (int b = 0; b < TN; ++b)
+      for (int a = 0; a < TM; ++a) sum[a][b] = 0.0f;
 #pragma unroll
       for (int grp = 0; grp < 4; ++grp) {
         const fv4 bs = bias4[b * 8 + grp * 2], ws = w34[b * 8 + grp * 2];
@@ -364,17 +369,23 @@ __global__ __launch_bounds__(kBlock, MINW) void disc_gemm_f16_kernel(GemmF16Args
         for (int a = 0; a < TM; ++a)
 #pragma unroll
           for (int i = 0; i < 4; ++i)
-            sum[a] += fmaxf(acc[a][b][4 * grp + i] * descale + bs[i], 0.0f) * ws[i];
+            sum[a][b] += fmaxf(acc[a][b][4 * grp + i] * descale + bs[i], 0.0f) * ws[i];
       }
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
-      const float v = sum[a] + __shfl_xor(sum[a], 32, 64);  // the other lane half holds the other columns
-      if (lh == 0) red[wn * BM + wm * (TM * 32) + a * 32 + li] = v;
     }
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const float v = sum[a][b] + __shfl_xor(sum[a][b], 32, 64);  // the other lane half holds the other columns
+        if (lh == 0) red[(wn * TN + b) * BM + wm * (TM * 32) + a * 32 + li] = v;
+      }
     __syncthreads();
-    if (tid < BM) {
-      const int64_t row = m0 + tid;
-      if (row < g.M) g.partial[row * g.n_tiles + nt] = red[tid] + red[BM + tid];
+    constexpr int BPT = 2 * TN;  // 32-column blocks per tile
+    const int n_blocks = g.N >> 5;
+    for (int e = tid; e < BM * BPT; e += kBlock) {
+      const int r = e / BPT, j = e - r * BPT;
+      const int64_t row = m0 + r;
+      if (row < g.M) g.partial[row * n_blocks + nt * BPT + j] = red[j * BM + r];
     }
   }
 }
@@ -383,7 +394,8 @@ template <int TM, int TN, int BK>
 constexpr int gemm_f16_lds_bytes() {
   constexpr int stage = 2 * (64 * TM + 64 * TN) * (BK + 8) * 2;
   constexpr int ep = 4 * 2 * 32 * (TN * 32 + 8) * 2;
-  return stage > ep ? stage : ep;
+  constexpr int red = 2 * TN * 64 * TM * 4;  // MODE 1: [2 TN][BM] floats
+  return (stage > ep ? stage : ep) > red ? (stage > ep ? stage : ep) : red;
 }
 
 }  // namespace amp

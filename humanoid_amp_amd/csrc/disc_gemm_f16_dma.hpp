@@ -307,30 +307,36 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN>::kWgPerCu)) void disc
     return;
   }
   const fv4* w34 = reinterpret_cast<const fv4*>(g.w3 + n0 + wn * (32 * TN) + 4 * lh);
-  float* red = reinterpret_cast<float*>(lds);  // [4][BM]
-  float sum[TM];
+  // canonical partial logits, one per (row, 32-column block): see disc_gemm_f16_kernel's MODE 1 epilogue
+  float* red = reinterpret_cast<float*>(lds);  // [4 TN][BM]
+  float sum[TM][TN];
 #pragma unroll
-  for (int a = 0; a < TM; ++a) sum[a] = 0.0f;
+  for (int b = 0; b < TN; ++b) {
 #pragma unroll
-  for (int b = 0; b < TN; ++b)
+    for (int a = 0; a < TM; ++a) sum[a][b] = 0.0f;
 #pragma unroll
     for (int grp4 = 0; grp4 < 4; ++grp4) {
       const fv4 bs = bias4[b * 8 + grp4 * 2], ws = w34[b * 8 + grp4 * 2];
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) sum[a] += fmaxf(acc[a][b][4 * grp4 + i] * descale + bs[i], 0.0f) * ws[i];
+        for (int i = 0; i < 4; ++i) sum[a][b] += fmaxf(acc[a][b][4 * grp4 + i] * descale + bs[i], 0.0f) * ws[i];
     }
-#pragma unroll
-  for (int a = 0; a < TM; ++a) {
-    const float v = sum[a] + __shfl_xor(sum[a], 32, 64);  // the other lane half holds the other columns
-    if (lh == 0) red[wn * BM + wm * (32 * TM) + a * 32 + li] = v;
   }
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const float v = sum[a][b] + __shfl_xor(sum[a][b], 32, 64);  // the other lane half holds the other columns
+      if (lh == 0) red[(wn * TN + b) * BM + wm * (32 * TM) + a * 32 + li] = v;
+    }
   __syncthreads();
-  if (tid < BM) {
-    const int64_t row = m0 + tid;
-    // fixed order over the four column waves: (0 + 1) + (2 + 3)
-    if (row < g.M) g.partial[row * g.n_tiles + nt] = (red[tid] + red[BM + tid]) + (red[2 * BM + tid] + red[3 * BM + tid]);
+  constexpr int BPT = 4 * TN;  // 32-column blocks per tile
+  const int n_blocks = g.N >> 5;
+  for (int e = tid; e < BM * BPT; e += kDmaThreads) {
+    const int r = e / BPT, j = e - r * BPT;
+    const int64_t row = m0 + r;
+    if (row < g.M) g.partial[row * n_blocks + nt * BPT + j] = red[j * BM + r];
   }
 }
 

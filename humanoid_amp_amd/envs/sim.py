@@ -91,7 +91,7 @@ class SyntheticArticulation:
         scatter(d.body_lin_vel_w, root_state[:, None, 7:10].expand(-1, nb, -1))
         scatter(d.body_ang_vel_w, root_state[:, None, 10:13].expand(-1, nb, -1))
         mask = torch.zeros(N + 1, dtype=torch.bool, device=self.device)
-        mask[tgt] = True
+        mask.index_fill_(0, tgt, True)  # (mask[tgt] = True stages its scalar through a blocking H2D copy)
         d.joint_acc.masked_fill_(mask[:N, None], 0.0)
 
     # ---- toy physics ------------------------------------------------------------------------------------

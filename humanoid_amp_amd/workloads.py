@@ -86,8 +86,13 @@ class HotPath:
 
     def __init__(self, spec: WorkloadSpec, num_envs: int, device, seed: int = 0, log_reward_terms: bool = False,
                  overlap: bool = False, fused_scaler: bool = True, disc_precision: str = "f16x3",
-                 expert_stream: bool = False, fused_expert: bool = True):
-        """``overlap``: run the discriminator on a second HIP stream so that the HBM-bound kernels of step t+1
+                 expert_stream: bool = False, fused_expert: bool = True, state: dict | None = None, state_sets: int = 1):
+        """``state``: use this synthetic state (a ``make_state`` dict on the device, e.g. a row block of a larger
+        shard's state) instead of drawing one from ``seed``.  ``state_sets`` > 1: that many independently drawn input
+        sets (seeds ``seed + 7919 i``), visited round-robin by successive steps, so that a benchmark's state reads are
+        not served by the 256 MB Infinity Cache from the previous step's identical addresses.
+
+        ``overlap``: run the discriminator on a second HIP stream so that the HBM-bound kernels of step t+1
         (motion sample, env step, compaction) execute under the MFMA-bound GEMMs of step t.  The style reward is
         consumed asynchronously in AMP (skrl reads it at the agent update), so nothing waits for it inside a step;
         ``synchronize()`` / ``torch.cuda.synchronize()`` joins both streams.  Bit-identical to the serial schedule
@@ -119,7 +124,14 @@ class HotPath:
         self.cfg = EnvStepConfig(n_dof=spec.n_dof, num_amp_observations=spec.K, max_episode_length=spec.max_episode_length,
                                  use_last_actions=spec.robot == "g1", reward_mode=1 if spec.robot == "g1" else 0, **rewards)
         self.kernel = EnvStepKernel(self.cfg, self.num_envs, self.device, log_reward_terms=log_reward_terms)
-        self.state = make_state(self.num_envs, spec.n_dof, spec.max_episode_length, ml.durations, seed, self.device)
+        if state is not None:
+            if int(state["joint_pos"].shape[0]) != self.num_envs:
+                raise nat.AmpEngineError("the injected state has the wrong number of envs")
+            self.states = [state]
+        else:
+            self.states = [make_state(self.num_envs, spec.n_dof, spec.max_episode_length, ml.durations, seed + 7919 * i, self.device)
+                           for i in range(max(1, int(state_sets)))]
+        self.state = self.states[0]
         self.expert_obs = torch.zeros((self.num_envs, spec.K * D), device=self.device)
         # discriminator: torch.nn.Linear default init under torch.manual_seed(0); scaler mean 0 / var 1
         self.disc_weights = make_disc_weights(spec.K * D, seed=0)
@@ -133,12 +145,12 @@ class HotPath:
         # expert rows are a plausible AMP history to start from
         self.motion.collect_reference(self.state["motion_times"], self.state["motion_ids"], spec.K,
                                       out=self.kernel.amp_observation_buffer)
-        self._sim = {k: self.state[k] for k in ("joint_pos", "joint_vel", "joint_acc", "actions", "root_pos", "root_quat",
-                                                "root_lin_vel", "root_ang_vel", "body_pos", "soft_limits", "episode_length",
-                                                "command", "last_actions")}
+        sim_keys = ["joint_pos", "joint_vel", "joint_acc", "actions", "root_pos", "root_quat", "root_lin_vel", "root_ang_vel",
+                    "body_pos", "soft_limits", "episode_length", "command", "last_actions"]
         if spec.robot != "g1":
-            for k in ("joint_acc", "actions", "soft_limits", "command", "last_actions"):
-                self._sim.pop(k)
+            sim_keys = [k for k in sim_keys if k not in ("joint_acc", "actions", "soft_limits", "command", "last_actions")]
+        self._sims = [{k: st[k] for k in sim_keys} for st in self.states]
+        self._sim = self._sims[0]
         self.last = None
         self._n = 0
         self.fused_expert = bool(fused_expert) and not expert_stream
@@ -158,14 +170,19 @@ class HotPath:
                     self.disc._workspace(self.num_envs, slot)
 
     def step(self):
-        if getattr(self, "_graph", None) is not None:
-            self._graph.replay()
-            self.last = self._graph_out
+        graphs = getattr(self, "_graphs", None)
+        if graphs:
+            g, out = graphs[self._n % len(graphs)]
+            g.replay()
+            self._n += 1
+            self.last = out
             return self.last
         return self._eager_step()
 
-    def _eager_step(self):
-        s, k = self.state, self.kernel
+    def _eager_step(self, which: int | None = None):
+        i = (self._n if which is None else which) % len(self.states)
+        s, k = self.states[i], self.kernel
+        self.state, self._sim = s, self._sims[i]
         env_stream = torch.cuda.current_stream(self.device)
         if self.overlap and self._n > 0:
             # the previous discriminator call must have read amp_obs / reward before this step shifts / rewrites them
@@ -211,9 +228,13 @@ class HotPath:
             for _ in range(warmup):
                 self._eager_step()
         torch.cuda.current_stream(self.device).wait_stream(side)
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            self._graph_out = self._eager_step()
+        graphs = []
+        for i in range(len(self.states)):  # one graph per input set (the state pointers are baked into the nodes)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self._eager_step(which=i)
+            graphs.append((g, out))
+        self._graphs = graphs
         return self
 
     def synchronize(self):

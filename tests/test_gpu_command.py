@@ -131,7 +131,7 @@ def test_g1_env_step_has_no_host_sync():
             assert not extras["log"].materialized
     finally:
         torch.cuda.set_sync_debug_mode("default")
-    assert int(resets) > 512                       # time-outs happened: the device reset path ran inside the guard
+    assert int(resets) >= 512                      # time-outs happened: the device reset path ran inside the guard
     assert not torch.equal(cmd_before, env.command_target_speed)  # commands were resampled on the device
     c = env.command_target_speed
     assert float(c.min()) >= cfg.track_vel_range[0] and float(c.max()) < cfg.track_vel_range[1]
