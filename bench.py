@@ -6,8 +6,16 @@
         bench.py --gpus N --steps K --warmup W
 
 One "step" = one env-step of the hot path for every env of the shard (humanoid_amp_amd/workloads.py), inputs
-resident in HBM.  One process per GPU; envs shard trivially (weak scaling: --envs per GPU is fixed), the only
-collective is the RCCL all-gather of the AMP replay minibatch every --rollouts steps (agents/*.yaml:65,91).
+resident in HBM.  One process per GPU, envs shard trivially, no data-path collective; the one exchange is the RCCL
+all-gather of the AMP replay minibatch every --rollouts steps (agents/*.yaml:65,91).
+
+Scaling mode.  BASELINE.json names GLOBAL env counts: configs[4] = G1-AMP-Walk, 65 536 envs on 1 and on 8 GPUs
+(8 192 envs per GPU), configs[3] = humanoid 3-clip, 32 768 envs on 4 GPUs.  So the default is STRONG scaling of the
+named configuration: `--global-envs` (default 65 536 for g1_walk / g1_dance, 32 768 for humanoid3) is split over
+--gpus ranks by `distributed.shard_bounds`, and the line says "scaling": "strong" and `envs_per_gpu`.
+    configs[4]:  torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8
+    configs[3]:  torch.distributed.run --nproc-per-node 4 ... bench.py --gpus 4 --workload humanoid3
+`--envs E` fixes the envs PER GPU instead (weak scaling, "scaling": "weak").
 Rank 0 prints ONE JSON line.  The CPU oracle (oracle/) is used only for the bounded `cpu_baseline` leg.
 """
 
@@ -28,11 +36,16 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
 # layer 2 of the discriminator: 2*M*1024*512 of the 2*M*(in*1024+1024*512+512) FLOPs
-# tracer labels: the fp16 engine launches disc_gemm_f16_dma_kernel<1> (large shards) or disc_gemm_f16_kernel<1>
+# tracer labels: the fp16 engine launches disc_gemm_f16_dma_kernel<1> (LDS-DMA tiles) or disc_gemm_f16_kernel<1>
 DOMINANT_FILTER = {"f16x3": "disc_gemm_f16_", "f32": "disc_gemm_kernel<1>"}
 DOMINANT_KERNEL = {"f16x3": "disc_gemm_f16_dma_kernel<1>", "f32": "disc_gemm_kernel<1>"}
 MFMA_PEAK_TFLOPS = {"f16x3": 16 * 157.3, "f32": 157.3}  # dense fp16 MFMA = 16 x the fp32 MFMA rate (MI355X_MICROARCH.md)
 MFMA_PER_PRODUCT = {"f16x3": 3, "f32": 1}               # the fp16 engine issues three MFMA products per algorithmic one
+DTYPE = {"f16x3": "f32 (GEMM operands as 2 fp16 planes, 3 fp16 MFMAs per product, f32 accumulate)", "f32": "f32"}
+DEFAULT_GLOBAL_ENVS = {"g1_walk": 65536, "g1_dance": 65536, "humanoid3": 32768}  # BASELINE.json configs[4] / [3]
+BASELINE_CONFIG = {("g1_walk", 65536, 1): "configs[4] on 1 GPU", ("g1_walk", 65536, 8): "configs[4]",
+                   ("humanoid3", 32768, 4): "configs[3]", ("g1_walk", 4096, 1): "configs[1]", ("g1_dance", 8192, 1): "configs[2]"}
+GRAPH_MAX_ENVS = 16384       # shards up to this size are launch-bound: the step is replayed as one hipGraph
 
 
 def parse_args():
@@ -40,19 +53,32 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU (weak scaling)")
+    ap.add_argument("--global-envs", type=int, default=0,
+                    help="envs of the whole job, split over --gpus ranks (strong scaling; 0 = the BASELINE config of the workload)")
+    ap.add_argument("--envs", type=int, default=0, help="envs PER GPU (weak scaling); overrides --global-envs")
     ap.add_argument("--workload", default="g1_walk", choices=["g1_walk", "g1_dance", "humanoid3"])
     ap.add_argument("--rollouts", type=int, default=16, help="steps between AMP-replay all-gathers (N > 1 only)")
     ap.add_argument("--replay-minibatch", type=int, default=4096, help="rows per rank in the all-gather")
     ap.add_argument("--minibatches", type=int, default=12, help="all-gathers per agent update (learning_epochs x mini_batches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-envs", type=int, default=0, help="envs of the CPU sample (0 = same as --envs)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the 4096-env secondary measurement")
+    ap.add_argument("--cpu-envs", type=int, default=0, help="envs of the CPU sample (0 = same as the shard)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the 8192- / 4096-env secondary measurements")
     ap.add_argument("--disc-precision", default="f16x3", choices=["f16x3", "f32"],
                     help="GEMM engine of the discriminator (both fp32-class accuracy): fp16-split (default) or fp32 MFMA")
     ap.add_argument("--no-fp32-engine", action="store_true", help="skip the comparison run on the fp32-MFMA GEMM engine")
-    ap.add_argument("--no-graph", action="store_true", help="never use hipGraph replay (secondary measurement included)")
+    ap.add_argument("--no-graph", action="store_true", help="never use hipGraph replay")
+    ap.add_argument("--state-sets", type=int, default=0,
+                    help="synthetic input sets visited round-robin (0 = enough to exceed the 256 MB Infinity Cache, >= 3)")
     return ap.parse_args()
+
+
+def n_state_sets(spec, envs, requested):
+    """>= 3 input sets and at least 320 MB of rotating state, so that a step's state reads come from HBM rather than from
+    the Infinity Cache lines the same addresses left there one step earlier (capped at 8 sets)."""
+    if requested > 0:
+        return requested
+    per_env = (4 * spec.n_dof + 3 + 4 + 3 + 3 + 12 + 2) * 4 + 8 + 16  # the SoA rows a step reads
+    return int(min(8, max(3, -(-320e6 // max(per_env * envs, 1)))))
 
 
 def settle(hot, max_seconds=4.0, block=20):
@@ -104,12 +130,26 @@ def timed_steps(hot, steps, warmup, world, collective):
     return dt
 
 
-def cpu_baseline(spec, n_envs, seed, target_seconds=12.0, probe=True):
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(spec, n_envs, seed, target_seconds=12.0, probe=True, threads=None):
     """The oracle (CPU restatement of the reference's torch path) timed on this box's host cores: same unit of
     work, same synthetic inputs; bounded to ~target_seconds."""
+    # a one-GPU box owns a 16-core share of the host (more threads only oversubscribe it)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(avail, 16) if threads is None else int(threads)
+    torch.set_num_threads(cores)
     if probe and n_envs > 4096:
         # bounded sample: probe at 4096 envs, then take the largest power-of-two shard (<= n_envs) whose ~8 steps fit
-        small = cpu_baseline(spec, 4096, seed, target_seconds=2.0, probe=False)
+        small = cpu_baseline(spec, 4096, seed, target_seconds=2.0, probe=False, threads=cores)
         per_env = small["ms_per_step"] * 1e-3 / 4096
         fit = target_seconds / 8.0 / per_env
         n = 4096
@@ -125,9 +165,6 @@ def cpu_baseline(spec, n_envs, seed, target_seconds=12.0, probe=True):
     from oracle import env as oenv
     from oracle import motion as om
 
-    # a one-GPU box owns a 16-core share of the host (more threads only oversubscribe it)
-    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
-    torch.set_num_threads(cores)
     mt = om.load_tables([os.path.join(MOTIONS_DIR, c + ".npz") for c in spec.clips])
     g1 = spec.robot == "g1"
     perm = [mt.dof_names.index(n) for n in G1_JOINT_NAMES] if g1 else list(range(len(mt.dof_names)))
@@ -176,6 +213,31 @@ def cpu_baseline(spec, n_envs, seed, target_seconds=12.0, probe=True):
             "ms_per_step": med * 1e3}
 
 
+def measure_shard(spec, envs, device, rank, world, steps, warmup, use_graph, precision="f16x3", sets=0, seed=99):
+    """Secondary measurement of one shard size: (env-steps/s whole-job, ms/step, launch mode, per-kernel us of an eager pass)."""
+    import contextlib
+
+    from humanoid_amp_amd import _native as nat
+    from humanoid_amp_amd.workloads import HotPath
+
+    with contextlib.redirect_stdout(sys.stderr):
+        hot = HotPath(spec, envs, device, seed=seed + rank, disc_precision=precision, state_sets=n_state_sets(spec, envs, sets))
+    with nat.KernelTrace(capacity=16 * 8) as tr_all:
+        for _ in range(8):
+            hot.step()
+    per_kernel = {k: round(t / 8 * 1e3, 2) for k, (c, t) in tr_all.summary().items()}
+    if use_graph:
+        hot.capture()
+    settle(hot, max_seconds=2.0)
+    dts = timed_steps(hot, steps, warmup, world, None)
+    out = {"value": envs * world * steps / dts, "unit": "env-steps/s", "ms_per_step": dts / steps * 1e3, "envs_per_gpu": envs,
+           "launch": "hipGraph replay of the captured step" if use_graph else "eager",
+           "kernel_us_per_step_eager": per_kernel, "state_sets": len(hot.states)}
+    del hot
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -202,14 +264,23 @@ def main():
 
     import humanoid_amp_amd  # noqa: F401  (fails loudly if libamp_engine.so is missing)
     from humanoid_amp_amd import _native as nat
-    from humanoid_amp_amd.distributed import ReplayAllGather
+    from humanoid_amp_amd.distributed import ReplayAllGather, shard_bounds
     from humanoid_amp_amd.workloads import WORKLOADS, HotPath, algorithmic_bytes_per_env_step, disc_flops_per_row
 
     import contextlib
 
     spec = WORKLOADS[args.workload]
+    # ---- shard: strong scaling of the named global configuration unless --envs fixes the per-GPU size -------------
+    if args.envs > 0:
+        scaling, envs, global_envs = "weak", args.envs, args.envs * world
+    else:
+        scaling, global_envs = "strong", args.global_envs or DEFAULT_GLOBAL_ENVS[args.workload]
+        lo, hi = shard_bounds(global_envs, world, rank)
+        envs = hi - lo
+    use_graph = not args.no_graph and envs <= GRAPH_MAX_ENVS
     with contextlib.redirect_stdout(sys.stderr):  # MotionLoader prints like the reference; stdout carries only the JSON line
-        hot = HotPath(spec, args.envs, device, seed=1234 + rank, disc_precision=args.disc_precision)
+        hot = HotPath(spec, envs, device, seed=1234 + rank, disc_precision=args.disc_precision,
+                      state_sets=n_state_sets(spec, envs, args.state_sets))
     dominant = DOMINANT_KERNEL[args.disc_precision]
     dominant_filter = DOMINANT_FILTER[args.disc_precision]
     collective = None
@@ -218,68 +289,87 @@ def main():
         # them: they are launched asynchronously (RCCL stream) and joined before the timed region ends
         # one agent update = `minibatches` discriminator minibatches: their replay rows are drawn together and gathered
         # by ONE collective of [minibatches * replay_minibatch, K*D] per rank (same bytes as one gather per minibatch)
-        ag = ReplayAllGather(hot.kernel.amp_observation_buffer.view(args.envs, -1), args.replay_minibatch, seed=rank,
+        ag = ReplayAllGather(hot.kernel.amp_observation_buffer.view(envs, -1), args.replay_minibatch, seed=rank,
                              slots=2, minibatches=args.minibatches)
         collective = {"every": args.rollouts, "fn": ag.start, "join": ag.wait_all}
 
-    # ---- timed region: exactly --steps steps, the dominant kernel bracketed by HIP events on its stream --------
+    # ---- timed region: exactly --steps steps ------------------------------------------------------------------------
+    # eager shards: the dominant kernel is bracketed by HIP events on its stream INSIDE the timed region; graph-replayed
+    # shards (<= GRAPH_MAX_ENVS envs) cannot carry the tracer's event pairs, so their dominant-kernel duration comes from
+    # an eager traced pass right after the timed region (said so in roofline.timing)
+    if use_graph:
+        hot.capture()
     settle(hot)
-    with nat.KernelTrace(capacity=8 * (args.steps + args.warmup) + 8, kernel_filter=dominant_filter) as tr:
+    if use_graph:
         dt = timed_steps(hot, args.steps, args.warmup, world, collective)
+        hot._graphs = None  # back to eager launches for the traced pass
+        with nat.KernelTrace(capacity=8 * (args.steps + args.warmup) + 8, kernel_filter=dominant_filter) as tr:
+            for _ in range(args.steps + args.warmup):
+                hot.step()
+        timing = "eager traced pass of the same steps right after the timed region (the timed region replays a hipGraph)"
+    else:
+        with nat.KernelTrace(capacity=8 * (args.steps + args.warmup) + 8, kernel_filter=dominant_filter) as tr:
+            dt = timed_steps(hot, args.steps, args.warmup, world, collective)
+        timing = "HIP events around every launch of the kernel inside the timed region"
     # the engine may run a large shard as several row chunks: launches per step = records / steps over the timed region
-    allrecs = [r for r in tr.records() if r[0].endswith("<1>")]  # layer 2 (small shards: the register-staged kernel)
+    allrecs = [r for r in tr.records() if r[0].endswith("<1>")]  # layer 2
     if allrecs:
         dominant = allrecs[-1][0]
     per_step = max(1, round(len(allrecs) / (args.steps + args.warmup)))
     recs = allrecs[-args.steps * per_step:]
     gemm2_ms = sum(ms for _, ms in recs) / max(len(recs), 1)
-    value = args.envs * world * args.steps / dt
-
-    # ---- per-kernel picture of one step (all kernels traced; outside the timed region) ---------------------------
-    with nat.KernelTrace(capacity=16 * 8) as tr_all:
-        for _ in range(8):
+    value = global_envs * args.steps / dt
+    n_sets = len(hot.states)
+    # ---- per-kernel picture of one step (all kernels traced, eager; outside the timed region, clocks settled) -----
+    hot._graphs = None
+    with nat.KernelTrace(capacity=16 * 16) as tr_all:
+        for _ in range(16):
             hot.step()
-    per_kernel = {k: round(t / 8 * 1e3, 2) for k, (c, t) in tr_all.summary().items()}  # us per step (all launches of the kernel)
+    per_kernel = {k: round(t / 16 * 1e3, 2) for k, (c, t) in tr_all.summary().items()}  # us per step (all launches of the kernel)
 
     out = None
     if rank == 0:
         # HBM traffic of the dominant kernel: PMC FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE per launch, collected
-        # in separate rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh) and committed
-        traffic = None
+        # in separate rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh) and committed: STATIC
+        # numbers of the profiled run, not re-measured here (traffic_source says so)
+        traffic, hbm_traffic, tj = None, None, {}
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            # keys are "kernel<template args>@workgroups"; layer 2 at this shard size = ceil(envs / 128) * 4 workgroups
-            # keys are "kernel<template args>@workgroups" (workgroups of one launch)
-            rows = args.envs // per_step
-            key = {"f16x3": f"disc_gemm_f16_dma_kernel<1, 0, 4, 2>@{(rows + 255) // 256 * 2}",
-                   "f32": f"disc_gemm_kernel<128, 128, 16, 1, 1, 4>@{(rows + 127) // 128 * 4}"}[args.disc_precision]
-            traffic = tj[key]["hbm_bytes"] if args.envs >= 16384 else None
         except Exception:
-            traffic = None
-        # fabric-side bytes of the env-step + expert-sample launch from the same PMC passes (it also writes the
-        # discriminator's scaled input, which the algorithmic count of SURVEY 8d does not include)
-        hbm_traffic = None
-        try:
-            hbm_traffic = tj[f"env_step_fast_reference_kernel<32>@{args.envs // 32 + args.envs * spec.K // 64}"]["hbm_bytes"]
-        except Exception:
-            hbm_traffic = None
-        flops2 = (2.0 * args.envs * 1024 * 512 + 2.0 * args.envs * 512) / per_step   # layer 2 + the fused 512 -> 1 dot, per launch
+            tj = {}
+        rows = envs // per_step
+        for key, val in tj.items():  # keys are "kernel<template args>@workgroups" (workgroups of one launch)
+            if not isinstance(val, dict):
+                continue
+            if key.startswith(dominant.split("<")[0]) and val.get("layer") == 2 and val.get("rows") == rows \
+                    and val.get("precision", "f16x3") == args.disc_precision:
+                traffic = val["hbm_bytes"]
+            if key.startswith("env_step") and val.get("envs") == envs and val.get("workload", "g1_walk") == spec.name:
+                hbm_traffic = val["hbm_bytes"]
+        flops2 = (2.0 * envs * 1024 * 512 + 2.0 * envs * 512) / per_step   # layer 2 + the fused 512 -> 1 dot, per launch
         achieved = flops2 / (gemm2_ms * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS[args.disc_precision]
         nprod = MFMA_PER_PRODUCT[args.disc_precision]
         # the env step and the expert-motion sample share one launch (amp_env_step_with_reference)
-        hbm_kernels = ("env_step_reference_kernel", "collect_reference_kernel", "env_step_kernel", "compact_scatter_kernel")
+        hbm_kernels = ("env_step_reference_kernel", "collect_reference_kernel", "env_step_kernel", "compact_scatter_kernel",
+                       "step_tail_kernel")
         hbm_us = sum(per_kernel.get(k, 0.0) for k in hbm_kernels)
-        alg_bytes = algorithmic_bytes_per_env_step(spec) * args.envs
+        alg_bytes = algorithmic_bytes_per_env_step(spec) * envs
+        rewards = ("reward scales of the reference's G1AmpEnvCfg_CUSTOM family (-1, -0.1, -10, -1e-6, -1e-3, velocity tracking 1.0; "
+                   "policy obs 102) -- MORE work per env than the all-zero scales / 100-float policy obs of the reference's Walk cfg"
+                   if spec.robot == "g1" else "constant task reward 1 (humanoid_amp_env.py:128-129)")
         out = {
             "metric": "AMP obs+motion-sample+reward env-steps/s", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (GEMM operands as 2 fp16 planes, 3 fp16 MFMAs per product, f32 accumulate)" if nprod == 3 else "f32",
-            "data": "synthetic",
-            "config": {"workload": f"{spec.description}, {args.envs} envs per GPU, synthetic joint states, discriminator "
-                                   f"[{spec.K * spec.D},1024,512,1] seed-0 init", "envs_per_gpu": args.envs,
-                       "global_envs": args.envs * world, "parallelism": f"env-shard x{world}",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": DTYPE[args.disc_precision], "data": "synthetic",
+            "config": {"workload": f"{spec.description}; {rewards}; {global_envs} envs globally = {envs} per GPU, synthetic joint "
+                                   f"states ({n_sets} input sets visited round-robin), discriminator [{spec.K * spec.D},1024,512,1] "
+                                   "seed-0 init",
+                       "baseline_config": BASELINE_CONFIG.get((spec.name, global_envs, world), "not a BASELINE.json configuration"),
+                       "envs_per_gpu": envs, "global_envs": global_envs, "parallelism": f"env-shard x{world}",
+                       "launch": "hipGraph replay of the captured step" if use_graph else "eager",
+                       "state_sets": n_sets,
                        "collective": (f"one RCCL all-gather of [{args.minibatches} x {args.replay_minibatch},{spec.K * spec.D}] f32 per "
                                       f"rank (the {args.minibatches} discriminator minibatches of an agent update) every "
                                       f"{args.rollouts} steps, async on the RCCL stream, joined inside the timed region")
@@ -288,59 +378,63 @@ def main():
             # issues; the fp16-split engine executes 3 MFMA products per algorithmic one (frac_executed counts those)
             "roofline": {"bound": "mfma", "kernel": dominant, "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                         "avg_launch_ms": gemm2_ms, "launches_timed": len(recs), "launches_per_step": per_step,
-                         "rows_per_launch": args.envs // per_step, "flops_per_launch": flops2,
+                         "traffic_source": "profiles/pmc_traffic.json (static: rocprofv3 --pmc passes of the profiled run, not "
+                                           "re-measured by this process)" if traffic else None,
+                         "avg_launch_ms": gemm2_ms, "launches_timed": len(recs), "launches_per_step": per_step, "timing": timing,
+                         "rows_per_launch": envs // per_step, "flops_per_launch": flops2,
                          "mfma_products_per_flop": nprod, "frac_executed": nprod * achieved / peak,
                          "vs_fp32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS},
             "roofline_hbm": {"bound": "hbm", "kernels": list(hbm_kernels), "achieved": alg_bytes / (hbm_us * 1e-6) / 1e9 if hbm_us else None,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (alg_bytes / (hbm_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if hbm_us else None,
                              "bytes_per_env_step": algorithmic_bytes_per_env_step(spec), "us": hbm_us,
                              "traffic": hbm_traffic,
-                             "frac_moved": (hbm_traffic / (per_kernel["env_step_reference_kernel"] * 1e-6) / 1e9 / HBM_PEAK_GBS)
-                             if hbm_traffic and per_kernel.get("env_step_reference_kernel") else None},
+                             "traffic_source": "profiles/pmc_traffic.json (static)" if hbm_traffic else None},
             "kernel_us_per_step": per_kernel,
             "disc_flops_per_env_step": disc_flops_per_row(spec.K * spec.D),
         }
+    del hot
+    torch.cuda.empty_cache()
 
-    # ---- secondary point of the metric: 4096 envs per GPU -------------------------------------------------------
-    if not args.no_secondary and args.envs != 4096:
-        del hot
-        torch.cuda.empty_cache()
-        with contextlib.redirect_stdout(sys.stderr):
-            hot_s = HotPath(spec, 4096, device, seed=99 + rank)
-        if not args.no_graph:
-            hot_s.capture()  # a 4096-env step is launch-bound: replay it as one hipGraph
-        settle(hot_s, max_seconds=2.0)
-        dts = timed_steps(hot_s, max(args.steps, 50), args.warmup, world, None)
-        if rank == 0:
-            out["envs_4096"] = {"value": 4096 * world * max(args.steps, 50) / dts, "unit": "env-steps/s",
-                                "ms_per_step": dts / max(args.steps, 50) * 1e3, "envs_per_gpu": 4096,
-                                "launch": "eager" if args.no_graph else "hipGraph replay of the captured step"}
-        del hot_s
+    # ---- secondary points of the metric: the shard sizes of the multi-GPU configs (8192) and of configs[1] (4096) ----
+    if not args.no_secondary:
+        for n_sec in (8192, 4096):
+            if n_sec == envs:
+                continue
+            sec = measure_shard(spec, n_sec, device, rank, world, max(args.steps, 50), args.warmup, not args.no_graph,
+                                args.disc_precision, args.state_sets)
+            if rank == 0:
+                out[f"envs_{n_sec}"] = sec
 
     # ---- the same step on the fp32-MFMA GEMM engine (exact fp32 fma chain), for comparison ---------------------------
     if not args.no_fp32_engine and args.disc_precision != "f32" and world == 1:
-        torch.cuda.empty_cache()
         with contextlib.redirect_stdout(sys.stderr):
-            hot_m = HotPath(spec, args.envs, device, seed=1234 + rank, disc_precision="f32")
+            hot_m = HotPath(spec, envs, device, seed=1234 + rank, disc_precision="f32", state_sets=n_state_sets(spec, envs, args.state_sets))
         settle(hot_m)
         with nat.KernelTrace(capacity=args.steps + args.warmup + 8, kernel_filter=DOMINANT_KERNEL["f32"]) as trm:
             dtm = timed_steps(hot_m, args.steps, args.warmup, world, None)
         rm = trm.records()[-args.steps:]
         ms32 = sum(ms for _, ms in rm) / max(len(rm), 1)
-        flops2 = 2.0 * args.envs * 1024 * 512 + 2.0 * args.envs * 512  # the fp32 engine runs the shard as one launch
+        flops2 = 2.0 * envs * 1024 * 512 + 2.0 * envs * 512  # the fp32 engine runs the shard as one launch
         out["fp32_mfma_engine"] = {
-            "value": args.envs * world * args.steps / dtm, "unit": "env-steps/s", "ms_per_step": dtm / args.steps * 1e3,
+            "value": global_envs * args.steps / dtm, "unit": "env-steps/s", "ms_per_step": dtm / args.steps * 1e3, "dtype": "f32",
             "roofline": {"bound": "mfma", "kernel": DOMINANT_KERNEL["f32"], "achieved": flops2 / (ms32 * 1e-3) / 1e12,
                          "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops2 / (ms32 * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
                          "avg_launch_ms": ms32},
             "note": "AmpDiscriminator(precision='f32'): v_mfma_f32_32x32x2_f32 on fp32 operands; same results to <= 1e-6"}
+        # both engines at the top level, each with its arithmetic type
+        out["value_fp32_engine"], out["dtype_fp32_engine"] = out["fp32_mfma_engine"]["value"], "f32"
         del hot_m
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(spec, args.cpu_envs or args.envs, seed=1234)
-            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+            cb = cpu_baseline(spec, args.cpu_envs or envs, seed=1234, target_seconds=10.0)
+            one = cpu_baseline(spec, 4096, seed=1234, target_seconds=3.0, probe=False, threads=1)
+            cb["threads_1"] = {"value": one["value"], "unit": one["unit"], "sample": one["sample"], "ms_per_step": one["ms_per_step"]}
+            cb["cpu_model"] = cpu_model()
+            cb["nproc"] = os.cpu_count()
+            cb["affinity_cores"] = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None
+            out["cpu_baseline"] = cb
+            out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -18,7 +18,11 @@ def test_committed_json_line_has_the_contract_fields():
     lines = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_bench_plain.json"))
     d = json.load(open(os.path.join(ROOT, "profiles", lines[-1])))
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
-    assert d["unit"] == "env-steps/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["data"] == "synthetic"
+    assert d["unit"] == "env-steps/s" and d["higher_is_better"] is True and d["data"] == "synthetic"
+    # round 2 on: strong scaling of BASELINE.json's global env counts is the default (weak only with --envs)
+    assert d["scaling"] in ("weak", "strong")
+    if d["scaling"] == "strong":
+        assert d["config"]["global_envs"] == d["config"]["envs_per_gpu"] * d["n_gpus"] == 65536
     assert d["vs_baseline"] is None                      # BASELINE.md publishes no number for this metric
     assert d["metric"].split()[0] == base["metric"].split()[0]
     assert d["n_gpus"] == 1 and d["steps"] > 0 and d["warmup"] >= 0
@@ -32,3 +36,24 @@ def test_committed_json_line_has_the_contract_fields():
     assert abs(r["achieved"] - r["flops_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12) <= 1e-6 * r["achieved"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
+
+
+def test_default_shards_are_the_baseline_configs():
+    """--gpus N without --envs splits BASELINE.json's global env count (configs[4]: 65 536 G1-Walk over 8; configs[3]:
+    32 768 humanoid over 4) with distributed.shard_bounds -> 8 192 envs per GPU."""
+    import importlib.util
+    import sys
+
+    sys.path.insert(0, ROOT)
+    spec = importlib.util.spec_from_file_location("_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from humanoid_amp_amd.distributed import shard_bounds
+
+    assert bench.DEFAULT_GLOBAL_ENVS == {"g1_walk": 65536, "g1_dance": 65536, "humanoid3": 32768}
+    for wl, world in (("g1_walk", 8), ("humanoid3", 4)):
+        sizes = {shard_bounds(bench.DEFAULT_GLOBAL_ENVS[wl], world, r)[1] - shard_bounds(bench.DEFAULT_GLOBAL_ENVS[wl], world, r)[0]
+                 for r in range(world)}
+        assert sizes == {8192}
+    assert bench.BASELINE_CONFIG[("g1_walk", 65536, 8)] == "configs[4]" and bench.BASELINE_CONFIG[("humanoid3", 32768, 4)] == "configs[3]"
+    assert bench.GRAPH_MAX_ENVS >= 8192
