@@ -45,7 +45,10 @@ DTYPE = {"f16x3": "f32 (GEMM operands as 2 fp16 planes, 3 fp16 MFMAs per product
 DEFAULT_GLOBAL_ENVS = {"g1_walk": 65536, "g1_dance": 65536, "humanoid3": 32768}  # BASELINE.json configs[4] / [3]
 BASELINE_CONFIG = {("g1_walk", 65536, 1): "configs[4] on 1 GPU", ("g1_walk", 65536, 8): "configs[4]",
                    ("humanoid3", 32768, 4): "configs[3]", ("g1_walk", 4096, 1): "configs[1]", ("g1_dance", 8192, 1): "configs[2]"}
-GRAPH_MAX_ENVS = 16384       # shards up to this size are launch-bound: the step is replayed as one hipGraph
+# hipGraph replay is OPT-IN (--graph): with the whole step issued by one C call (amp_hot_step) the eager launches queue up
+# back to back (rocprofv3: gaps <= 0.6 us), while a graph replay pays ~8.5 us between replays (profiles/r02_small_shard_gaps.md):
+# 8 192 envs 63.6 us eager vs 67.7 us replayed, 4 096 envs 48.7 vs 53.2
+GRAPH_MAX_ENVS = 16384       # --graph replays shards up to this size as one hipGraph
 
 
 def parse_args():
@@ -66,7 +69,7 @@ def parse_args():
     ap.add_argument("--disc-precision", default="f16x3", choices=["f16x3", "f32"],
                     help="GEMM engine of the discriminator (both fp32-class accuracy): fp16-split (default) or fp32 MFMA")
     ap.add_argument("--no-fp32-engine", action="store_true", help="skip the comparison run on the fp32-MFMA GEMM engine")
-    ap.add_argument("--no-graph", action="store_true", help="never use hipGraph replay")
+    ap.add_argument("--graph", action="store_true", help="replay shards of <= 16384 envs as a captured hipGraph instead of eager launches")
     ap.add_argument("--state-sets", type=int, default=0,
                     help="synthetic input sets visited round-robin (0 = enough to exceed the 256 MB Infinity Cache, >= 3)")
     return ap.parse_args()
@@ -231,7 +234,7 @@ def measure_shard(spec, envs, device, rank, world, steps, warmup, use_graph, pre
     settle(hot, max_seconds=2.0)
     dts = timed_steps(hot, steps, warmup, world, None)
     out = {"value": envs * world * steps / dts, "unit": "env-steps/s", "ms_per_step": dts / steps * 1e3, "envs_per_gpu": envs,
-           "launch": "hipGraph replay of the captured step" if use_graph else "eager",
+           "launch": "hipGraph replay of the captured step" if use_graph else "eager: one amp_hot_step call per step (4 kernel launches)",
            "kernel_us_per_step_eager": per_kernel, "state_sets": len(hot.states)}
     del hot
     torch.cuda.empty_cache()
@@ -277,7 +280,7 @@ def main():
         scaling, global_envs = "strong", args.global_envs or DEFAULT_GLOBAL_ENVS[args.workload]
         lo, hi = shard_bounds(global_envs, world, rank)
         envs = hi - lo
-    use_graph = not args.no_graph and envs <= GRAPH_MAX_ENVS
+    use_graph = args.graph and envs <= GRAPH_MAX_ENVS
     with contextlib.redirect_stdout(sys.stderr):  # MotionLoader prints like the reference; stdout carries only the JSON line
         hot = HotPath(spec, envs, device, seed=1234 + rank, disc_precision=args.disc_precision,
                       state_sets=n_state_sets(spec, envs, args.state_sets))
@@ -368,7 +371,7 @@ def main():
                                    "seed-0 init",
                        "baseline_config": BASELINE_CONFIG.get((spec.name, global_envs, world), "not a BASELINE.json configuration"),
                        "envs_per_gpu": envs, "global_envs": global_envs, "parallelism": f"env-shard x{world}",
-                       "launch": "hipGraph replay of the captured step" if use_graph else "eager",
+                       "launch": "hipGraph replay of the captured step" if use_graph else "eager: one amp_hot_step call per step (4 kernel launches)",
                        "state_sets": n_sets,
                        "collective": (f"one RCCL all-gather of [{args.minibatches} x {args.replay_minibatch},{spec.K * spec.D}] f32 per "
                                       f"rank (the {args.minibatches} discriminator minibatches of an agent update) every "
@@ -400,7 +403,7 @@ def main():
         for n_sec in (8192, 4096):
             if n_sec == envs:
                 continue
-            sec = measure_shard(spec, n_sec, device, rank, world, max(args.steps, 50), args.warmup, not args.no_graph,
+            sec = measure_shard(spec, n_sec, device, rank, world, max(args.steps, 50), args.warmup, args.graph,
                                 args.disc_precision, args.state_sets)
             if rank == 0:
                 out[f"envs_{n_sec}"] = sec

@@ -46,6 +46,19 @@ class AmpResetArgs(C.Structure):
     ]
 
 
+class AmpCompactArgs(C.Structure):
+    _fields_ = [("mask", C.c_void_p), ("tile_counts", C.c_void_p), ("tile_envs", C.c_int32), ("reserved", C.c_int32),
+                ("num_envs", C.c_int64), ("ids", C.c_void_p), ("count", C.c_void_p)]
+
+
+class AmpHotStepArgs(C.Structure):
+    _fields_ = [("cfg", C.c_void_p), ("state", C.c_void_p), ("bufs", C.c_void_p), ("num_envs", C.c_int64), ("motion", C.c_void_p),
+                ("times", C.c_void_p), ("motion_ids", C.c_void_p), ("n_samples", C.c_int64), ("K", C.c_int32), ("reserved", C.c_int32),
+                ("expert_out", C.c_void_p), ("disc", C.c_void_p), ("reward_scale", C.c_float), ("task_weight", C.c_float),
+                ("style_weight", C.c_float), ("reserved2", C.c_int32), ("logits", C.c_void_p), ("style", C.c_void_p),
+                ("combined", C.c_void_p), ("workspace", C.c_void_p), ("compact", C.c_void_p)]
+
+
 class AmpCommandArgs(C.Structure):
     _fields_ = [
         ("command", C.c_void_p), ("time_left", C.c_void_p), ("step_dt", C.c_float), ("vel_lo", C.c_float), ("vel_span", C.c_float),
@@ -180,6 +193,9 @@ SIGNATURES = {
     "amp_ring_append": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
     "amp_ring_sample": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _i64, _vp, _i64, _vp, _vp]),
     "amp_disc_style_reward_prescaled": (C.c_int, [_vp, _vp, _i64, _f32, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "amp_disc_style_reward_prescaled_compact": (C.c_int, [_vp, _vp, _i64, _f32, _vp, _f32, _f32, _vp, _vp, _vp, _vp,
+                                                          C.POINTER(AmpCompactArgs), _vp]),
+    "amp_hot_step": (C.c_int, [C.POINTER(AmpHotStepArgs), _vp]),
     "amp_disc_style_reward": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 

@@ -6,11 +6,9 @@
 //   pass 2: a workgroup owns 4 tiles (one per wave).  Its base offset is the sum of all earlier tile counts
 //           (block-wide reduction of <= N/64 ints, L2 resident); inside a wave the rank of a set lane is
 //           mbcnt(ballot) -- gfx950 v_mbcnt_lo/hi -- so ids come out ascending by construction.
-#include "amp_common.hpp"
+#include "compact_kernels.hpp"
 
 namespace amp {
-
-constexpr int kTile = 64;
 
 __global__ __launch_bounds__(kBlock) void tile_count_kernel(const uint8_t* __restrict__ mask, int64_t N,
                                                             int32_t* __restrict__ counts) {
@@ -23,36 +21,12 @@ __global__ __launch_bounds__(kBlock) void tile_count_kernel(const uint8_t* __res
   }
 }
 
-// counts[] holds one entry per `64 / sub` envs (sub = 1, 2 or 4 count entries per 64-env wave tile)
 __global__ __launch_bounds__(kBlock) void compact_scatter_kernel(const uint8_t* __restrict__ mask,
                                                                  const int32_t* __restrict__ counts, int64_t N,
                                                                  int64_t n_tiles, int sub, int64_t n_counts,
                                                                  int64_t* __restrict__ ids,
                                                                  int64_t* __restrict__ count_out) {
-  __shared__ long long s_part[kBlock / kWave];
-  __shared__ long long s_base;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t first_tile = (int64_t)blockIdx.x * (kBlock / kTile);
-  // exclusive prefix of the tile counts before this workgroup
-  long long acc = 0;
-  for (int64_t t = tid; t < first_tile * sub; t += kBlock) acc += counts[t];
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-  if (lane == 0) s_part[wave] = acc;
-  __syncthreads();
-  if (tid == 0) s_base = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
-  __syncthreads();
-  long long base = s_base;
-  const int64_t my_tile = first_tile + wave;
-  for (int64_t c = first_tile * sub; c < my_tile * sub && c < n_counts; ++c) base += counts[c];
-  const int64_t i = my_tile * kTile + lane;
-  const int bit = (i < N) ? (mask[i] != 0) : 0;
-  const unsigned long long b = __ballot(bit);
-  if (bit) {
-    const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
-    ids[base + rank] = i;
-  }
-  // the workgroup holding the last tile publishes the total
-  if (my_tile == n_tiles - 1 && lane == 0) *count_out = base + __popcll(b);
+  compact_scatter_body(blockIdx.x, mask, counts, N, n_tiles, sub, n_counts, ids, count_out);
 }
 
 }  // namespace amp

@@ -21,6 +21,7 @@
 #include "disc_gemm.hpp"
 #include "disc_gemm_f16.hpp"
 #include "disc_gemm_f16_dma.hpp"
+#include "compact_kernels.hpp"
 
 #include <cstdlib>
 
@@ -56,12 +57,11 @@ constexpr int kPadK = 16;  // in_dim is zero-padded to a multiple of the fp32 la
 constexpr int kPadKH = 32; // ... and of the fp16 layer-1 k-tile
 constexpr int64_t kWsHeader = 256;  // workspace header: [0] abs-max of the scaled input (dynamic bound)
 
-__global__ __launch_bounds__(kBlock) void disc_finalize_kernel(const float* __restrict__ partial, int n_tiles,
-                                                               const float* __restrict__ b3, int64_t M, float scale,
-                                                               const float* __restrict__ task, float task_w,
-                                                               float style_w, float* __restrict__ logits,
-                                                               float* __restrict__ style, float* __restrict__ combined) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+__device__ __forceinline__ void disc_finalize_body(const int64_t i, const float* __restrict__ partial, int n_tiles,
+                                                   const float* __restrict__ b3, int64_t M, float scale,
+                                                   const float* __restrict__ task, float task_w, float style_w,
+                                                   float* __restrict__ logits, float* __restrict__ style,
+                                                   float* __restrict__ combined) {
   if (i >= M) return;
   const float* p = partial + i * n_tiles;
   float s = 0.0f;
@@ -84,6 +84,34 @@ __global__ __launch_bounds__(kBlock) void disc_finalize_kernel(const float* __re
   if (logits) logits[i] = lg;
   if (style) style[i] = st;
   if (combined) combined[i] = task ? task_w * task[i] + style_w * st : style_w * st;
+}
+
+__global__ __launch_bounds__(kBlock) void disc_finalize_kernel(const float* __restrict__ partial, int n_tiles,
+                                                               const float* __restrict__ b3, int64_t M, float scale,
+                                                               const float* __restrict__ task, float task_w,
+                                                               float style_w, float* __restrict__ logits,
+                                                               float* __restrict__ style, float* __restrict__ combined) {
+  disc_finalize_body((int64_t)blockIdx.x * kBlock + threadIdx.x, partial, n_tiles, b3, M, scale, task, task_w, style_w, logits,
+                     style, combined);
+}
+
+// The step's two latency-bound tail launches as ONE (horizontal fusion; they share nothing): workgroups
+// [0, compact_blocks) run the reset-id compaction of amp_reset_compact_tiles, the rest the finalize.  Bit-identical
+// to the separate launches by construction (the same device bodies).
+struct CompactLaunch {
+  const uint8_t* mask; const int32_t* counts; int64_t N, n_tiles, n_counts; int sub; int64_t* ids; int64_t* count; int blocks;
+};
+__global__ __launch_bounds__(kBlock) void step_tail_kernel(CompactLaunch c, const float* __restrict__ partial, int n_tiles,
+                                                           const float* __restrict__ b3, int64_t M, float scale,
+                                                           const float* __restrict__ task, float task_w, float style_w,
+                                                           float* __restrict__ logits, float* __restrict__ style,
+                                                           float* __restrict__ combined) {
+  if ((int)blockIdx.x < c.blocks) {
+    compact_scatter_body(blockIdx.x, c.mask, c.counts, c.N, c.n_tiles, c.sub, c.n_counts, c.ids, c.count);
+    return;
+  }
+  disc_finalize_body((int64_t)(blockIdx.x - c.blocks) * kBlock + threadIdx.x, partial, n_tiles, b3, M, scale, task, task_w,
+                     style_w, logits, style, combined);
 }
 
 __global__ void disc_scaler_kernel(const double* __restrict__ mean64, const double* __restrict__ var64, int n, int np,
@@ -312,7 +340,23 @@ static int launch_f16(GemmF16Args g, int64_t rows, int N, const char* name, hipS
   disc_gemm_f16_kernel<TM, TN, BK, MODE, MINW><<<grid, kBlock, gemm_f16_lds_bytes<TM, TN, BK>(), st>>>(g);
   return launch_status(name);
 }
-// kernels whose LDS tile exceeds the 64 KB default need the limit raised once (not capturable: done at create)
+// LDS-DMA launch of one layer on a (64 TM) x (128 TN) tile (block-layout operands)
+template <int MODE, int TM, int TN>
+static int launch_dma(GemmF16Args g, int64_t rows, int N, const char* name, hipStream_t st) {
+  using T = DmaTile<TM, TN>;
+  g.n_tiles = N / T::BN;
+  g.m_tiles = (int)((rows + T::BM - 1) / T::BM);
+  const unsigned grid = (unsigned)(((int64_t)g.m_tiles * g.n_tiles + 7) / 8 * 8);
+  amp::TraceScope trace__(name, st);
+  disc_gemm_f16_dma_kernel<MODE, TM, TN><<<grid, kDmaThreads, T::kLds, st>>>(g);
+  return launch_status(name);
+}
+template <int MODE, int TM, int TN>
+static hipError_t dma_kernel_init() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gemm_f16_dma_kernel<MODE, TM, TN>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, DmaTile<TM, TN>::kLds);
+}
+// kernels whose LDS tile exceeds the 64 KB default need the limit raised once per device (not capturable: done at create)
 static int f16_kernels_init() {
   // the attribute is per DEVICE: a process that creates discriminators on several GPUs raises the limit on each
   static bool done[64] = {};
@@ -321,10 +365,11 @@ static int f16_kernels_init() {
   if (dev >= 0 && dev < 64 && done[dev]) return AMP_OK;
   AMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gemm_f16_kernel<2, 2, 64, 1, 2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, gemm_f16_lds_bytes<2, 2, 64>()));
-  AMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gemm_f16_dma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              kDmaLdsBytes));
-  AMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gemm_f16_dma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              kDmaLdsBytes));
+  AMP_HIP((dma_kernel_init<0, 4, 2>()));
+  AMP_HIP((dma_kernel_init<1, 4, 2>()));
+  AMP_HIP((dma_kernel_init<1, 4, 1>()));
+  AMP_HIP((dma_kernel_init<0, 2, 1>()));
+  AMP_HIP((dma_kernel_init<1, 2, 1>()));
   if (dev >= 0 && dev < 64) done[dev] = true;
   return AMP_OK;
 }
@@ -333,48 +378,53 @@ static int f16_kernels_init() {
 // on-die instead of from HBM (a 65 536-row shard writes 268 MB: read back in the same order NOTHING would still be
 // resident).  32 768 rows = 134 MB, and 128 x 2 layer-2 tiles = one workgroup per CU.
 constexpr int64_t kChunkRows = 32768;
-static bool f16_use_dma(const AmpDisc* h, int64_t rows) {  // 256 x 256 LDS-DMA kernel: needs >= ~1 tile per CU
-  return h->h1 % kDmaBN == 0 && h->h2 % kDmaBN == 0 && (rows + kDmaBM - 1) / kDmaBM * (h->h2 / kDmaBN) >= 192;
+
+// Kernel plan of a chunk of `rows` rows, measured on MI355X with tools/gemm_f16_bench.hip (TILES=1 / default mode;
+// profiles/r02_gemm_f16_small_shards.txt).  What decides it: an LDS-DMA workgroup takes in ~68 GB/s, so a tile must be
+// large enough to compute longer than its fills take (256 x 256: 21 B of fill per matrix-pipe cycle of the CU, 128 x 128: 42)
+// AND the launch must cover the 256 CUs.  us per launch, layer 1 / layer 2 (K = 192 / 1024):
+//   rows      256x256      256x128      128x128      register-staged 128x128 / 64x64
+//   32 768    56 / 80
+//   16 384    28.9 / 66.7   33.6 / 44.3  30.8 / 47.1
+//   12 288    26.6 / 64.2   31.1 / 40.6  25.4 / 42.8
+//    8 192    24.8 / 62.0   19.1 / 37.9  18.0 / 29.0   18.5 / 34.6, 20.8 / 37.6
+//    4 096    22.7 / 60.2   16.1 / 35.6  12.0 / 25.9   (64 x 64: 12 / 22 inside the step)
+enum { kPlanRegister = 0, kPlanDmaSmall = 1, kPlanDmaMid = 2, kPlanDmaLarge = 3 };
+static int f16_plan(const AmpDisc* h, int64_t rows) {
+  if (h->h1 % kDmaBN != 0 || h->h2 % kDmaBN != 0) return kPlanRegister;   // the LDS-DMA tiles need 256-column multiples
+  if ((rows + kDmaBM - 1) / kDmaBM * (h->h2 / kDmaBN) >= 192) return kPlanDmaLarge;  // >= ~1 tile of 256 x 256 per CU
+  if (rows >= 12288) return kPlanDmaMid;     // layer 1: 256 x 256, layer 2: 256 x 128
+  if (rows > 5120) return kPlanDmaSmall;     // both layers 128 x 128 (the 8 192-env shards of the multi-GPU configurations)
+  return kPlanRegister;
 }
+static bool f16_use_dma(const AmpDisc* h, int64_t rows) { return f16_plan(h, rows) != kPlanRegister; }
 static int64_t f16_chunk_rows(const AmpDisc* h, int64_t rows) {
-  return f16_use_dma(h, kChunkRows) && rows > kChunkRows + kChunkRows / 2 ? kChunkRows : rows;
-}
-// column tiles of the layer-2 launch (the partial-logit layout does not depend on it: h2 / 32 block sums per row)
-static int f16_n_tiles(const AmpDisc* h, int64_t rows) {
-  const int64_t chunk = f16_chunk_rows(h, rows);
-  if (f16_use_dma(h, chunk)) return h->h2 / kDmaBN;
-  const bool big = (chunk + 127) / 128 * (h->h2 / 128) >= 512;
-  return h->h2 / (big ? 128 : 64);
+  return f16_plan(h, kChunkRows) == kPlanDmaLarge && rows > kChunkRows + kChunkRows / 2 ? kChunkRows : rows;
 }
 static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* amax, int64_t rows, _Float16* H1p, float* partial,
                             float scale, const float* task, float task_w, float style_w, float* logits, float* style,
-                            float* combined, hipStream_t st) {
-  // Kernel choice measured with tools/gemm_f16_bench.hip (profiles/r01_gemm_f16_variants.txt): the 256 x 256 LDS-DMA
-  // kernels (block-layout operands) for both layers when a chunk fills the chip; else the register-staged kernels on
-  // planar operands: 128 x 128 (x 32 at 3 workgroups / CU for layer 1, x 64 at 2 for layer 2), 64 x 64 below 512 such tiles
+                            float* combined, hipStream_t st, const CompactLaunch* compact = nullptr) {
+  // every kernel below accumulates in the same order and emits the same canonical partial logits (one per row and
+  // 32-column block), so the choice changes the time, never a bit of the result
   const int64_t chunk = f16_chunk_rows(h, rows);
-  const int n_tiles = f16_n_tiles(h, rows);
   const int n_blocks = h->h2 / 32;  // canonical partial logits: one per (row, 32-column block)
   int rc = AMP_OK;
   for (int64_t r0 = 0; r0 < rows && rc == AMP_OK; r0 += chunk) {
     const int64_t m = rows - r0 < chunk ? rows - r0 : chunk;
+    const int plan = f16_plan(h, chunk);  // by the chunk size (a short last chunk keeps the hidden layer's layout)
+    const bool dma = plan != kPlanRegister;
     auto big_tiles = [&](int N) { return (m + 127) / 128 * (N / 128) >= 512; };
     GemmF16Args g1{};
     g1.A = Xp + 2 * r0 * h->k1h; g1.lda = h->k1h; g1.plane_a = 0; g1.M = m;  // (p0, p1) pairs: two halves per element
     g1.W = h->w1h; g1.plane_w = (int64_t)h->h1 * h->k1h; g1.Kp = h->k1h; g1.N = h->h1;
     g1.bias = h->b1; g1.range = h->range; g1.amax = amax; g1.layer = 1;
     g1.H = H1p + r0 * h->h1; g1.ldh = h->h1; g1.plane_h = rows * h->h1;
-    const bool dma = f16_use_dma(h, chunk);  // both layers or neither: it decides the hidden layer's layout
     if (dma) {
       g1.W = h->w1b;  // block layout; the hidden layer comes out in block layout too (row pitch 2 * h1)
       g1.H = H1p;     // every chunk reuses the SAME 134 MB: rewritten while still dirty in the Infinity Cache, the hidden
                       // layer is (mostly) never written back to HBM, and the lines it evicts are not dirty either
-      g1.n_tiles = h->h1 / kDmaBN;
-      g1.m_tiles = (int)((m + kDmaBM - 1) / kDmaBM);
-      const unsigned grid = (unsigned)(((int64_t)g1.m_tiles * g1.n_tiles + 7) / 8 * 8);
-      amp::TraceScope trace__("disc_gemm_f16_dma_kernel<0>", st);
-      disc_gemm_f16_dma_kernel<0><<<grid, kDmaThreads, kDmaLdsBytes, st>>>(g1);
-      rc = launch_status("disc_gemm_f16_dma_kernel<0>");
+      if (plan == kPlanDmaSmall) rc = launch_dma<0, 2, 1>(g1, m, h->h1, "disc_gemm_f16_dma_kernel<0>", st);
+      else rc = launch_dma<0, 4, 2>(g1, m, h->h1, "disc_gemm_f16_dma_kernel<0>", st);
     } else if (big_tiles(h->h1)) {
       rc = launch_f16<2, 2, 32, 0, 3>(g1, m, h->h1, "disc_gemm_f16_kernel<0>", st);
     } else {
@@ -387,25 +437,29 @@ static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* a
     g2.W = h->w2h; g2.plane_w = (int64_t)h->h2 * h->h1; g2.Kp = h->h1; g2.N = h->h2;
     g2.bias = h->b2; g2.range = h->range; g2.amax = amax; g2.layer = 2;
     g2.w3 = h->w3; g2.partial = partial + r0 * n_blocks;
-    if (dma) {  // every chunk (a short last one too): one partial layout
+    if (dma) {
       g2.A = H1p;
       g2.W = h->w2b;
-      g2.n_tiles = n_tiles;
-      g2.m_tiles = (int)((m + kDmaBM - 1) / kDmaBM);
-      const unsigned grid = (unsigned)(((int64_t)g2.m_tiles * g2.n_tiles + 7) / 8 * 8);
-      amp::TraceScope trace__("disc_gemm_f16_dma_kernel<1>", st);
-      disc_gemm_f16_dma_kernel<1><<<grid, kDmaThreads, kDmaLdsBytes, st>>>(g2);
-      rc = launch_status("disc_gemm_f16_dma_kernel");
-    } else if (n_tiles == h->h2 / 128) {
+      if (plan == kPlanDmaSmall) rc = launch_dma<1, 2, 1>(g2, m, h->h2, "disc_gemm_f16_dma_kernel<1>", st);
+      else if (plan == kPlanDmaMid) rc = launch_dma<1, 4, 1>(g2, m, h->h2, "disc_gemm_f16_dma_kernel<1>", st);
+      else rc = launch_dma<1, 4, 2>(g2, m, h->h2, "disc_gemm_f16_dma_kernel<1>", st);
+    } else if (big_tiles(h->h2)) {
       rc = launch_f16<2, 2, 64, 1, 2>(g2, m, h->h2, "disc_gemm_f16_kernel<1>", st);
     } else {
       rc = launch_f16<1, 1, 64, 1, 4>(g2, m, h->h2, "disc_gemm_f16_kernel<1>", st);
     }
   }
   if (rc != AMP_OK) return rc;
+  const unsigned fin_blocks = (unsigned)((rows + kBlock - 1) / kBlock);
+  if (compact) {
+    amp::TraceScope trace__("step_tail_kernel", st);
+    step_tail_kernel<<<fin_blocks + (unsigned)compact->blocks, kBlock, 0, st>>>(*compact, partial, n_blocks, h->b3, rows, scale, task,
+                                                                              task_w, style_w, logits, style, combined);
+    return launch_status("step_tail_kernel");
+  }
   { amp::TraceScope trace__("disc_finalize_kernel", st);
-    disc_finalize_kernel<<<(unsigned)((rows + kBlock - 1) / kBlock), kBlock, 0, st>>>(partial, n_blocks, h->b3, rows, scale, task,
-                                                                                   task_w, style_w, logits, style, combined);
+    disc_finalize_kernel<<<fin_blocks, kBlock, 0, st>>>(partial, n_blocks, h->b3, rows, scale, task, task_w, style_w, logits, style,
+                                                      combined);
   }
   return launch_status("disc_finalize_kernel");
 }
@@ -675,9 +729,41 @@ int amp_disc_input_layout(const AmpDisc* h, AmpDiscInputLayout* out) {
   return AMP_OK;
 }
 
+static int style_reward_prescaled_impl(const AmpDisc* h, const void* xs_any, int64_t rows, float scale, const float* task, float task_w,
+                                       float style_w, float* logits, float* style, float* combined, void* workspace,
+                                       amp_stream_t stream, const CompactLaunch* compact);
+
 int amp_disc_style_reward_prescaled(const AmpDisc* h, const void* xs_any, int64_t rows, float scale, const float* task, float task_w,
                                     float style_w, float* logits, float* style, float* combined, void* workspace,
                                     amp_stream_t stream) {
+  return style_reward_prescaled_impl(h, xs_any, rows, scale, task, task_w, style_w, logits, style, combined, workspace, stream, nullptr);
+}
+
+int amp_disc_style_reward_prescaled_compact(const AmpDisc* h, const void* xs_any, int64_t rows, float scale, const float* task,
+                                            float task_w, float style_w, float* logits, float* style, float* combined,
+                                            void* workspace, const AmpCompactArgs* c, amp_stream_t stream) {
+  AMP_REQUIRE(h && c, "amp_disc_style_reward_prescaled_compact: null argument");
+  AMP_REQUIRE(c->num_envs >= 1 && c->mask && c->tile_counts && c->ids && c->count, "amp_disc_style_reward_prescaled_compact: null compaction buffer");
+  AMP_REQUIRE(c->tile_envs == 16 || c->tile_envs == 32 || c->tile_envs == 64, "amp_disc_style_reward_prescaled_compact: tile_envs must be 16, 32 or 64");
+  AMP_REQUIRE(rows >= 1, "amp_disc_style_reward_prescaled_compact: needs at least one row");
+  CompactLaunch cl;
+  cl.mask = c->mask; cl.counts = c->tile_counts; cl.N = c->num_envs;
+  cl.n_tiles = (c->num_envs + kTile - 1) / kTile;
+  cl.n_counts = (c->num_envs + c->tile_envs - 1) / c->tile_envs;
+  cl.sub = kTile / c->tile_envs; cl.ids = c->ids; cl.count = c->count;
+  cl.blocks = (int)((cl.n_tiles + 3) / 4);
+  if (!(h->mode == AMP_DISC_F16X3 && static_bound(h))) {
+    // other engines / input formats: the two launches stay separate (same results)
+    int rc = amp_reset_compact_tiles(c->mask, c->tile_counts, c->tile_envs, c->num_envs, c->ids, c->count, stream);
+    if (rc != AMP_OK) return rc;
+    return style_reward_prescaled_impl(h, xs_any, rows, scale, task, task_w, style_w, logits, style, combined, workspace, stream, nullptr);
+  }
+  return style_reward_prescaled_impl(h, xs_any, rows, scale, task, task_w, style_w, logits, style, combined, workspace, stream, &cl);
+}
+
+static int style_reward_prescaled_impl(const AmpDisc* h, const void* xs_any, int64_t rows, float scale, const float* task, float task_w,
+                                       float style_w, float* logits, float* style, float* combined, void* workspace,
+                                       amp_stream_t stream, const CompactLaunch* compact) {
   AMP_REQUIRE(h, "amp_disc_style_reward_prescaled: null handle");
   AMP_REQUIRE(rows >= 0, "amp_disc_style_reward_prescaled: negative rows");
   if (rows == 0) return AMP_OK;
@@ -689,7 +775,7 @@ int amp_disc_style_reward_prescaled(const AmpDisc* h, const void* xs_any, int64_
   hipStream_t st = (hipStream_t)stream;
   if (h->mode == AMP_DISC_F16X3 && static_bound(h))  // fp16 pairs at the clamp's plane scale (amp_disc_input_layout)
     return disc_forward_f16(h, (const _Float16*)xs_any, nullptr, rows, (_Float16*)ws.h1, ws.partial, scale, task, task_w, style_w,
-                            logits, style, combined, st);
+                            logits, style, combined, st, compact);
   if (h->mode == AMP_DISC_F16X3) {
     // fp32 rows with no clamp to bound them: bound them by their abs-max, then split into planes
     AMP_HIP(hipMemsetAsync(ws.header, 0, sizeof(float), st));

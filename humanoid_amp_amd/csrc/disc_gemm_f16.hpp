@@ -206,10 +206,9 @@ struct StageF16 {
 };
 
 // MODE 0 reads its activations as (p0, p1) pairs (the scaled input), MODE 1 as planes (H1, written by MODE 0).
-// PF = register stages prefetched ahead (1 or 2).
-// XP (tools/gemm_f16_bench.hip only; wrong results): 1 = no global loads / LDS writes after the first k-tile,
-// 2 = additionally no barriers.
-template <int TM, int TN, int BK, int MODE, int MINW, int PF = 1, int XP = 0>
+// One register stage prefetched ahead (two stages and the no-load / no-barrier ablations were measured in round 1:
+// profiles/r01_gemm_f16_variants.txt; neither is kept in the product kernel).
+template <int TM, int TN, int BK, int MODE, int MINW>
 __global__ __launch_bounds__(kBlock, MINW) void disc_gemm_f16_kernel(GemmF16Args g) {
   constexpr int BM = 64 * TM, BN = 64 * TN, LDK = BK + 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -263,45 +262,19 @@ __global__ __launch_bounds__(kBlock, MINW) void disc_gemm_f16_kernel(GemmF16Args
         for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[b], x0[a], acc[a][b], 0, 0, 0);
     }
   };
-  if (PF == 1) {
+  {
     StageF16<BM, BN, BK, MODE == 0> stg;
     stg.load(g, m0, n0, 0, tid);
     stg.store(smem, tid);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-      if (XP == 0 && kt + 1 < nk) stg.load(g, m0, n0, kt + 1, tid);  // in flight under this tile's MFMAs
-      __builtin_amdgcn_sched_barrier(0);
-      compute();
-      if (XP < 2) f16_lds_barrier();
-      if (kt + 1 < nk) {
-        if (XP == 0) stg.store(smem, tid);
-        if (XP < 2) f16_lds_barrier();
-      }
-    }
-  } else {
-    // two register stages: the loads of k-tile kt + 2 are issued before the MFMAs of k-tile kt (two compute phases
-    // of cover for the global latency); named stages, loop unrolled by two, so every access is to a fixed register
-    StageF16<BM, BN, BK, MODE == 0> s0, s1;
-    s0.load(g, m0, n0, 0, tid);
-    if (nk > 1) s1.load(g, m0, n0, 1, tid);
-    s0.store(smem, tid);
-    __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
-      if (kt + 2 < nk) s0.load(g, m0, n0, kt + 2, tid);
+      if (kt + 1 < nk) stg.load(g, m0, n0, kt + 1, tid);  // in flight under this tile's MFMAs
       __builtin_amdgcn_sched_barrier(0);
       compute();
       f16_lds_barrier();
       if (kt + 1 < nk) {
-        s1.store(smem, tid);
+        stg.store(smem, tid);
         f16_lds_barrier();
-        if (kt + 3 < nk) s1.load(g, m0, n0, kt + 3, tid);
-        __builtin_amdgcn_sched_barrier(0);
-        compute();
-        f16_lds_barrier();
-        if (kt + 2 < nk) {
-          s0.store(smem, tid);
-          f16_lds_barrier();
-        }
       }
     }
   }

@@ -149,6 +149,38 @@ class EnvStepKernel:
         workgroups, bit-identical to the separate call.  State arguments are torch views straight off the simulator:
         ``[N, n_dof]`` rows (any env stride), ``[N, 3|4]`` root views (e.g. ``body_pos_w[:, ref]``),
         ``body_pos`` = ``[N, B, 3]`` with ``key_body_indexes`` into B, ``soft_limits`` ``[N, n_dof, 2]`` or ``[n_dof, 2]``."""
+        s = self.sim_state(joint_pos=joint_pos, joint_vel=joint_vel, joint_acc=joint_acc, actions=actions, root_pos=root_pos,
+                           root_quat=root_quat, root_lin_vel=root_lin_vel, root_ang_vel=root_ang_vel, body_pos=body_pos,
+                           key_body_indexes=key_body_indexes, soft_limits=soft_limits, episode_length=episode_length,
+                           command=command, last_actions=last_actions)
+        cfg, N = self.cfg, self.num_envs
+        b = self._buffers()
+        with torch.cuda.device(self.device):
+            if reference is None:
+                nat.check(self._lib.amp_env_step(C.byref(self._c), C.byref(s), C.byref(b), N, int(phases), nat.stream_ptr()),
+                          "amp_env_step")
+            else:
+                loader, times, ids, out = reference
+                n, K = self.check_reference(times, ids, out)
+                nat.check(self._lib.amp_env_step_with_reference(C.byref(self._c), C.byref(s), C.byref(b), N, int(phases),
+                                                                loader._handle, nat.dptr(times), nat.dptr(ids), n, K, nat.dptr(out),
+                                                                nat.stream_ptr()), "amp_env_step_with_reference")
+
+    def check_reference(self, times, ids, out):
+        """Argument checks of the fused expert-motion sample; returns (n_samples, K)."""
+        cfg = self.cfg
+        n, K = int(times.shape[0]), cfg.num_amp_observations
+        if times.dtype != torch.float64 or ids.dtype != torch.int64 or ids.shape[0] != n:
+            raise nat.AmpEngineError("reference times / ids must be float64 / int64 device tensors of equal length")
+        if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != n * K * cfg.amp_frame_size:
+            raise nat.AmpEngineError(f"reference output must be a contiguous float32 [{n}, {K * cfg.amp_frame_size}] tensor")
+        return n, K
+
+    def sim_state(self, *, joint_pos=None, joint_vel=None, joint_acc=None, actions=None, root_pos=None, root_quat=None,
+                  root_lin_vel=None, root_ang_vel=None, body_pos=None, key_body_indexes: Sequence[int] = (), soft_limits=None,
+                  episode_length=None, command=None, last_actions=None) -> nat.AmpSimState:
+        """The ``AmpSimState`` view struct of :meth:`launch`'s state arguments (checked); reusable for as long as the
+        tensors live and keep their addresses."""
         cfg, N = self.cfg, self.num_envs
         s = nat.AmpSimState()
 
@@ -193,21 +225,15 @@ class EnvStepKernel:
                                ("last_actions", last_actions, (N, cfg.n_dof))):
             if t is not None and tuple(t.shape) != shape:
                 raise nat.AmpEngineError(f"{name} must have shape {shape}, got {tuple(t.shape)}")
-        b = self._buffers()
-        with torch.cuda.device(self.device):
-            if reference is None:
-                nat.check(self._lib.amp_env_step(C.byref(self._c), C.byref(s), C.byref(b), N, int(phases), nat.stream_ptr()),
-                          "amp_env_step")
-            else:
-                loader, times, ids, out = reference
-                n, K = int(times.shape[0]), cfg.num_amp_observations
-                if times.dtype != torch.float64 or ids.dtype != torch.int64 or ids.shape[0] != n:
-                    raise nat.AmpEngineError("reference times / ids must be float64 / int64 device tensors of equal length")
-                if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != n * K * cfg.amp_frame_size:
-                    raise nat.AmpEngineError(f"reference output must be a contiguous float32 [{n}, {K * cfg.amp_frame_size}] tensor")
-                nat.check(self._lib.amp_env_step_with_reference(C.byref(self._c), C.byref(s), C.byref(b), N, int(phases),
-                                                                loader._handle, nat.dptr(times), nat.dptr(ids), n, K, nat.dptr(out),
-                                                                nat.stream_ptr()), "amp_env_step_with_reference")
+        return s
+
+    def compact_args(self) -> nat.AmpCompactArgs:
+        """``AmpCompactArgs`` of this shard's reset-id compaction (for the fused tail / ``amp_hot_step``)."""
+        c = nat.AmpCompactArgs()
+        c.mask, c.tile_counts = self.reset_mask.data_ptr(), self.reset_tile_counts.data_ptr()
+        c.tile_envs, c.num_envs = self.tile_envs, self.num_envs
+        c.ids, c.count = self.reset_ids.data_ptr(), self.reset_count.data_ptr()
+        return c
 
     def compact_resets(self):
         """Ascending reset ids from ``reset_mask`` using the tile counts of the last DONES launch.
@@ -438,9 +464,12 @@ class AmpDiscriminator:
         return lay
 
     def style_reward_prescaled(self, scaled: torch.Tensor, task_reward: Optional[torch.Tensor] = None, *,
-                               want_logits: bool = False):
+                               want_logits: bool = False, compact: Optional["EnvStepKernel"] = None):
         """Same as :meth:`style_reward` for an input already scaled, padded and laid out as :meth:`input_layout`
-        says (``EnvStepKernel.attach_discriminator``): float32 ``[M, padded]`` or float16 pairs ``[M, padded, 2]``."""
+        says (``EnvStepKernel.attach_discriminator``): float32 ``[M, padded]`` or float16 pairs ``[M, padded, 2]``.
+        ``compact`` (the :class:`EnvStepKernel` whose DONES phase ran this step): its reset-id compaction
+        (``compact_resets()``) rides on the finalize launch (``amp_disc_style_reward_prescaled_compact``), one launch
+        fewer; ``compact.reset_ids`` / ``reset_count`` are valid once this call's work completes."""
         lay = self.input_layout()
         pairs = lay.format == nat.AMP_DISC_INPUT_F16_PAIRS
         want = (torch.float16, (lay.padded_dim, 2)) if pairs else (torch.float32, (lay.padded_dim,))
@@ -460,11 +489,18 @@ class AmpDiscriminator:
             combined = torch.empty((M, 1), **f32)
         ws = self._workspace(M)
         with torch.cuda.device(self.device):
-            nat.check(self._lib.amp_disc_style_reward_prescaled(self._handle, nat.dptr(scaled), M, self.reward_scale, nat.dptr(task),
-                                                                self.task_reward_weight, self.style_reward_weight,
-                                                                nat.dptr(logits), nat.dptr(style), nat.dptr(combined),
-                                                                nat.dptr(ws), nat.stream_ptr()),
-                      "amp_disc_style_reward_prescaled")
+            if compact is not None:
+                c = compact.compact_args()
+                nat.check(self._lib.amp_disc_style_reward_prescaled_compact(
+                    self._handle, nat.dptr(scaled), M, self.reward_scale, nat.dptr(task), self.task_reward_weight,
+                    self.style_reward_weight, nat.dptr(logits), nat.dptr(style), nat.dptr(combined), nat.dptr(ws), C.byref(c),
+                    nat.stream_ptr()), "amp_disc_style_reward_prescaled_compact")
+            else:
+                nat.check(self._lib.amp_disc_style_reward_prescaled(self._handle, nat.dptr(scaled), M, self.reward_scale, nat.dptr(task),
+                                                                    self.task_reward_weight, self.style_reward_weight,
+                                                                    nat.dptr(logits), nat.dptr(style), nat.dptr(combined),
+                                                                    nat.dptr(ws), nat.stream_ptr()),
+                          "amp_disc_style_reward_prescaled")
         out = {"style": style}
         if combined is not None:
             out["combined"] = combined

@@ -86,7 +86,8 @@ class HotPath:
 
     def __init__(self, spec: WorkloadSpec, num_envs: int, device, seed: int = 0, log_reward_terms: bool = False,
                  overlap: bool = False, fused_scaler: bool = True, disc_precision: str = "f16x3",
-                 expert_stream: bool = False, fused_expert: bool = True, state: dict | None = None, state_sets: int = 1):
+                 expert_stream: bool = False, fused_expert: bool = True, state: dict | None = None, state_sets: int = 1,
+                 fused_tail: bool = True, one_call: bool = True):
         """``state``: use this synthetic state (a ``make_state`` dict on the device, e.g. a row block of a larger
         shard's state) instead of drawing one from ``seed``.  ``state_sets`` > 1: that many independently drawn input
         sets (seeds ``seed + 7919 i``), visited round-robin by successive steps, so that a benchmark's state reads are
@@ -109,6 +110,9 @@ class HotPath:
         the 12 us kernel) -> default off."""
         self.spec, self.num_envs = spec, int(num_envs)
         self.overlap = bool(overlap)
+        self.fused_tail = bool(fused_tail)  # compaction + finalize as one launch (amp_disc_style_reward_prescaled_compact)
+        self.one_call = bool(one_call)      # the whole step as one amp_hot_step call on prebuilt arguments (outputs are
+        #                                     then two fixed [N, 1] tensors, overwritten by the next step)
         self.fused_scaler = bool(fused_scaler) and not self.overlap  # the overlapped schedule needs the snapshot pass
         self.device = nat.require_gpu(device)
         files = ",".join(os.path.join(MOTIONS_DIR, c + ".npz") for c in spec.clips)
@@ -154,6 +158,7 @@ class HotPath:
         self.last = None
         self._n = 0
         self.fused_expert = bool(fused_expert) and not expert_stream
+        self._hot_args = None
         self._expert_stream = None
         if expert_stream:
             self._expert_stream = torch.cuda.Stream(device=self.device)
@@ -179,10 +184,51 @@ class HotPath:
             return self.last
         return self._eager_step()
 
+    def _build_hot_args(self):
+        """One prebuilt ``AmpHotStepArgs`` per input set: the whole step becomes ONE call across the C ABI
+        (``amp_hot_step``), with nothing marshalled per step -- on small shards the four separate calls of the generic
+        path cost the host more (~90 us) than the step costs the GPU (~64 us at 8 192 envs)."""
+        import ctypes as C
+
+        k, N, K = self.kernel, self.num_envs, self.spec.K
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self._hot_out = {"style": torch.empty((N, 1), **f32), "combined": torch.empty((N, 1), **f32)}
+        ws = self.disc._workspace(N)
+        self._hot_keep = []  # ctypes structs referenced by pointer from the args
+        args = []
+        for st, sim in zip(self.states, self._sims):
+            s = k.sim_state(key_body_indexes=[0, 1, 2, 3], **sim)
+            b, c = k._buffers(), k.compact_args()
+            k.check_reference(st["motion_times"], st["motion_ids"], self.expert_obs)
+            a = nat.AmpHotStepArgs()
+            a.cfg, a.state, a.bufs = C.addressof(k._c), C.addressof(s), C.addressof(b)
+            a.num_envs = N
+            a.motion = self.motion._handle.value if hasattr(self.motion._handle, "value") else self.motion._handle
+            a.times, a.motion_ids = st["motion_times"].data_ptr(), st["motion_ids"].data_ptr()
+            a.n_samples, a.K, a.expert_out = N, K, self.expert_obs.data_ptr()
+            a.disc = self.disc._handle.value
+            a.reward_scale, a.task_weight, a.style_weight = self.disc.reward_scale, self.disc.task_reward_weight, self.disc.style_reward_weight
+            a.logits, a.style, a.combined = None, self._hot_out["style"].data_ptr(), self._hot_out["combined"].data_ptr()
+            a.workspace, a.compact = ws.data_ptr(), C.addressof(c)
+            self._hot_keep.append((s, b, c))
+            args.append(a)
+        self._hot_args = args
+        self._hot_lib = nat.load()
+
     def _eager_step(self, which: int | None = None):
         i = (self._n if which is None else which) % len(self.states)
         s, k = self.states[i], self.kernel
         self.state, self._sim = s, self._sims[i]
+        if self.one_call and self.fused_scaler and self.fused_tail and self.fused_expert and not self.overlap:
+            import ctypes as C
+
+            if self._hot_args is None:
+                self._build_hot_args()
+            with torch.cuda.device(self.device):
+                nat.check(self._hot_lib.amp_hot_step(C.byref(self._hot_args[i]), nat.stream_ptr()), "amp_hot_step")
+            self._n += 1
+            self.last = self._hot_out
+            return self.last
         env_stream = torch.cuda.current_stream(self.device)
         if self.overlap and self._n > 0:
             # the previous discriminator call must have read amp_obs / reward before this step shifts / rewrites them
@@ -199,10 +245,13 @@ class HotPath:
                 self.motion.collect_reference(s["motion_times"], s["motion_ids"], self.spec.K, out=self.expert_obs)
                 self._join.record(self._expert_stream)
         k.launch(nat.AMP_PHASE_ALL, key_body_indexes=[0, 1, 2, 3], reference=reference, **self._sim)
-        k.compact_resets()
         amp = k.amp_observation_buffer.view(self.num_envs, -1)
+        tail = self.fused_scaler and self.fused_tail
+        if not tail:
+            k.compact_resets()
         if self.fused_scaler:
-            self.last = self.disc.style_reward_prescaled(k.disc_input, k.reward)
+            # fused tail: the reset-id compaction rides on the finalize launch (one launch fewer; same results)
+            self.last = self.disc.style_reward_prescaled(k.disc_input, k.reward, compact=k if tail else None)
         elif not self.overlap:
             self.last = self.disc.style_reward(amp, k.reward)
         else:

@@ -353,6 +353,52 @@ int amp_disc_style_reward_prescaled(const AmpDisc* h, const void* scaled_dev, in
                                     float* logits_dev, float* style_dev, float* combined_dev, void* workspace_dev,
                                     amp_stream_t stream);
 
+/* amp_disc_style_reward_prescaled + amp_reset_compact_tiles with ONE tail launch: the reset-id compaction (independent of
+ * the GEMMs) rides on the workgroups of the finalize launch instead of paying its own ~6 us launch -- what matters on the
+ * 8 192-env shards of the multi-GPU configurations, where the step is a chain of latency-bound launches.  Results are
+ * bit-identical to the two separate calls; ids / count become valid when this call's work completes. */
+typedef struct {
+  const uint8_t* mask;         /* dev [num_envs] reset mask (AmpEnvBuffers.reset_mask) */
+  const int32_t* tile_counts;  /* dev: AmpEnvBuffers.reset_tile_counts of the same step */
+  int32_t tile_envs;           /* amp_env_step_tile_envs(num_envs) */
+  int32_t reserved;
+  int64_t num_envs;
+  int64_t* ids;                /* dev [num_envs] out, ascending */
+  int64_t* count;              /* dev [1] out */
+} AmpCompactArgs;
+int amp_disc_style_reward_prescaled_compact(const AmpDisc* h, const void* scaled_dev, int64_t rows, float reward_scale,
+                                            const float* task_reward_dev, float task_weight, float style_weight,
+                                            float* logits_dev, float* style_dev, float* combined_dev, void* workspace_dev,
+                                            const AmpCompactArgs* compact, amp_stream_t stream);
+
+/* One env-step of the hot path (motion sample + sim AMP obs / history / policy obs + dones + reset ids +
+ * task reward + style reward) issued by ONE call: amp_env_step_with_reference(all phases) followed by
+ * amp_disc_style_reward_prescaled_compact on bufs->disc_input / bufs->reward.  Same launches, same results; it exists
+ * because four separately marshalled calls cost the host more than a small shard's step costs the GPU.  Every pointer
+ * is borrowed for the duration of the enqueue; motion == NULL skips the expert-motion sample. */
+typedef struct {
+  const AmpEnvCfg* cfg;
+  const AmpSimState* state;
+  const AmpEnvBuffers* bufs;    /* needs disc_input (fused scaler, amp_disc_input_layout of `disc`) and reward */
+  int64_t num_envs;
+  const AmpMotion* motion;      /* expert-motion sample of the step, or NULL */
+  const double* times;          /* dev [n_samples] */
+  const int64_t* motion_ids;    /* dev [n_samples] or NULL */
+  int64_t n_samples;
+  int32_t K;
+  int32_t reserved;
+  float* expert_out;            /* dev [n_samples, K * D] */
+  const AmpDisc* disc;
+  float reward_scale, task_weight, style_weight;
+  int32_t reserved2;
+  float* logits;                /* dev [num_envs] or NULL */
+  float* style;                 /* dev [num_envs] or NULL */
+  float* combined;              /* dev [num_envs] or NULL */
+  void* workspace;              /* amp_disc_workspace_bytes(disc, num_envs) */
+  const AmpCompactArgs* compact;
+} AmpHotStepArgs;
+int amp_hot_step(const AmpHotStepArgs* args, amp_stream_t stream);
+
 /* Current weights in torch.nn.Linear layout (W1 [h1, in_dim], ... , W3 [1, h2]) into caller-owned device buffers. */
 int amp_disc_get_weights(const AmpDisc* h, float* w1_dev, float* b1_dev, float* w2_dev, float* b2_dev, float* w3_dev,
                          float* b3_dev, amp_stream_t stream);

@@ -56,4 +56,3 @@ def test_default_shards_are_the_baseline_configs():
                  for r in range(world)}
         assert sizes == {8192}
     assert bench.BASELINE_CONFIG[("g1_walk", 65536, 8)] == "configs[4]" and bench.BASELINE_CONFIG[("humanoid3", 32768, 4)] == "configs[3]"
-    assert bench.GRAPH_MAX_ENVS >= 8192

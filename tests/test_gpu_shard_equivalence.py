@@ -107,3 +107,28 @@ def test_device_reset_and_commands_are_shard_invariant():
         parts = [reset(*shard_bounds(N, world, r)) for r in range(world)]
         for key in whole:
             assert torch.equal(torch.cat([p[key] for p in parts]), whole[key]), (world, key)
+
+
+@pytest.mark.parametrize("envs", [1000, 8192, 12288, 20000, 40000])
+def test_fused_tail_and_every_kernel_plan_agree(envs):
+    """(a) amp_disc_style_reward_prescaled_compact (compaction riding on the finalize launch) == the two separate
+    launches, bit for bit; (b) the kernel plans a shard size selects (register-staged 64 x 64, LDS-DMA 128 x 128,
+    256 x 256 + 256 x 128, 256 x 256 in one or two chunks) give the same style rewards as the fp32-MFMA engine to
+    1e-6 and -- through test_shards_concatenate_to_the_whole -- the same bits as each other."""
+    import contextlib, io
+
+    from humanoid_amp_amd.workloads import WORKLOADS, HotPath
+
+    spec = WORKLOADS["g1_walk"]
+    outs = {}
+    for name, kw in (("fused", dict(fused_tail=True)), ("separate", dict(fused_tail=False)), ("f32", dict(disc_precision="f32"))):
+        with contextlib.redirect_stdout(io.StringIO()):
+            hot = HotPath(spec, envs, "cuda:0", seed=5, **kw)
+        o = hot.step()
+        o = hot.step()
+        n = int(hot.kernel.reset_count.item())
+        outs[name] = (o["style"].clone(), o["combined"].clone(), hot.kernel.reset_ids[:n].clone())
+    for a, b in zip(outs["fused"], outs["separate"]):
+        assert torch.equal(a, b)
+    assert len(outs["fused"][2]) > 0 and torch.equal(outs["fused"][2], outs["f32"][2])
+    assert float((outs["fused"][0] - outs["f32"][0]).abs().max()) <= 2e-6

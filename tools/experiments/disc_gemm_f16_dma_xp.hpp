@@ -1,82 +1,19 @@
-// GEMMs of the fp16-split discriminator forward for large shards: the same arithmetic, in the same order, as
-// disc_gemm_f16_kernel (three v_mfma_f32_32x32x16_f16 per k-step into one fp32 accumulator, transposed accumulator
-// tile; MODE 0: bias + ReLU -> fp16 planes of the hidden layer, activations read as (p0, p1) pairs; MODE 1: bias +
-// ReLU + dot(w3) -> partial logits), rebuilt around what bounds them on MI355X -- the operand fill path:
-//
-//   * measured with a fill-only probe (tools/gemm_f16_bench.hip, FILL=1: the kernel's DMA pattern, no compute): LDS-DMA
-//     pieces that take 32 B from each row move 6.9 TB/s chip-wide, 64 B 11.9 TB/s, a whole 128-B line 17.1 TB/s.  A
-//     256 x 256 tile needs 1.07 GB of fills per 65 536-row launch: 154 us with 32-B row segments (= the whole kernel),
-//     63 us with full lines.
-//   * so every operand is stored in BLOCK layout: row r, k-block kb (32 values) = 128 contiguous bytes holding both
-//     planes, [p0: 32 halves][p1: 32 halves] (the (p0, p1)-pair layout of the scaled input is the same 128 B per 32
-//     values).  One LDS-DMA piece = 8 rows x 128 B = 1 KiB, full cache lines only.
-//   * 256 x 256 workgroup tile, 512 threads = 8 waves as 2 (rows) x 4 (columns), each wave 128 x 64 = 4 x 2
-//     accumulator blocks; one workgroup per CU, two waves per SIMD.
-//   * stage = 2 k-steps (one k-block) of both operands = 2 x 256 rows x 128 B = 64 KB; two stages (128 KB).
-//   * a piece lands lane-linearly (wave-uniform base + 16 B x lane), so rows cannot be padded: the 16-B chunk c of row
-//     r sits at chunk c ^ ((r >> 1) & 7) -- applied to the per-lane SOURCE address of the fill and to the fragment
-//     reads alike -- which spreads the 16 lanes of a ds_read_b128 group over the 16 slots of a bank row.
-//   * every k-step is a LOAD segment (12 ds_read_b128 of fragments; MODE 0: + 32 v_perm_b32) followed by a MATRIX
-//     segment (24 MFMAs at s_setprio 1) bracketed by two barriers; the two wave groups (waves 0-3 / 4-7: one wave of
-//     each per SIMD) run the sequence one barrier apart, so a SIMD's matrix pipe alternates between its two waves.
-//
-// Fill schedule (interval = one barrier-to-barrier slot; group 0 runs k-block q in intervals 4q..4q+3 as R0 M0 R1 M1,
-// group 1 one interval later).  Stage (q + 1) & 1 holds k-block q - 1, last read in interval 4q - 1 (group 1's R1).
-//   group 0 fills the ACTIVATION half (from the Infinity Cache / HBM): its 8 pieces of k-block q + 1 are issued in
-//           R0(q) (interval 4q) and awaited (vmcnt(0)) behind the MFMAs of M1(q) (interval 4q + 3);
-//   group 1 fills the WEIGHT half (L2-resident): its 8 pieces are issued in its R0(q) (interval 4q + 1) and awaited at
-//           the end of its R1(q) (interval 4q + 3).
-// Both waits sit in front of the barrier that ends interval 4q + 3, which every reader passes before the first read of
-// k-block q + 1 (interval 4q + 4): the LDS-DMA visibility rule of MI355X_MICROARCH.md (counted wait of the ISSUING wave
-// + a barrier the reader has passed).  Every refill is issued behind a barrier that follows the lgkmcnt(0) of the
-// stage's last reads.  The slow operand has three intervals (>= 2 400 cycles) to land, the L2-warm one two.
+// ABLATION COPY of csrc/disc_gemm_f16_dma.hpp's kernel for tools/gemm_f16_bench.hip -- NOT part of the product library.
+// XP != 0 variants produce wrong results on purpose (1 = no fills in the loop, 2 = also no fragment reads, 3 = MODE 0
+// without the epilogue's global stores, 4 = MODE 0 epilogue only) or a different schedule (5 = free-running waves, one
+// barrier per k-block: correct results).  XP = 0 is the product schedule.
 #pragma once
-#include "disc_gemm_f16.hpp"
+#include "disc_gemm_f16_dma.hpp"  // product kernel, DmaTile, split_rows_blocks_kernel, pointer typedefs
 
 namespace amp {
 
-constexpr int kDmaThreads = 512, kDmaBM = 256, kDmaBN = 256;  // the default tile (TM = 4, TN = 2)
-constexpr int kDmaKB = 32;                                  // values per k-block = 2 k-steps
-constexpr int kDmaLdsBytes = 2 * (kDmaBM + kDmaBN) * 128;   // 128 KB: two stages of both operands
-// Tile geometry: 8 waves as 2 (rows) x 4 (columns), each wave (32 TM) x (32 TN); workgroup tile (64 TM) x (128 TN).
-template <int TM, int TN>
-struct DmaTile {
-  static constexpr int BM = 64 * TM, BN = 128 * TN;
-  static constexpr int kA = BM * 128, kB = BN * 128;          // bytes of one operand in a stage
-  static constexpr int kStage = kA + kB;
-  static constexpr int kLds = 2 * kStage;
-  static constexpr int kWgPerCu = kLds <= 80 * 1024 ? 2 : 1;
-};
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-// planes of scale[0] * src[rows, cols] (row pitch ld_src floats) -> block layout dst[rows][kp / 32][2][32] halves;
-// columns in [cols, kp) are zero.  One thread per four columns.
-__global__ __launch_bounds__(kBlock) void split_rows_blocks_kernel(const float* __restrict__ src, int64_t rows, int cols,
-                                                                   int64_t ld_src, const float* __restrict__ scale,
-                                                                   _Float16* __restrict__ dst, int kp) {
-  const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x, per_row = kp / 4;
-  if (q >= rows * per_row) return;
-  const int64_t r = q / per_row;
-  const int c = (int)(q - r * per_row) * 4;
-  const float s = scale[0];
-  fv4 v;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] = c + i < cols ? src[r * ld_src + c + i] * s : 0.0f;
-  h4 p0, p1;
-  split_planes4(v, p0, p1);
-  _Float16* blk = dst + r * (2 * (int64_t)kp) + (c >> 5) * 64 + (c & 31);
-  *reinterpret_cast<h4*>(blk) = p0;
-  *reinterpret_cast<h4*>(blk + 32) = p1;
-}
-
 // Args: A = activations, row pitch 2 * lda halves (MODE 0: lda pairs per row; MODE 1: block layout of lda values);
 // W = weights in block layout, row pitch 2 * Kp halves; MODE 0 output H in block layout, row pitch 2 * ldh halves.
-// (Ablated variants of this kernel -- no fills, no fragment reads, no stores, free-running waves -- live in
-// tools/experiments/disc_gemm_f16_dma_xp.hpp for tools/gemm_f16_bench.hip; the product kernel carries none.)
-template <int MODE, int TM = 4, int TN = 2>
-__global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN>::kWgPerCu)) void disc_gemm_f16_dma_kernel(GemmF16Args g) {
+// XP != 0: ablations for tools/gemm_f16_bench.hip (wrong results): 1 = no fills in the loop, 2 = also no fragment reads,
+// 3 = MODE 0 without the global stores of the epilogue, 4 = MODE 0 epilogue only (one k-block), 5 = no ping-pong (free-running
+// waves, one barrier per k-block; correct results: 106 us against 80 us at 32 768 rows of layer 2)
+template <int MODE, int XP = 0, int TM = 4, int TN = 2>
+__global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN>::kWgPerCu)) void disc_gemm_f16_dma_xp_kernel(GemmF16Args g) {
   using T = DmaTile<TM, TN>;
   constexpr int BM = T::BM, BN = T::BN, kOpA = T::kA, kStage = T::kStage;
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
@@ -88,7 +25,7 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN>::kWgPerCu)) void disc
   const int grp = wave >> 2;
   const int64_t m0 = (int64_t)mt * BM;
   const int n0 = nt * BN;
-  const int nq = g.Kp / kDmaKB;  // k-blocks
+  const int nq = XP == 4 ? 1 : g.Kp / kDmaKB;  // k-blocks
 
   // ---- fill plan: a piece is 8 rows x 128 B.  Group 0's wave w fills a quarter of the activation rows, group 1's
   // wave 4 + w a quarter of the weight rows: NP pieces each.  lane l: row 8 j + (l >> 3) of the wave's quarter, stored
@@ -205,22 +142,57 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN>::kWgPerCu)) void disc
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();  // k-block 0 is visible to every wave
+  if (XP == 5) {
+    // ablation / experiment: no ping-pong -- every wave runs reads -> MFMAs -> reads -> MFMAs freely, ONE barrier per k-block
+    auto mfmas = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[b], x1[a], acc[a][b], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[b], x0[a], acc[a][b], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[b], x0[a], acc[a][b], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int q = 0; q < nq; ++q) {
+      const unsigned char* sb = lds + (q & 1) * kStage;
+      if (q >= 1 && q + 1 < nq) fill(q + 1, (q + 1) & 1);  // its last reads were retired in front of the barrier below
+      read_frags(sb, 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      mfmas();
+      read_frags(sb, 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      mfmas();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
   if (grp == 1) __builtin_amdgcn_s_barrier();
   for (int q = 0; q < nq; ++q) {
     const unsigned char* sb = lds + (q & 1) * kStage;
     // R0: fragments of k-step 0; the other stage (k-block q - 1: its last reads were retired in front of a barrier
     // this wave has passed) takes k-block q + 1 (k-block 1 was issued in the prologue)
-    read_frags(sb, 0);
-    if (q >= 1 && q + 1 < nq) fill(q + 1, (q + 1) & 1);
+    if (XP < 2 || q == 0) read_frags(sb, 0);
+    if (XP == 0 && q >= 1 && q + 1 < nq) fill(q + 1, (q + 1) & 1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     matrix_segment(false);
     // R1: fragments of k-step 1; group 1's pieces of k-block q + 1 must have landed before the next barrier
-    read_frags(sb, 1);
+    if (XP < 2 || q == 0) read_frags(sb, 1);
     if (grp == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     matrix_segment(grp == 0);  // group 0's pieces: behind its MFMAs
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
+  }
   __syncthreads();  // every wave is done with the stages: the scratch below reuses them
 
   // ---- epilogue: register r of lane half lh is output column (r & 3) + 8 (r >> 2) + 4 lh of the 32-wide block,
@@ -261,7 +233,7 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN>::kWgPerCu)) void disc
         const int idx = lane + 64 * i, row = idx / CPR, ch = idx % CPR, b = ch >> 3, pl = (ch >> 2) & 1, qq = ch & 3;
         const h8 v = *reinterpret_cast<const h8*>(&ep[pl * 32 * EPL + row * EPL + b * 32 + 8 * qq]);
         const int64_t grow = m0 + wm * (32 * TM) + a * 32 + row;
-        if (grow < g.M)
+        if (grow < g.M && (XP != 3 || v[0] == (_Float16)12345.0f))
           *reinterpret_cast<h8*>(&g.H[grow * (2 * g.ldh) + (int64_t)((n0 + wn * CW) >> 5) * 64 + 8 * ch]) = v;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -8,7 +8,8 @@
 #include <algorithm>
 #include <vector>
 
-#include "disc_gemm_f16_dma.hpp"
+#include "../tools/experiments/disc_gemm_f16_dma4.hpp"
+#include "../tools/experiments/disc_gemm_f16_dma_xp.hpp"
 
 using namespace amp;
 
@@ -152,13 +153,14 @@ static void calib(float* out, int blocks_per_cu, int iters) {
 
 static double g_us = 0;
 
-template <int TM, int TN, int BK, int MODE, int MW, int PF = 1, int XP = 0>
+template <int TM, int TN, int BK, int MODE, int MW>
 static void run(GemmF16Args g, int64_t M, int N, int K, bool quiet) {
+  constexpr int PF = 1;
   g.n_tiles = N / (64 * TN);
   g.m_tiles = (int)((M + 64 * TM - 1) / (64 * TM));
   const unsigned grid = (unsigned)(((int64_t)g.m_tiles * g.n_tiles + 7) / 8 * 8);
   constexpr int lds = gemm_f16_lds_bytes<TM, TN, BK>();
-  auto kern = disc_gemm_f16_kernel<TM, TN, BK, MODE, MW, PF, XP>;
+  auto kern = disc_gemm_f16_kernel<TM, TN, BK, MODE, MW>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   hipEvent_t a, b;
   CK(hipEventCreate(&a));
@@ -195,15 +197,16 @@ static void run_dma(GemmF16Args g, int64_t M, int N, int K, bool quiet) {
   g.n_tiles = N / T::BN;
   g.m_tiles = (int)((M + T::BM - 1) / T::BM);
   const unsigned grid = (unsigned)(((int64_t)g.m_tiles * g.n_tiles + 7) / 8 * 8);
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gemm_f16_dma_kernel<MODE, XP, TM, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, T::kLds));
+  auto kern = disc_gemm_f16_dma_xp_kernel<MODE, XP, TM, TN>;  // XP = 0 is the product schedule (tools/experiments copy)
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, T::kLds));
   hipEvent_t a, b;
   CK(hipEventCreate(&a));
   CK(hipEventCreate(&b));
-  for (int i = 0; i < 3; ++i) disc_gemm_f16_dma_kernel<MODE, XP, TM, TN><<<grid, kDmaThreads, T::kLds>>>(g);
+  for (int i = 0; i < 3; ++i) kern<<<grid, kDmaThreads, T::kLds>>>(g);
   CK(hipDeviceSynchronize());
   const int reps = 10;
   CK(hipEventRecord(a));
-  for (int i = 0; i < reps; ++i) disc_gemm_f16_dma_kernel<MODE, XP, TM, TN><<<grid, kDmaThreads, T::kLds>>>(g);
+  for (int i = 0; i < reps; ++i) kern<<<grid, kDmaThreads, T::kLds>>>(g);
   CK(hipEventRecord(b));
   CK(hipEventSynchronize(b));
   float ms;
@@ -212,6 +215,37 @@ static void run_dma(GemmF16Args g, int64_t M, int N, int K, bool quiet) {
   if (!quiet) {
     const double tf = 2.0 * M * N * K / (g_us * 1e-6) / 1e12;
     printf("LDS-DMA %3dx%3dx32 blocks, 2 stages, 512 thr            %8.1f us   %6.1f TF(alg)  %.3f of fp16 peak executed\n", T::BM, T::BN, g_us, tf,
+           3 * tf / 2516.6);
+    fflush(stdout);
+  }
+}
+
+template <int MODE, int NA, int NW>
+static void run_dma4(GemmF16Args g, int64_t M, int N, int K, bool quiet) {
+  if (MODE == 1) g.A = g_Ab;  // block layout; MODE 0 reads the (p0, p1) pairs as they are
+  g.W = g_Wb;
+  g_dma_last = true;
+  g.n_tiles = N / kDma4BN;
+  g.m_tiles = (int)((M + kDma4BM - 1) / kDma4BM);
+  const unsigned grid = (unsigned)(((int64_t)g.m_tiles * g.n_tiles + 7) / 8 * 8);
+  constexpr int lds = dma4_lds_bytes<NA, NW>();
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gemm_f16_dma4_kernel<MODE, NA, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a));
+  CK(hipEventCreate(&b));
+  for (int i = 0; i < 3; ++i) disc_gemm_f16_dma4_kernel<MODE, NA, NW><<<grid, kDma4Threads, lds>>>(g);
+  CK(hipDeviceSynchronize());
+  const int reps = 10;
+  CK(hipEventRecord(a));
+  for (int i = 0; i < reps; ++i) disc_gemm_f16_dma4_kernel<MODE, NA, NW><<<grid, kDma4Threads, lds>>>(g);
+  CK(hipEventRecord(b));
+  CK(hipEventSynchronize(b));
+  float ms;
+  CK(hipEventElapsedTime(&ms, a, b));
+  g_us = ms * 1e3 / reps;
+  if (!quiet) {
+    const double tf = 2.0 * M * N * K / (g_us * 1e-6) / 1e12;
+    printf("LDS-DMA4 128x128x32 blocks, %d + %d stages, 256 thr (4 waves of 64x64) %8.1f us   %6.1f TF(alg)  %.3f of fp16 peak executed\n", NA, NW, g_us, tf,
            3 * tf / 2516.6);
     fflush(stdout);
   }
@@ -276,6 +310,7 @@ int main(int argc, char** argv) {
 
   g_Ab = Ab; g_Wb = Wb;
   auto check = [&](int n_tiles) {
+    if (mode == 1) n_tiles = N / 32;  // canonical partial logits: one per (row, 32-column block), whatever the tile
     const bool blocks = g_dma_last;
     g_dma_last = false;
     const int rows = 64;
@@ -332,8 +367,8 @@ int main(int argc, char** argv) {
 
 #define V(TM, TN, BK, MW, PF)                                        \
   do {                                                               \
-    if (mode == 1) run<TM, TN, BK, 1, MW, PF>(g, M, N, K, quiet);    \
-    else run<TM, TN, BK, 0, MW, PF>(g, M, N, K, quiet);              \
+    if (PF == 1 && mode == 1) run<TM, TN, BK, 1, MW>(g, M, N, K, quiet);    \
+    else if (PF == 1) run<TM, TN, BK, 0, MW>(g, M, N, K, quiet);     \
   } while (0)
   bool quiet = false;
   if (getenv("CALIB")) {
@@ -392,6 +427,39 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
+  if (getenv("DMA4")) {
+    for (int rep = 0; rep < 3; ++rep) {
+      if (mode == 0) {
+        run_dma4<0, 3, 3>(g, M, N, K, false); check(0);
+        run_dma4<0, 5, 3>(g, M, N, K, false); check(0);
+        run_dma4<0, 6, 3>(g, M, N, K, false); check(0);
+        run_dma4<0, 4, 4>(g, M, N, K, false); check(0);
+        run_dma<0, 0, 2, 1>(g, M, N, K, false); check(0);
+      } else {
+        run_dma4<1, 3, 3>(g, M, N, K, false); check(0);
+        run_dma4<1, 5, 3>(g, M, N, K, false); check(0);
+        run_dma4<1, 6, 3>(g, M, N, K, false); check(0);
+        run_dma4<1, 4, 4>(g, M, N, K, false); check(0);
+        run_dma<1, 0, 2, 1>(g, M, N, K, false); check(0);
+      }
+    }
+    return 0;
+  }
+  if (getenv("FREE")) {  // free-running waves (XP = 5: one barrier per k-block, no ping-pong) on the small tiles
+    for (int rep = 0; rep < 2; ++rep) {
+      if (mode == 0) {
+        run_dma<0, 5, 2, 1>(g, M, N, K, false); check(N / 128);
+        run_dma<0, 5, 1, 1>(g, M, N, K, false); check(N / 128);
+        run_dma<0, 5, 2, 2>(g, M, N, K, false); check(N / 256);
+      } else {
+        run_dma<1, 5, 2, 1>(g, M, N, K, false); check(N / 128);
+        run_dma<1, 5, 1, 1>(g, M, N, K, false); check(N / 128);
+        run_dma<1, 5, 2, 2>(g, M, N, K, false); check(N / 256);
+        run_dma<1, 5, 4, 1>(g, M, N, K, false); check(N / 128);
+      }
+    }
+    return 0;
+  }
   if (getenv("TILES")) {
     for (int rep = 0; rep < 3; ++rep) {
       if (mode == 0) {
@@ -399,11 +467,13 @@ int main(int argc, char** argv) {
         run_dma<0, 0, 2, 2>(g, M, N, K, false); check(N / 256);
         run_dma<0, 0, 2, 1>(g, M, N, K, false); check(N / 128);
         run_dma<0, 0, 4, 1>(g, M, N, K, false); check(N / 128);
+        run_dma<0, 0, 1, 1>(g, M, N, K, false); check(N / 128);
       } else {
         run_dma<1, 0, 4, 2>(g, M, N, K, false); check(N / 256);
         run_dma<1, 0, 2, 2>(g, M, N, K, false); check(N / 256);
         run_dma<1, 0, 2, 1>(g, M, N, K, false); check(N / 128);
         run_dma<1, 0, 4, 1>(g, M, N, K, false); check(N / 128);
+        run_dma<1, 0, 1, 1>(g, M, N, K, false); check(N / 128);
       }
     }
     return 0;
@@ -420,13 +490,6 @@ int main(int argc, char** argv) {
     return 0;
   }
   if (getenv("XP") && mode == 1) {
-    printf("experiments on 128x128x64 w2 (wrong results by construction):\n");
-    run<2, 2, 64, 1, 2, 1, 0>(g, M, N, K, false);
-    printf("  ^ full kernel\n");
-    run<2, 2, 64, 1, 2, 1, 1>(g, M, N, K, false);
-    printf("  ^ no global loads / LDS writes (barriers kept)\n");
-    run<2, 2, 64, 1, 2, 1, 2>(g, M, N, K, false);
-    printf("  ^ no global loads / LDS writes / barriers: ds_read + MFMA only\n");
     run_dma<1, 5>(g, M, N, K, false); check(N / 256);
     puts("  ^ no ping-pong: free-running waves, one barrier per k-block");
     run_dma<1, 0>(g, M, N, K, false);
