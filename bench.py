@@ -331,6 +331,11 @@ def main():
     per_kernel = {k: round(t / 16 * 1e3, 2) for k, (c, t) in tr_all.summary().items()}  # us per step (all launches of the kernel)
 
     out = None
+    sustained = None
+    if rank == 0 and args.disc_precision == "f16x3":
+        # what the matrix pipes of THIS device sustain on a bare fp16 MFMA stream (amp_calibrate_mfma_f16): MI355X is power-
+        # limited, and on operands that change from one MFMA to the next the figure is well below the nominal peak
+        sustained = {"constant_operands": nat.calibrate_mfma_f16(False, 256, device), "random_operands": nat.calibrate_mfma_f16(True, 256, device)}
     if rank == 0:
         # HBM traffic of the dominant kernel: PMC FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE per launch, collected
         # in separate rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh) and committed: STATIC
@@ -386,7 +391,10 @@ def main():
                          "avg_launch_ms": gemm2_ms, "launches_timed": len(recs), "launches_per_step": per_step, "timing": timing,
                          "rows_per_launch": envs // per_step, "flops_per_launch": flops2,
                          "mfma_products_per_flop": nprod, "frac_executed": nprod * achieved / peak,
-                         "vs_fp32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS},
+                         "vs_fp32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS,
+                         # measured on this device in this process: a bare v_mfma_f32_32x32x16_f16 stream, one wave per SIMD
+                         "mfma_sustained_tflops": sustained,
+                         "frac_executed_of_sustained_random": (nprod * achieved / sustained["random_operands"]) if sustained else None},
             "roofline_hbm": {"bound": "hbm", "kernels": list(hbm_kernels), "achieved": alg_bytes / (hbm_us * 1e-6) / 1e9 if hbm_us else None,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (alg_bytes / (hbm_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if hbm_us else None,
                              "bytes_per_env_step": algorithmic_bytes_per_env_step(spec), "us": hbm_us,

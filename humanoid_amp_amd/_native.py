@@ -150,6 +150,7 @@ SIGNATURES = {
     "amp_trace_end": (C.c_int, []),
     "amp_trace_count": (_i64, []),
     "amp_trace_get": (C.c_int, [_i64, C.c_char_p, _i64, C.POINTER(C.c_float)]),
+    "amp_calibrate_mfma_f16": (C.c_int, [_i32, _i32, _vp, _i64, C.POINTER(C.c_double), _vp]),
     "amp_motion_create": (C.c_int, [C.POINTER(AmpMotionDesc), C.POINTER(_vp)]),
     "amp_motion_destroy": (C.c_int, [_vp]),
     "amp_motion_set_obs_layout": (C.c_int, [_vp, C.POINTER(_i32), _i32, C.POINTER(_i32), _i32, _vp]),
@@ -305,3 +306,22 @@ class KernelTrace:
             c, t = agg.get(name, (0, 0.0))
             agg[name] = (c + 1, t + ms)
         return agg
+
+
+
+def calibrate_mfma_f16(random_operands: bool, iters: int = 256, device="cuda:0", reps: int = 3) -> float:
+    """TFLOP/s the matrix pipes sustain on a bare fp16 MFMA stream (``amp_calibrate_mfma_f16``): the best of ``reps``
+    launches of ~``iters`` x 48 MFMAs per wave, timed by the engine's tracer."""
+    lib = load()
+    dev = require_gpu(device)
+    scratch = torch.empty(1024 * 256, dtype=torch.float32, device=dev)
+    flops = C.c_double()
+    best = 0.0
+    with torch.cuda.device(dev):
+        for _ in range(reps + 1):
+            with KernelTrace(capacity=4, kernel_filter="mfma_f16_calibration_kernel") as tr:
+                check(lib.amp_calibrate_mfma_f16(int(bool(random_operands)), int(iters), dptr(scratch), scratch.numel(), C.byref(flops),
+                                                 stream_ptr()), "amp_calibrate_mfma_f16")
+            ms = tr.records()[-1][1]
+            best = max(best, flops.value / (ms * 1e-3) / 1e12)
+    return best

@@ -8,7 +8,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["core.hip", "motion.hip", "env_step.hip", "compact.hip", "command.hip", "disc.hip", "disc_train.hip", "ring.hip", "convert.hip", "hot_step.hip"]
+SOURCES = ["core.hip", "motion.hip", "env_step.hip", "compact.hip", "command.hip", "disc.hip", "disc_train.hip", "ring.hip", "convert.hip", "hot_step.hip", "calibrate.hip"]
 
 
 

@@ -111,8 +111,7 @@ class HotPath:
         self.spec, self.num_envs = spec, int(num_envs)
         self.overlap = bool(overlap)
         self.fused_tail = bool(fused_tail)  # compaction + finalize as one launch (amp_disc_style_reward_prescaled_compact)
-        self.one_call = bool(one_call)      # the whole step as one amp_hot_step call on prebuilt arguments (outputs are
-        #                                     then two fixed [N, 1] tensors, overwritten by the next step)
+        self.one_call = bool(one_call)      # the whole step as one amp_hot_step call on prebuilt arguments
         self.fused_scaler = bool(fused_scaler) and not self.overlap  # the overlapped schedule needs the snapshot pass
         self.device = nat.require_gpu(device)
         files = ",".join(os.path.join(MOTIONS_DIR, c + ".npz") for c in spec.clips)
@@ -191,8 +190,6 @@ class HotPath:
         import ctypes as C
 
         k, N, K = self.kernel, self.num_envs, self.spec.K
-        f32 = dict(dtype=torch.float32, device=self.device)
-        self._hot_out = {"style": torch.empty((N, 1), **f32), "combined": torch.empty((N, 1), **f32)}
         ws = self.disc._workspace(N)
         self._hot_keep = []  # ctypes structs referenced by pointer from the args
         args = []
@@ -208,7 +205,7 @@ class HotPath:
             a.n_samples, a.K, a.expert_out = N, K, self.expert_obs.data_ptr()
             a.disc = self.disc._handle.value
             a.reward_scale, a.task_weight, a.style_weight = self.disc.reward_scale, self.disc.task_reward_weight, self.disc.style_reward_weight
-            a.logits, a.style, a.combined = None, self._hot_out["style"].data_ptr(), self._hot_out["combined"].data_ptr()
+            a.logits = None  # style / combined are set per step
             a.workspace, a.compact = ws.data_ptr(), C.addressof(c)
             self._hot_keep.append((s, b, c))
             args.append(a)
@@ -224,10 +221,15 @@ class HotPath:
 
             if self._hot_args is None:
                 self._build_hot_args()
+            a = self._hot_args[i]
+            # fresh [N, 1] outputs per step (a caller may keep earlier steps' results), everything else is prebuilt
+            style = torch.empty((self.num_envs, 1), dtype=torch.float32, device=self.device)
+            combined = torch.empty((self.num_envs, 1), dtype=torch.float32, device=self.device)
+            a.style, a.combined = style.data_ptr(), combined.data_ptr()
             with torch.cuda.device(self.device):
-                nat.check(self._hot_lib.amp_hot_step(C.byref(self._hot_args[i]), nat.stream_ptr()), "amp_hot_step")
+                nat.check(self._hot_lib.amp_hot_step(C.byref(a), nat.stream_ptr()), "amp_hot_step")
             self._n += 1
-            self.last = self._hot_out
+            self.last = {"style": style, "combined": combined}
             return self.last
         env_stream = torch.cuda.current_stream(self.device)
         if self.overlap and self._n > 0:

@@ -57,6 +57,14 @@ int64_t amp_trace_count(void);
 /* name and duration in milliseconds of record i; AMP_ERR_HIP if its events have not completed yet */
 int amp_trace_get(int64_t i, char* name_buf, int64_t name_len, float* ms);
 
+/* Measurement aid: one launch of a bare v_mfma_f32_32x32x16_f16 stream (one 4-wave workgroup per CU, 16 independent
+ * accumulators, iters x 48 MFMAs per wave) on constant (random_operands = 0) or changing full-entropy operands (1).
+ * *flops_out = FLOPs of the launch; time it with the tracer (kernel name "mfma_f16_calibration_kernel") or events.
+ * scratch_dev: >= 256 floats per CU.  What the result is for: MI355X is power-limited, the matrix pipes sustain 0.55-0.62
+ * of the nominal fp16 peak on changing operands -- the ceiling the discriminator GEMMs' roofline fraction is read against. */
+int amp_calibrate_mfma_f16(int32_t random_operands, int32_t iters, float* scratch_dev, int64_t scratch_floats,
+                           double* flops_out, amp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Motion table  (replaces MotionLoader.__init__, motions/motion_loader.py:98-164)
  * ------------------------------------------------------------------------------------------------ */

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../tools/experiments/disc_gemm_f16_dma4.hpp"
+#include "../tools/experiments/disc_gemm_f16_w4.hpp"
 #include "../tools/experiments/disc_gemm_f16_dma_xp.hpp"
 
 using namespace amp;
@@ -46,6 +47,64 @@ __global__ __launch_bounds__(256) void mfma_f16_only_kernel(float* out, int iter
 #pragma unroll
     for (int r = 0; r < 16; ++r) s += acc[i][r];
   out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+// Calibration 2: the same bare MFMA loop on operands that CHANGE from one MFMA to the next.  ENTROPY 0: eight register
+// sets holding the same small constants (what mfma_f16_only_kernel measures); 1: eight sets of full-entropy random fp16
+// values (what a GEMM on real data feeds the multipliers).  The matrix pipe's power -- and with it the clock the chip
+// sustains -- depends on how many multiplier inputs toggle between consecutive MFMAs.
+template <int ENTROPY>
+__global__ __launch_bounds__(256, 1) void mfma_f16_entropy_kernel(float* out, int iters) {
+  fx16 acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+  h8 a[8], b[8];
+  unsigned s = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (ENTROPY) {
+        s = s * 1664525u + 1013904223u;
+        a[k][i] = (_Float16)(((int)((s >> 9) & 0xFFFF) - 32768) * (1.0f / 32768.0f));
+        s = s * 1664525u + 1013904223u;
+        b[k][i] = (_Float16)(((int)((s >> 9) & 0xFFFF) - 32768) * (1.0f / 32768.0f));
+      } else {
+        a[k][i] = (_Float16)(0.5f);
+        b[k][i] = (_Float16)(0.25f);
+      }
+    }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 48; ++u)
+      acc[u & 15] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u & 7], b[(u * 3 + (u >> 3)) & 7], acc[u & 15], 0, 0, 0);
+  }
+  float t = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += acc[i][r];
+  out[blockIdx.x * 256 + threadIdx.x] = t;
+}
+template <int ENTROPY>
+static void calib_entropy(float* out, int iters) {
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a));
+  CK(hipEventCreate(&b));
+  mfma_f16_entropy_kernel<ENTROPY><<<256, 256>>>(out, iters);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(a));
+  mfma_f16_entropy_kernel<ENTROPY><<<256, 256>>>(out, iters);
+  CK(hipEventRecord(b));
+  CK(hipEventSynchronize(b));
+  float ms;
+  CK(hipEventElapsedTime(&ms, a, b));
+  const double flops = 256.0 * 4 * iters * 48 * 32768.0;
+  printf("fp16 MFMA only, 16 accumulators, one wave per SIMD, %s operands, %d x 48 MFMAs: %.1f us  %.1f TF  %.3f of the 2516.8 TF peak\n",
+         ENTROPY ? "RANDOM (8 rotating register sets)" : "constant", iters, ms * 1e3, flops / (ms * 1e-3) / 1e12,
+         flops / (ms * 1e-3) / 1e12 / 2516.8);
 }
 
 // Store-only floor of layer 1: every thread writes 16 B per plane the way the epilogue does (row segments of 128 B).
@@ -251,6 +310,35 @@ static void run_dma4(GemmF16Args g, int64_t M, int N, int K, bool quiet) {
   }
 }
 
+static void run_w4(GemmF16Args g, int64_t M, int N, int K, bool quiet) {
+  g.A = g_Ab;  // block layout
+  g.W = g_Wb;
+  g_dma_last = true;
+  g.n_tiles = N / kW4BN;
+  g.m_tiles = (int)((M + kW4BM - 1) / kW4BM);
+  const unsigned grid = (unsigned)(((int64_t)g.m_tiles * g.n_tiles + 7) / 8 * 8);
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gemm_f16_w4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kW4LdsBytes));
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a));
+  CK(hipEventCreate(&b));
+  for (int i = 0; i < 3; ++i) disc_gemm_f16_w4_kernel<<<grid, kW4Threads, kW4LdsBytes>>>(g);
+  CK(hipDeviceSynchronize());
+  const int reps = 10;
+  CK(hipEventRecord(a));
+  for (int i = 0; i < reps; ++i) disc_gemm_f16_w4_kernel<<<grid, kW4Threads, kW4LdsBytes>>>(g);
+  CK(hipEventRecord(b));
+  CK(hipEventSynchronize(b));
+  float ms;
+  CK(hipEventElapsedTime(&ms, a, b));
+  g_us = ms * 1e3 / reps;
+  if (!quiet) {
+    const double tf = 2.0 * M * N * K / (g_us * 1e-6) / 1e12;
+    printf("W4 256x256x32 blocks, 2 stages, 256 thr (4 waves of 128x128)  %8.1f us   %6.1f TF(alg)  %.3f of fp16 peak executed\n", g_us, tf,
+           3 * tf / 2516.6);
+    fflush(stdout);
+  }
+}
+
 int main(int argc, char** argv) {
   const int64_t M = argc > 1 ? atoll(argv[1]) : 65536;
   const int N = argc > 2 ? atoi(argv[2]) : 512;
@@ -371,7 +459,17 @@ int main(int argc, char** argv) {
     else if (PF == 1) run<TM, TN, BK, 0, MW>(g, M, N, K, quiet);     \
   } while (0)
   bool quiet = false;
+  if (getenv("ENTROPY")) {  // what the matrix pipe sustains on constant vs random operands, 50 us .. 1 ms bursts
+    for (int iters : {64, 256, 1024}) {
+      calib_entropy<0>((float*)Hp, iters);
+      calib_entropy<1>((float*)Hp, iters);
+    }
+    calib_entropy<0>((float*)Hp, 256);
+    calib_entropy<1>((float*)Hp, 256);
+    return 0;
+  }
   if (getenv("CALIB")) {
+    if (N != 1024) { puts("CALIB needs N = 1024 (the store probes write M x 1024 x 2 planes)"); return 1; }
     calib<4>((float*)Hp, 1, 512);    // ~50 us
     calib<4>((float*)Hp, 1, 2048);   // ~200 us
     calib<4>((float*)Hp, 2, 2048);
@@ -424,6 +522,17 @@ int main(int argc, char** argv) {
       V(2, 1, 32, 3, 1); check(N / 64);
       V(1, 2, 32, 3, 1); check(N / 128);
       V(2, 1, 64, 3, 1); check(N / 64);
+    }
+    return 0;
+  }
+  if (getenv("W4")) {
+    for (int rep = 0; rep < 3; ++rep) {
+      if (mode == 0) {
+        run_dma<0, 0, 4, 2>(g, M, N, K, false); check(0);
+      } else {
+        run_w4(g, M, N, K, false); check(0);
+        run_dma<1, 0, 4, 2>(g, M, N, K, false); check(0);
+      }
     }
     return 0;
   }
