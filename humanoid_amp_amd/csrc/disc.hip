@@ -419,6 +419,7 @@ static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* a
     g1.W = h->w1h; g1.plane_w = (int64_t)h->h1 * h->k1h; g1.Kp = h->k1h; g1.N = h->h1;
     g1.bias = h->b1; g1.range = h->range; g1.amax = amax; g1.layer = 1;
     g1.H = H1p + r0 * h->h1; g1.ldh = h->h1; g1.plane_h = rows * h->h1;
+    g1.ksteps = (h->in_dim + 15) / 16;  // k-steps beyond the true K hold zero padding in both operands: skipped
     if (dma) {
       g1.W = h->w1b;  // block layout; the hidden layer comes out in block layout too (row pitch 2 * h1)
       g1.H = H1p;     // every chunk reuses the SAME 134 MB: rewritten while still dirty in the Infinity Cache, the hidden

@@ -75,6 +75,10 @@ struct GemmF16Args {
   _Float16* H; int64_t ldh, plane_h;                            // mode 0 output planes
   const float* w3; float* partial;                              // mode 1 output [M, n_tiles]
   int32_t n_tiles, m_tiles;
+  // k-steps (of 16) that can hold non-zero values: ceil(true K / 16).  Kp pads K to the k-block (32) with zeros in BOTH
+  // operands; a k-step made of padding only adds exact zeros to every accumulator and is skipped (K = 166 -> 11 of 12
+  // k-steps: 8 % of layer 1's MFMAs).  0 = all of Kp / 16.
+  int32_t ksteps;
 };
 
 // rn16(v), rn16(v - rn16(v)) for four values
@@ -234,9 +238,11 @@ __global__ __launch_bounds__(kBlock, MINW) void disc_gemm_f16_kernel(GemmF16Args
   const _Float16* wb = smem + 2 * BM * LDK + (wn * TN * 32 + li) * LDK + 8 * lh;  // weight fragments, plane 0
   // hipcc orders the fragment reads itself (explicitly double-buffered fragment sets pinned with sched_barrier were
   // measured: +3 % on the bare ds_read + MFMA loop, spills at 3 workgroups / CU)
-  auto compute = [&]() {
+  const int ksteps = g.ksteps > 0 ? g.ksteps : g.Kp / 16;
+  auto compute = [&](const int kt) {
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
+      if (kt * (BK / 16) + s >= ksteps) break;  // zero padding only (workgroup-uniform)
       h8 x0[TM], x1[TM], w0[TN], w1[TN];
 #pragma unroll
       for (int a = 0; a < TM; ++a) {
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(kBlock, MINW) void disc_gemm_f16_kernel(GemmF16Args
     for (int kt = 0; kt < nk; ++kt) {
       if (kt + 1 < nk) stg.load(g, m0, n0, kt + 1, tid);  // in flight under this tile's MFMAs
       __builtin_amdgcn_sched_barrier(0);
-      compute();
+      compute(kt);
       f16_lds_barrier();
       if (kt + 1 < nk) {
         stg.store(smem, tid);

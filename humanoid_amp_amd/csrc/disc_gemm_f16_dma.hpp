@@ -89,6 +89,7 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN>::kWgPerCu)) void disc
   const int64_t m0 = (int64_t)mt * BM;
   const int n0 = nt * BN;
   const int nq = g.Kp / kDmaKB;  // k-blocks
+  const int ksteps = g.ksteps > 0 ? g.ksteps : 2 * nq;
 
   // ---- fill plan: a piece is 8 rows x 128 B.  Group 0's wave w fills a quarter of the activation rows, group 1's
   // wave 4 + w a quarter of the weight rows: NP pieces each.  lane l: row 8 j + (l >> 3) of the wave's quarter, stored
@@ -206,7 +207,11 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN>::kWgPerCu)) void disc
   }
   __builtin_amdgcn_s_barrier();  // k-block 0 is visible to every wave
   if (grp == 1) __builtin_amdgcn_s_barrier();
-  for (int q = 0; q < nq; ++q) {
+  // one k-block = R0 M0 [R1 M1]; `second` = false drops the second k-step of the LAST k-block when it is zero padding only
+  // (GemmF16Args::ksteps; uniform over the grid, so both wave groups drop the same two barriers; nothing is in flight then:
+  // the last fill was drained a k-block earlier).  The steady loop stays free of extra control flow -- a `break` inside it
+  // cost the 256 x 256 instantiations 350-420 B of scratch spills and 7x the time.
+  auto kblock = [&](const int q, const bool second) {
     const unsigned char* sb = lds + (q & 1) * kStage;
     // R0: fragments of k-step 0; the other stage (k-block q - 1: its last reads were retired in front of a barrier
     // this wave has passed) takes k-block q + 1 (k-block 1 was issued in the prologue)
@@ -214,12 +219,15 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN>::kWgPerCu)) void disc
     if (q >= 1 && q + 1 < nq) fill(q + 1, (q + 1) & 1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     matrix_segment(false);
+    if (!second) return;
     // R1: fragments of k-step 1; group 1's pieces of k-block q + 1 must have landed before the next barrier
     read_frags(sb, 1);
     if (grp == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     matrix_segment(grp == 0);  // group 0's pieces: behind its MFMAs
-  }
+  };
+  for (int q = 0; q + 1 < nq; ++q) kblock(q, true);
+  kblock(nq - 1, 2 * nq - 1 < ksteps);
   if (grp == 0) __builtin_amdgcn_s_barrier();
   __syncthreads();  // every wave is done with the stages: the scratch below reuses them
 
