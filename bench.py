@@ -335,7 +335,10 @@ def main():
     if rank == 0 and args.disc_precision == "f16x3":
         # what the matrix pipes of THIS device sustain on a bare fp16 MFMA stream (amp_calibrate_mfma_f16): MI355X is power-
         # limited, and on operands that change from one MFMA to the next the figure is well below the nominal peak
-        sustained = {"constant_operands": nat.calibrate_mfma_f16(False, 256, device), "random_operands": nat.calibrate_mfma_f16(True, 256, device)}
+        tc, fc = nat.calibrate_mfma_f16(False, 256, device, with_clock=True)
+        tr_, fr = nat.calibrate_mfma_f16(True, 256, device, with_clock=True)
+        sustained = {"constant_operands": tc, "random_operands": tr_, "core_clock_mhz_constant_operands": fc,
+                     "core_clock_mhz_random_operands": fr}
     if rank == 0:
         # HBM traffic of the dominant kernel: PMC FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE per launch, collected
         # in separate rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh) and committed: STATIC

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libamp_engine.so")
 ABI_VERSION = 6
 
 AMP_DISC_F16X3, AMP_DISC_FP32 = 0, 1
-AMP_DISC_INPUT_F32_ROWS, AMP_DISC_INPUT_F16_PAIRS = 0, 1
+AMP_DISC_INPUT_F32_ROWS, AMP_DISC_INPUT_F16_BLOCKS = 0, 1
 AMP_PHASE_DONES, AMP_PHASE_REWARD, AMP_PHASE_OBS = 1, 2, 4
 AMP_PHASE_ALL = 7
 AMP_COMMAND_TICK, AMP_COMMAND_RESET = 0, 1
@@ -309,19 +309,25 @@ class KernelTrace:
 
 
 
-def calibrate_mfma_f16(random_operands: bool, iters: int = 256, device="cuda:0", reps: int = 3) -> float:
+def calibrate_mfma_f16(random_operands: bool, iters: int = 256, device="cuda:0", reps: int = 3, with_clock: bool = False):
     """TFLOP/s the matrix pipes sustain on a bare fp16 MFMA stream (``amp_calibrate_mfma_f16``): the best of ``reps``
-    launches of ~``iters`` x 48 MFMAs per wave, timed by the engine's tracer."""
+    launches of ~``iters`` x 48 MFMAs per wave, timed by the engine's tracer.  ``with_clock``: also the core clock (MHz)
+    the chip sustained inside that launch's MFMA loop (shader-clock ticks / 100 MHz wall ticks, median over workgroups)."""
     lib = load()
     dev = require_gpu(device)
-    scratch = torch.empty(1024 * 256, dtype=torch.float32, device=dev)
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    scratch = torch.zeros(cus * 256 + cus * 4, dtype=torch.float32, device=dev)
     flops = C.c_double()
-    best = 0.0
+    best, mhz = 0.0, None
     with torch.cuda.device(dev):
         for _ in range(reps + 1):
             with KernelTrace(capacity=4, kernel_filter="mfma_f16_calibration_kernel") as tr:
                 check(lib.amp_calibrate_mfma_f16(int(bool(random_operands)), int(iters), dptr(scratch), scratch.numel(), C.byref(flops),
                                                  stream_ptr()), "amp_calibrate_mfma_f16")
             ms = tr.records()[-1][1]
-            best = max(best, flops.value / (ms * 1e-3) / 1e12)
-    return best
+            tf = flops.value / (ms * 1e-3) / 1e12
+            if tf > best:
+                best = tf
+                ticks = scratch[cus * 256:].view(torch.int64).view(cus, 2).double().cpu()
+                mhz = float((ticks[:, 0] / ticks[:, 1].clamp(min=1)).median()) * 100.0
+    return (best, mhz) if with_clock else best

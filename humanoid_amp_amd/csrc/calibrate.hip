@@ -13,7 +13,7 @@ typedef float cal_fx16 __attribute__((ext_vector_type(16)));
 namespace amp {
 
 template <int ENTROPY>
-__global__ __launch_bounds__(256, 1) void mfma_f16_calibration_kernel(float* out, int iters) {
+__global__ __launch_bounds__(256, 1) void mfma_f16_calibration_kernel(float* out, int iters, unsigned long long* clocks) {
   cal_fx16 acc[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i)
@@ -35,10 +35,18 @@ __global__ __launch_bounds__(256, 1) void mfma_f16_calibration_kernel(float* out
         b[k][i] = (_Float16)(0.25f);
       }
     }
+  // shader clock (s_memtime: counts at the CURRENT core clock) against the constant 100 MHz wall clock (s_memrealtime):
+  // their ratio over the loop is the clock the chip actually sustained under this load
+  const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int u = 0; u < 48; ++u)
       acc[u & 15] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u & 7], b[(u * 3 + (u >> 3)) & 7], acc[u & 15], 0, 0, 0);
+  }
+  const unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+  if (threadIdx.x == 0 && clocks) {
+    clocks[2 * blockIdx.x] = c1 - c0;
+    clocks[2 * blockIdx.x + 1] = w1 - w0;
   }
   float t = 0;
 #pragma unroll
@@ -61,9 +69,12 @@ int amp_calibrate_mfma_f16(int32_t random_operands, int32_t iters, float* scratc
   AMP_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   AMP_REQUIRE(scratch_floats >= (int64_t)cus * 256, "amp_calibrate_mfma_f16: scratch must hold %d floats", cus * 256);
   hipStream_t st = (hipStream_t)stream;
+  // clock samples: 2 x uint64 per workgroup (shader-clock ticks, 100 MHz wall ticks) behind the 256 floats per CU
+  unsigned long long* clocks = scratch_floats >= (int64_t)cus * 256 + (int64_t)cus * 4
+                                   ? reinterpret_cast<unsigned long long*>(scratch_dev + (int64_t)cus * 256) : nullptr;
   { amp::TraceScope trace__("mfma_f16_calibration_kernel", st);
-    if (random_operands) amp::mfma_f16_calibration_kernel<1><<<(unsigned)cus, 256, 0, st>>>(scratch_dev, iters);
-    else amp::mfma_f16_calibration_kernel<0><<<(unsigned)cus, 256, 0, st>>>(scratch_dev, iters);
+    if (random_operands) amp::mfma_f16_calibration_kernel<1><<<(unsigned)cus, 256, 0, st>>>(scratch_dev, iters, clocks);
+    else amp::mfma_f16_calibration_kernel<0><<<(unsigned)cus, 256, 0, st>>>(scratch_dev, iters, clocks);
   }
   *flops_out = (double)cus * 4.0 * (double)iters * 48.0 * 32768.0;  // one launch: CUs x 4 waves x iters x 48 MFMAs x 2*32*32*16
   return amp::launch_status("mfma_f16_calibration_kernel");

@@ -7,7 +7,7 @@
 //   AMP_DISC_FP32             v_mfma_f32_32x32x2_f32 on fp32 operands (disc_gemm.hpp): exact fp32 fma chain.
 //
 //   scale    one pass over amp_obs: RunningStandardScaler (exact fp32 divide, once per element) + zero padding of
-//            K*D to the k-tile -> Xs in the workspace (fp32 rows, or (p0, p1) fp16 pairs of s_x * Xs).
+//            K*D to the k-tile -> Xs in the workspace (fp32 rows, or the fp16 planes of s_x * Xs in block layout).
 //   layer 1  GEMM [M, k] x [k, 1024]: bias + ReLU in the epilogue, transposed through LDS so every store is a full
 //            row segment; H1 written once to the workspace (fp32, or the two planes of s_h * H1).
 //   layer 2  GEMM [M,1024] x [1024,512]: bias + ReLU + the 512->1 output layer as a per-lane dot with w3 over the
@@ -245,13 +245,13 @@ __global__ __launch_bounds__(kBlock) void disc_absmax_kernel(const float* __rest
   if (threadIdx.x == 0) atomicMax(amax, __float_as_uint(red[0]));
 }
 
-// amp_obs [M, in] (any row stride) -> (p0, p1) fp16 pairs of s_x * clamp((x - mean) / den) [M, kh], zero padded.
-// One thread per 4 columns (one 16-B store).  Also snapshots the task reward like disc_scale_pad_kernel.
+// amp_obs [M, in] (any row stride) -> the fp16 planes of s_x * clamp((x - mean) / den) in block layout [M, kh / 32, 2, 32],
+// zero padded.  One thread per 4 columns (one 8-B store per plane).  Also snapshots the task reward like disc_scale_pad_kernel.
 __global__ __launch_bounds__(kBlock) void disc_scale_split_kernel(const float* __restrict__ x, int64_t row_stride, int64_t M,
                                                                   int k, int kh, const float* __restrict__ mean,
                                                                   const float* __restrict__ den, float clip,
                                                                   const DiscRange* __restrict__ range,
-                                                                  const float* __restrict__ amax, uint32_t* __restrict__ pairs,
+                                                                  const float* __restrict__ amax, uint32_t* __restrict__ blocks,
                                                                   const float* __restrict__ task, float* __restrict__ task_copy) {
   const int q_per_row = kh >> 2;
   const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(kBlock) void disc_scale_split_kernel(const float* _
   const int64_t m = e / q_per_row;
   const int c0 = (int)(e - m * q_per_row) * 4;
   const float* row = x + m * row_stride;
-  uv4 o;
+  fv4 sv;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = c0 + i;
@@ -273,9 +273,14 @@ __global__ __launch_bounds__(kBlock) void disc_scale_split_kernel(const float* _
         v = fminf(fmaxf(v, -clip), clip);
       }
     }
-    o[i] = plane_pair(v * s_x);
+    sv[i] = v * s_x;
   }
-  *reinterpret_cast<uv4*>(pairs + m * kh + c0) = o;
+  // block layout: row m, k-block c0 / 32 = [p0 x 32 | p1 x 32] halves; the thread's four columns are 8 B of each plane
+  h4 p0, p1;
+  split_planes4(sv, p0, p1);
+  _Float16* blk = reinterpret_cast<_Float16*>(blocks) + m * (2 * (int64_t)kh) + (c0 >> 5) * 64 + (c0 & 31);
+  *reinterpret_cast<h4*>(blk) = p0;
+  *reinterpret_cast<h4*>(blk + 32) = p1;
 }
 
 }  // namespace amp
@@ -329,7 +334,7 @@ static int disc_forward(const AmpDisc* h, const float* Xs, int64_t rows, float* 
   }
   return launch_status("disc_finalize_kernel");
 }
-// fp16-split forward on the (p0, p1) pairs Xp [rows][k1h] of the scaled input (disc_gemm_f16.hpp); `amax` = the dynamic
+// fp16-split forward on the block-layout planes Xp [rows][k1h / 32][2][32] of the scaled input; `amax` = the dynamic
 // bound of the scaled input, or null when the scaler's clamp bounds it
 template <int TM, int TN, int BK, int MODE, int MINW>
 static int launch_f16(GemmF16Args g, int64_t rows, int N, const char* name, hipStream_t st) {
@@ -415,7 +420,7 @@ static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* a
     const bool dma = plan != kPlanRegister;
     auto big_tiles = [&](int N) { return (m + 127) / 128 * (N / 128) >= 512; };
     GemmF16Args g1{};
-    g1.A = Xp + 2 * r0 * h->k1h; g1.lda = h->k1h; g1.plane_a = 0; g1.M = m;  // (p0, p1) pairs: two halves per element
+    g1.A = Xp + 2 * r0 * h->k1h; g1.lda = h->k1h; g1.plane_a = 0; g1.M = m;  // block layout: 2 * k1h halves per row
     g1.W = h->w1h; g1.plane_w = (int64_t)h->h1 * h->k1h; g1.Kp = h->k1h; g1.N = h->h1;
     g1.bias = h->b1; g1.range = h->range; g1.amax = amax; g1.layer = 1;
     g1.H = H1p + r0 * h->h1; g1.ldh = h->h1; g1.plane_h = rows * h->h1;
@@ -721,7 +726,7 @@ int amp_disc_style_reward(const AmpDisc* h, const float* x, int64_t rows, int64_
 int amp_disc_input_layout(const AmpDisc* h, AmpDiscInputLayout* out) {
   AMP_REQUIRE(h && out, "amp_disc_input_layout: null argument");
   const bool planes = h->mode == AMP_DISC_F16X3 && static_bound(h);
-  out->format = planes ? AMP_DISC_INPUT_F16_PAIRS : AMP_DISC_INPUT_F32_ROWS;
+  out->format = planes ? AMP_DISC_INPUT_F16_BLOCKS : AMP_DISC_INPUT_F32_ROWS;
   out->padded_dim = planes ? h->k1h : h->k1p;
   out->mean_dev = h->has_scaler ? h->mean : nullptr;
   out->den_dev = h->den;
@@ -774,7 +779,7 @@ static int style_reward_prescaled_impl(const AmpDisc* h, const void* xs_any, int
   AMP_REQUIRE(rows <= ((int64_t)1 << 30), "amp_disc_style_reward_prescaled: too many rows");
   const DiscWorkspace ws = disc_workspace(h, rows, workspace);
   hipStream_t st = (hipStream_t)stream;
-  if (h->mode == AMP_DISC_F16X3 && static_bound(h))  // fp16 pairs at the clamp's plane scale (amp_disc_input_layout)
+  if (h->mode == AMP_DISC_F16X3 && static_bound(h))  // fp16 plane blocks at the clamp's plane scale (amp_disc_input_layout)
     return disc_forward_f16(h, (const _Float16*)xs_any, nullptr, rows, (_Float16*)ws.h1, ws.partial, scale, task, task_w, style_w,
                             logits, style, combined, st, compact);
   if (h->mode == AMP_DISC_F16X3) {

@@ -66,8 +66,8 @@ __device__ __forceinline__ LayerScales layer_scales(const DiscRange* r, const fl
 }
 
 struct GemmF16Args {
-  // activations: planes A + p * plane_a with rows of lda halves, or (PAIRS) one array of (p0, p1) half pairs, rows of
-  // lda pairs -- the layout producers write with one 32-bit store per element (amp_env_step's fused scaler)
+  // activations: planes A + p * plane_a with rows of lda halves, or (BLOCKS) block layout: rows of 2 * lda halves, per
+  // k-block of 32 values [p0 x 32 | p1 x 32] -- the layout the scaled input is produced in (amp_env_step's fused scaler)
   const _Float16* A; int64_t lda, plane_a; int64_t M;
   const _Float16* W; int64_t plane_w; int32_t Kp; int32_t N;    // weight planes [N, Kp]
   const float* bias;
@@ -125,21 +125,6 @@ __global__ __launch_bounds__(kBlock) void split_rows_f16_kernel(const float* __r
   *reinterpret_cast<h4*>(&dst[plane + r * ld_dst + c]) = p1;
 }
 
-// (p0, p1) pairs of scale[0] * src[rows, cols] -> dst [rows, ld_dst] words; columns in [cols, ld_dst) are zero
-__global__ __launch_bounds__(kBlock) void split_rows_pairs_kernel(const float* __restrict__ src, int64_t rows, int cols,
-                                                                  int64_t ld_src, const float* __restrict__ scale,
-                                                                  uint32_t* __restrict__ dst, int64_t ld_dst) {
-  const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x, per_row = ld_dst / 4;
-  if (q >= rows * per_row) return;
-  const int64_t r = q / per_row;
-  const int c = (int)(q - r * per_row) * 4;
-  const float s = scale[0];
-  uv4 o;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = c + i < cols ? plane_pair(src[r * ld_src + c + i] * s) : 0u;
-  *reinterpret_cast<uv4*>(&dst[r * ld_dst + c]) = o;
-}
-
 __device__ __forceinline__ bool f16_tile_of_block(const GemmF16Args& g, int& mt, int& nt) {
   const int total = g.m_tiles * g.n_tiles;
   const int per_xcd = (total + 7) / 8;
@@ -152,7 +137,7 @@ __device__ __forceinline__ bool f16_tile_of_block(const GemmF16Args& g, int& mt,
 
 __device__ __forceinline__ void f16_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int BM, int BN, int BK, bool PAIRS>
+template <int BM, int BN, int BK, bool BLOCKS>
 struct StageF16 {
   static constexpr int LDK = BK + 8;                // halves per LDS row
   static constexpr int CPR = BK / 8;                // 16-B chunks per row
@@ -169,21 +154,16 @@ struct StageF16 {
     for (int p = 0; p < 2; ++p)
 #pragma unroll
       for (int i = 0; i < CB; ++i) b[p][i] = *reinterpret_cast<const h8*>(w + p * g.plane_w + (int64_t)i * RPP * g.Kp);
-    if (PAIRS) {
-      // 8 elements = 8 (p0, p1) words = two 16-B loads; v_perm_b32 gathers the low / high halves into plane chunks
-      const uint32_t* x32 = reinterpret_cast<const uint32_t*>(g.A) + kt * BK + 8 * kc;
+    if (BLOCKS) {
+      // block layout: row m, k-block kb = 64 halves [p0 x 32 | p1 x 32]; this thread's 8 values start at k = kt BK + 8 kc
+      const int k0 = kt * BK + 8 * kc;
+      const _Float16* blk = g.A + (k0 >> 5) * 64 + (k0 & 31);
 #pragma unroll
       for (int i = 0; i < CA; ++i) {
         const int64_t m = m0 + r + RPP * i;
-        const uint32_t* src = x32 + (m < last ? m : last) * g.lda;
-        const uv4 lo = *reinterpret_cast<const uv4*>(src), hi = *reinterpret_cast<const uv4*>(src + 4);
-        uv4 q0, q1;
-        q0[0] = __builtin_amdgcn_perm(lo[1], lo[0], 0x05040100u); q1[0] = __builtin_amdgcn_perm(lo[1], lo[0], 0x07060302u);
-        q0[1] = __builtin_amdgcn_perm(lo[3], lo[2], 0x05040100u); q1[1] = __builtin_amdgcn_perm(lo[3], lo[2], 0x07060302u);
-        q0[2] = __builtin_amdgcn_perm(hi[1], hi[0], 0x05040100u); q1[2] = __builtin_amdgcn_perm(hi[1], hi[0], 0x07060302u);
-        q0[3] = __builtin_amdgcn_perm(hi[3], hi[2], 0x05040100u); q1[3] = __builtin_amdgcn_perm(hi[3], hi[2], 0x07060302u);
-        a[0][i] = __builtin_bit_cast(h8, q0);
-        a[1][i] = __builtin_bit_cast(h8, q1);
+        const _Float16* src = blk + (m < last ? m : last) * (2 * g.lda);
+        a[0][i] = *reinterpret_cast<const h8*>(src);
+        a[1][i] = *reinterpret_cast<const h8*>(src + 32);
       }
     } else {
 #pragma unroll
@@ -209,7 +189,7 @@ struct StageF16 {
   }
 };
 
-// MODE 0 reads its activations as (p0, p1) pairs (the scaled input), MODE 1 as planes (H1, written by MODE 0).
+// MODE 0 reads its activations in block layout (the scaled input), MODE 1 as planes (H1, written by MODE 0).
 // One register stage prefetched ahead (two stages and the no-load / no-barrier ablations were measured in round 1:
 // profiles/r01_gemm_f16_variants.txt; neither is kept in the product kernel).
 template <int TM, int TN, int BK, int MODE, int MINW>

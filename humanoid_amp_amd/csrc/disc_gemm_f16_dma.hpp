@@ -1,6 +1,6 @@
 // GEMMs of the fp16-split discriminator forward for large shards: the same arithmetic, in the same order, as
 // disc_gemm_f16_kernel (three v_mfma_f32_32x32x16_f16 per k-step into one fp32 accumulator, transposed accumulator
-// tile; MODE 0: bias + ReLU -> fp16 planes of the hidden layer, activations read as (p0, p1) pairs; MODE 1: bias +
+// tile; MODE 0: bias + ReLU -> fp16 planes of the hidden layer (its activations are the scaled input); MODE 1: bias +
 // ReLU + dot(w3) -> partial logits), rebuilt around what bounds them on MI355X -- the operand fill path:
 //
 //   * measured with a fill-only probe (tools/gemm_f16_bench.hip, FILL=1: the kernel's DMA pattern, no compute): LDS-DMA
@@ -8,7 +8,7 @@
 //     256 x 256 tile needs 1.07 GB of fills per 65 536-row launch: 154 us with 32-B row segments (= the whole kernel),
 //     63 us with full lines.
 //   * so every operand is stored in BLOCK layout: row r, k-block kb (32 values) = 128 contiguous bytes holding both
-//     planes, [p0: 32 halves][p1: 32 halves] (the (p0, p1)-pair layout of the scaled input is the same 128 B per 32
+//     planes, [p0: 32 halves][p1: 32 halves] (the scaled input is produced in the same layout: 128 B per 32
 //     values).  One LDS-DMA piece = 8 rows x 128 B = 1 KiB, full cache lines only.
 //   * 256 x 256 workgroup tile, 512 threads = 8 waves as 2 (rows) x 4 (columns), each wave 128 x 64 = 4 x 2
 //     accumulator blocks; one workgroup per CU, two waves per SIMD.
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(kBlock) void split_rows_blocks_kernel(const float* 
   *reinterpret_cast<h4*>(blk + 32) = p1;
 }
 
-// Args: A = activations, row pitch 2 * lda halves (MODE 0: lda pairs per row; MODE 1: block layout of lda values);
+// Args: A = activations in block layout, row pitch 2 * lda halves (lda values per row);
 // W = weights in block layout, row pitch 2 * Kp halves; MODE 0 output H in block layout, row pitch 2 * ldh halves.
 // (Ablated variants of this kernel -- no fills, no fragment reads, no stores, free-running waves -- live in
 // tools/experiments/disc_gemm_f16_dma_xp.hpp for tools/gemm_f16_bench.hip; the product kernel carries none.)
@@ -123,14 +123,14 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN>::kWgPerCu)) void disc
 
   // ---- fragment addresses (bytes inside a stage): row r, chunk c -> r * 128 + (c ^ ((r >> 1) & 7)) * 16; the wave's
   // rows start at multiples of 32, so (r >> 1) & 7 = (li >> 1) & 7.  Block layout: plane pl, k-step s, lane half lh ->
-  // chunk 4 pl + 2 s + lh.  Pair layout (MODE 0 activations): the lane's eight values are chunks 4 s + 2 lh, + 1.
+  // chunk 4 pl + 2 s + lh (activations and weights alike).
   const int swz = (li >> 1) & 7;
   const int arow = (wm * (32 * TM) + li) * 128, brow = kOpA + (wn * (32 * TN) + li) * 128;
-  int ca[2][2], cb[2][2];  // [k-step][plane, or first / second chunk of the pairs] byte offsets inside a row
+  int ca[2][2], cb[2][2];  // [k-step][plane] byte offsets inside a row
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    ca[s][0] = ((MODE == 1 ? 2 * s + lh : 4 * s + 2 * lh) ^ swz) * 16;
-    ca[s][1] = ((MODE == 1 ? 4 + 2 * s + lh : 4 * s + 2 * lh + 1) ^ swz) * 16;
+    ca[s][0] = ((2 * s + lh) ^ swz) * 16;
+    ca[s][1] = ((4 + 2 * s + lh) ^ swz) * 16;
     cb[s][0] = ((2 * s + lh) ^ swz) * 16;
     cb[s][1] = ((4 + 2 * s + lh) ^ swz) * 16;
   }
@@ -147,20 +147,8 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN>::kWgPerCu)) void disc
   auto read_frags = [&](const unsigned char* sb, const int s) {
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
-      if (MODE == 1) {
-        x0[a] = *reinterpret_cast<const h8*>(sb + arow + a * 32 * 128 + ca[s][0]);
-        x1[a] = *reinterpret_cast<const h8*>(sb + arow + a * 32 * 128 + ca[s][1]);
-      } else {
-        const uv4 lo = *reinterpret_cast<const uv4*>(sb + arow + a * 32 * 128 + ca[s][0]);
-        const uv4 hi = *reinterpret_cast<const uv4*>(sb + arow + a * 32 * 128 + ca[s][1]);
-        uv4 q0, q1;
-        q0[0] = __builtin_amdgcn_perm(lo[1], lo[0], 0x05040100u); q1[0] = __builtin_amdgcn_perm(lo[1], lo[0], 0x07060302u);
-        q0[1] = __builtin_amdgcn_perm(lo[3], lo[2], 0x05040100u); q1[1] = __builtin_amdgcn_perm(lo[3], lo[2], 0x07060302u);
-        q0[2] = __builtin_amdgcn_perm(hi[1], hi[0], 0x05040100u); q1[2] = __builtin_amdgcn_perm(hi[1], hi[0], 0x07060302u);
-        q0[3] = __builtin_amdgcn_perm(hi[3], hi[2], 0x05040100u); q1[3] = __builtin_amdgcn_perm(hi[3], hi[2], 0x07060302u);
-        x0[a] = __builtin_bit_cast(h8, q0);
-        x1[a] = __builtin_bit_cast(h8, q1);
-      }
+      x0[a] = *reinterpret_cast<const h8*>(sb + arow + a * 32 * 128 + ca[s][0]);
+      x1[a] = *reinterpret_cast<const h8*>(sb + arow + a * 32 * 128 + ca[s][1]);
     }
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
@@ -175,18 +163,28 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN>::kWgPerCu)) void disc
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
+    // the same three products per accumulator in every f16 kernel: (w0, x1), (w1, x0), (w0, x0).  MODE 1 passes the WEIGHT
+    // fragment first (accumulator registers = output columns: the 512 -> 1 layer is a per-lane sum); MODE 0 passes the
+    // ACTIVATION fragment first (registers = output rows, lanes = columns: rows store without a transpose).  The element
+    // arithmetic is the same either way -- the MFMA's reduction order depends on k alone.
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
-      for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[b], x1[a], acc[a][b], 0, 0, 0);
+      for (int b = 0; b < TN; ++b)
+        acc[a][b] = MODE == 0 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(x1[a], w0[b], acc[a][b], 0, 0, 0)
+                              : __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[b], x1[a], acc[a][b], 0, 0, 0);
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
-      for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[b], x0[a], acc[a][b], 0, 0, 0);
+      for (int b = 0; b < TN; ++b)
+        acc[a][b] = MODE == 0 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(x0[a], w1[b], acc[a][b], 0, 0, 0)
+                              : __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[b], x0[a], acc[a][b], 0, 0, 0);
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
-      for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[b], x0[a], acc[a][b], 0, 0, 0);
+      for (int b = 0; b < TN; ++b)
+        acc[a][b] = MODE == 0 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(x0[a], w0[b], acc[a][b], 0, 0, 0)
+                              : __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[b], x0[a], acc[a][b], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -231,53 +229,50 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN>::kWgPerCu)) void disc
   if (grp == 0) __builtin_amdgcn_s_barrier();
   __syncthreads();  // every wave is done with the stages: the scratch below reuses them
 
-  // ---- epilogue: register r of lane half lh is output column (r & 3) + 8 (r >> 2) + 4 lh of the 32-wide block,
-  //      lane li is activation row li
   const LayerScales sc = layer_scales(g.range, g.amax, g.layer);
   const float descale = sc.descale;
-  const fv4* bias4 = reinterpret_cast<const fv4*>(g.bias + n0 + wn * (32 * TN) + 4 * lh);
   if (MODE == 0) {
-    // relu(. + bias) -> the two planes of s_h H in block layout, transposed through a wave-private LDS slab per 32
-    // rows so that a lane stores 16 B and sixteen lanes cover the 256 contiguous bytes a row gets from this wave
-    // (two k-blocks x [p0 | p1])
-    constexpr int CW = 32 * TN, EPL = CW + 8;  // the wave's columns, padded slab row (halves)
-    const float s_h = sc.s_out;
-    _Float16* ep = reinterpret_cast<_Float16*>(lds) + wave * (2 * 32 * EPL);
+    // ---- layer-1 epilogue.  Accumulator register r of lane (li, lh) is output ROW (r & 3) + 8 (r >> 2) + 4 lh of the
+    // 32 x 32 block and COLUMN li: relu_split4's arithmetic per value (fma, max, two roundings to fp16), then adjacent lanes
+    // swap their (p0, p1) words (one DPP move + one v_perm_b32) so that even lanes hold the p0 halves of columns (li, li + 1)
+    // and odd lanes the p1 halves of (li - 1, li), and ONE buffer_store_dword per (row, 32-column k-block) writes the
+    // block's [p0 x 32 | p1 x 32] line: 128 contiguous bytes per lane half, no transpose through LDS (round 1's slab
+    // transposes cost 1.6 M bank-conflict cycles per launch and ran with the matrix pipes idle).
+    // The buffer is the wave's band of rows: base and extent in four SGPRs, a scalar offset per (register, block), one
+    // per-lane offset for everything -- and rows past M fall outside the extent, so the hardware drops them (no mask).
+    const float s_h = sc.s_out, ds = descale * s_h;
+    const uint32_t row_pitch = (uint32_t)(2 * g.ldh * (int64_t)sizeof(_Float16));
+    const int band = __builtin_amdgcn_readfirstlane(wm) * (32 * TM);       // the wave's first row inside the tile
+    const int col0 = n0 + __builtin_amdgcn_readfirstlane(wn) * (32 * TN);  // ... and first column
+    const int64_t rows_left = g.M - (m0 + band);
+    const int valid = rows_left <= 0 ? 0 : (rows_left < 32 * TM ? (int)rows_left : 32 * TM);
+    unsigned char* const hband = reinterpret_cast<unsigned char*>(g.H) + (m0 + band) * (int64_t)row_pitch + (col0 >> 5) * 128;
+    const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(hband, 0, (int)((uint32_t)valid * row_pitch), 0x00020000);
+    const uint32_t lane_off = (uint32_t)(4 * lh) * row_pitch + (uint32_t)((li & 1) * 64 + (li >> 1) * 4);
+    const uint32_t sel = (li & 1) ? 0x03020706u : 0x05040100u;  // v_perm_b32(neighbour, own, sel): odd [nb.hi, own.hi], even [own.lo, nb.lo]
+    float bs[TN];
 #pragma unroll
-    for (int a = 0; a < TM; ++a) {
+    for (int b = 0; b < TN; ++b) bs[b] = g.bias[col0 + b * 32 + li] * s_h;
 #pragma unroll
-      for (int b = 0; b < TN; ++b)
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int grp4 = 0; grp4 < 4; ++grp4) {
-          const fv4 bs = bias4[b * 8 + grp4 * 2] * s_h;
-          fv4 v;
+      for (int r = 0; r < 16; ++r)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = acc[a][b][4 * grp4 + i];
-          h4 p0, p1;
-          relu_split4(v, descale * s_h, bs, p0, p1);
-          const int col = b * 32 + 8 * grp4 + 4 * lh;
-          *reinterpret_cast<h4*>(&ep[li * EPL + col]) = p0;
-          *reinterpret_cast<h4*>(&ep[32 * EPL + li * EPL + col]) = p1;
+        for (int b = 0; b < TN; ++b) {
+          const float v = fmaxf(__builtin_fmaf(acc[a][b][r], ds, bs[b]), 0.0f);
+          const _Float16 p0 = (_Float16)v;
+          const _Float16 p1 = (_Float16)__builtin_fmaf((float)p0, -1.0f, v);
+          const uint32_t own = (uint32_t)__builtin_bit_cast(uint16_t, p0) | ((uint32_t)__builtin_bit_cast(uint16_t, p1) << 16);
+          const uint32_t nb = (uint32_t)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);  // quad_perm [1, 0, 3, 2]
+          const uint32_t word = __builtin_amdgcn_perm(nb, own, sel);
+          const int soff = (int)((uint32_t)(a * 32 + (r & 3) + 8 * (r >> 2)) * row_pitch) + b * 128;  // wave-uniform
+          __builtin_amdgcn_raw_buffer_store_b32(word, hrsrc, (int)lane_off, soff, 0);
         }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-      for (int i = 0; i < 4 * TN; ++i) {
-        // 8 TN chunks per row in memory order: k-block b, plane pl, quarter qq
-        constexpr int CPR = 8 * TN;
-        const int idx = lane + 64 * i, row = idx / CPR, ch = idx % CPR, b = ch >> 3, pl = (ch >> 2) & 1, qq = ch & 3;
-        const h8 v = *reinterpret_cast<const h8*>(&ep[pl * 32 * EPL + row * EPL + b * 32 + 8 * qq]);
-        const int64_t grow = m0 + wm * (32 * TM) + a * 32 + row;
-        if (grow < g.M)
-          *reinterpret_cast<h8*>(&g.H[grow * (2 * g.ldh) + (int64_t)((n0 + wn * CW) >> 5) * 64 + 8 * ch]) = v;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
     return;
   }
+  // ---- layer-2 epilogue: register r of lane half lh is output column (r & 3) + 8 (r >> 2) + 4 lh of the 32-wide block,
+  //      lane li is activation row li
+  const fv4* bias4 = reinterpret_cast<const fv4*>(g.bias + n0 + wn * (32 * TN) + 4 * lh);
   const fv4* w34 = reinterpret_cast<const fv4*>(g.w3 + n0 + wn * (32 * TN) + 4 * lh);
   // canonical partial logits, one per (row, 32-column block): see disc_gemm_f16_kernel's MODE 1 epilogue
   float* red = reinterpret_cast<float*>(lds);  // [4 TN][BM]

@@ -202,9 +202,9 @@ __device__ __forceinline__ void env_step_body(const EnvPlan& p, const AmpSimStat
     const int count = n_tile * D;
     const float inv_d = 1.0f / (float)D;
     constexpr int U = 4;  // independent columns per lane per trip: their loads are issued before any store
-    // optional fused discriminator input: the same values, scaled, into disc_input (fp32 rows or fp16 (p0, p1) pairs:
-    // one 32-bit store per element either way)
-    const bool pairs = bf.disc_input_format == AMP_DISC_INPUT_F16_PAIRS;
+    // optional fused discriminator input: the same values, scaled, into disc_input (fp32 rows: one 32-bit store per
+    // element; fp16 plane blocks: per row and 32-column k-block [p0 x 32 | p1 x 32] halves, two 16-bit stores here)
+    const bool blocks = bf.disc_input_format == AMP_DISC_INPUT_F16_BLOCKS;
     const bool fused = bf.disc_input != nullptr;
     uint32_t* const xs = reinterpret_cast<uint32_t*>(bf.disc_input) + tile_base * bf.disc_input_stride;
     const float s_x = bf.disc_plane_scale;
@@ -215,7 +215,14 @@ __device__ __forceinline__ void env_step_body(const EnvPlan& p, const AmpSimStat
         v = (v - s_mu[c]) / s_dn[c];  // skrl RunningStandardScaler, exact fp32 divide
         v = fminf(fmaxf(v, -clip), clip);
       }
-      xs[off] = pairs ? plane_pair(v * s_x) : __float_as_uint(v);
+      if (blocks) {
+        const uint32_t w = plane_pair(v * s_x);  // p0 | p1 << 16
+        uint16_t* h = reinterpret_cast<uint16_t*>(xs) + 2 * (off - c) + (c >> 5) * 64 + (c & 31);  // row start + block + column
+        h[0] = (uint16_t)w;
+        h[32] = (uint16_t)(w >> 16);
+      } else {
+        xs[off] = __float_as_uint(v);
+      }
     };
     for (int e0 = tid; e0 < count; e0 += U * kBlock) {
       float* col[U];
@@ -525,10 +532,10 @@ __device__ __forceinline__ void env_step_fast_body(const EnvPlan& p, const AmpSi
   }
   if (fused) {
     // the same rows, scaled, as the discriminator's input: two columns per lane (rows hold an even number of them)
-    const bool pairs = bf.disc_input_format == AMP_DISC_INPUT_F16_PAIRS;
+    const bool blocks = bf.disc_input_format == AMP_DISC_INPUT_F16_BLOCKS;
     uint32_t* const xs = reinterpret_cast<uint32_t*>(bf.disc_input) + tile_base * bf.disc_input_stride;
     const float s_x = bf.disc_plane_scale, clip = bf.scaler_clip;
-    const float inv_ch = 1.0f / (float)D;  // D column pairs per row
+    const float inv_ch = 1.0f / (float)D;  // D two-column items per row
 #pragma unroll 4
     for (int it = tid; it < T * D; it += kBlock) {
       const int s = row_of(it, inv_ch), c = 2 * (it - s * D);
@@ -542,10 +549,19 @@ __device__ __forceinline__ void env_step_fast_body(const EnvPlan& p, const AmpSi
         x0 = fminf(fmaxf(x0, -clip), clip);
         x1 = fminf(fmaxf(x1, -clip), clip);
       }
-      uint2 o;
-      o.x = pairs ? plane_pair(x0 * s_x) : __float_as_uint(x0);
-      o.y = pairs ? plane_pair(x1 * s_x) : __float_as_uint(x1);
-      *reinterpret_cast<uint2*>(xs + s * bf.disc_input_stride + c) = o;
+      if (blocks) {
+        // columns c, c + 1 (c even: the same k-block): their p0 halves are one 32-bit word of the block's first 64 B,
+        // their p1 halves the word 64 B further
+        const uint32_t wa = plane_pair(x0 * s_x), wb = plane_pair(x1 * s_x);  // p0 | p1 << 16 of each column
+        uint32_t* blk = xs + s * bf.disc_input_stride + (c >> 5) * 32 + ((c & 31) >> 1);
+        blk[0] = __builtin_amdgcn_perm(wb, wa, 0x05040100u);   // [p0(c), p0(c + 1)]
+        blk[16] = __builtin_amdgcn_perm(wb, wa, 0x07060302u);  // [p1(c), p1(c + 1)]
+      } else {
+        uint2 o;
+        o.x = __float_as_uint(x0);
+        o.y = __float_as_uint(x1);
+        *reinterpret_cast<uint2*>(xs + s * bf.disc_input_stride + c) = o;
+      }
     }
   }
   {  // policy observation (g1_amp_env.py:195-242; humanoid_amp_env.py:126), P == Pcur (no actor history here)
@@ -724,7 +740,7 @@ static int env_step_launch(const AmpEnvCfg* cfg, const AmpSimState* st, const Am
     AMP_REQUIRE(!bf->disc_input || bf->disc_input_stride >= (int64_t)p.K * p.D, "amp_env_step(obs): disc_input_stride too small");
     AMP_REQUIRE(!bf->disc_input || !bf->scaler_mean || bf->scaler_den, "amp_env_step(obs): scaler_den is null");
     AMP_REQUIRE(!bf->disc_input || bf->disc_input_format == AMP_DISC_INPUT_F32_ROWS ||
-                    (bf->disc_input_format == AMP_DISC_INPUT_F16_PAIRS && bf->disc_plane_scale > 0.0f),
+                    (bf->disc_input_format == AMP_DISC_INPUT_F16_BLOCKS && bf->disc_plane_scale > 0.0f && bf->disc_input_stride % 32 == 0),
                 "amp_env_step(obs): bad disc_input format / plane scale");
   }
   const bool per_env_limits = g1_rew && st->soft_limits_stride != 0;

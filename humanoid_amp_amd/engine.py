@@ -112,14 +112,14 @@ class EnvStepKernel:
     def attach_discriminator(self, disc: "AmpDiscriminator") -> torch.Tensor:
         """Fuse ``disc``'s input scaler into the OBS phase: every OBS launch also writes the scaled, zero-padded
         discriminator input in the layout the discriminator's GEMMs consume -- ``disc_input`` float32 ``[N, padded]``
-        or float16 (p0, p1) pairs ``[N, padded, 2]`` (feed it to ``disc.style_reward_prescaled``) -- which saves the
+        or float16 plane blocks ``[N, padded / 32, 2, 32]`` (feed it to ``disc.style_reward_prescaled``) -- which saves the
         separate scaler pass over ``amp_obs``.  Call again after ``disc.set_scaler`` / ``set_weights``."""
         lay = disc.input_layout()
         if lay.padded_dim < self.cfg.num_amp_observations * self.cfg.amp_frame_size:
             raise nat.AmpEngineError("discriminator input is narrower than K * D")
-        pairs = lay.format == nat.AMP_DISC_INPUT_F16_PAIRS
-        shape = (self.num_envs, lay.padded_dim, 2) if pairs else (self.num_envs, lay.padded_dim)
-        dtype = torch.float16 if pairs else torch.float32
+        blocks = lay.format == nat.AMP_DISC_INPUT_F16_BLOCKS  # per row and 32-column k-block: [p0 x 32 | p1 x 32] halves
+        shape = (self.num_envs, lay.padded_dim // 32, 2, 32) if blocks else (self.num_envs, lay.padded_dim)
+        dtype = torch.float16 if blocks else torch.float32
         if self.disc_input is None or tuple(self.disc_input.shape) != shape or self.disc_input.dtype != dtype:
             self.disc_input = torch.zeros(shape, dtype=dtype, device=self.device)  # padding columns stay zero
         self._disc_layout = lay
@@ -457,7 +457,7 @@ class AmpDiscriminator:
         return out
 
     def input_layout(self) -> nat.AmpDiscInputLayout:
-        """Layout of the scaled input the GEMMs consume (``format``: fp32 rows or fp16 pairs, ``padded_dim``, the
+        """Layout of the scaled input the GEMMs consume (``format``: fp32 rows or fp16 plane blocks, ``padded_dim``, the
         handle's fp32 scaler vectors as device pointers, ``clip``, ``plane_scale``)."""
         lay = nat.AmpDiscInputLayout()
         nat.check(self._lib.amp_disc_input_layout(self._handle, C.byref(lay)), "amp_disc_input_layout")
@@ -466,13 +466,13 @@ class AmpDiscriminator:
     def style_reward_prescaled(self, scaled: torch.Tensor, task_reward: Optional[torch.Tensor] = None, *,
                                want_logits: bool = False, compact: Optional["EnvStepKernel"] = None):
         """Same as :meth:`style_reward` for an input already scaled, padded and laid out as :meth:`input_layout`
-        says (``EnvStepKernel.attach_discriminator``): float32 ``[M, padded]`` or float16 pairs ``[M, padded, 2]``.
+        says (``EnvStepKernel.attach_discriminator``): float32 ``[M, padded]`` or float16 plane blocks ``[M, padded / 32, 2, 32]``.
         ``compact`` (the :class:`EnvStepKernel` whose DONES phase ran this step): its reset-id compaction
         (``compact_resets()``) rides on the finalize launch (``amp_disc_style_reward_prescaled_compact``), one launch
         fewer; ``compact.reset_ids`` / ``reset_count`` are valid once this call's work completes."""
         lay = self.input_layout()
-        pairs = lay.format == nat.AMP_DISC_INPUT_F16_PAIRS
-        want = (torch.float16, (lay.padded_dim, 2)) if pairs else (torch.float32, (lay.padded_dim,))
+        blocks = lay.format == nat.AMP_DISC_INPUT_F16_BLOCKS
+        want = (torch.float16, (lay.padded_dim // 32, 2, 32)) if blocks else (torch.float32, (lay.padded_dim,))
         if scaled.dtype != want[0] or tuple(scaled.shape[1:]) != want[1] or not scaled.is_contiguous():
             raise nat.AmpEngineError(f"scaled input must be a contiguous {want[0]} [M, {', '.join(map(str, want[1]))}] tensor "
                                      "(see input_layout)")

@@ -200,7 +200,10 @@ class MotionLoader:
             raise IndexError(f"motion_ids out of range [0, {self.num_trajectories})")
 
     def _compute_frame_blend(self, times, motion_ids):
-        """(index_0, index_1, blend): int64 / int64 / float64 device tensors (motion_loader.py:281-307)."""
+        """(index_0, index_1, blend) of motion_loader.py:281-307, computed by ``amp_motion_frame_blend``.  Return types
+        follow the input: numpy ``times`` (the reference's calling convention) -> numpy int64 / int64 / float64 arrays like
+        the reference returns; device tensors in -> device tensors out (no host round trip)."""
+        as_numpy = not isinstance(times, torch.Tensor)
         h = self._need_handle()
         t = _as_device(times, torch.float64, self._tdev, name="times")
         n = t.numel()
@@ -212,6 +215,8 @@ class MotionLoader:
         with torch.cuda.device(self._tdev):
             nat.check(self._lib.amp_motion_frame_blend(h, nat.dptr(t), nat.dptr(ids), n, nat.dptr(i0), nat.dptr(i1),
                                                        nat.dptr(blend), nat.stream_ptr()), "amp_motion_frame_blend")
+        if as_numpy:
+            return i0.cpu().numpy(), i1.cpu().numpy(), blend.cpu().numpy()
         return i0, i1, blend
 
     def sample(self, num_samples: int, times=None, duration: float | None = None, motion_ids=None):

@@ -60,7 +60,9 @@ int amp_trace_get(int64_t i, char* name_buf, int64_t name_len, float* ms);
 /* Measurement aid: one launch of a bare v_mfma_f32_32x32x16_f16 stream (one 4-wave workgroup per CU, 16 independent
  * accumulators, iters x 48 MFMAs per wave) on constant (random_operands = 0) or changing full-entropy operands (1).
  * *flops_out = FLOPs of the launch; time it with the tracer (kernel name "mfma_f16_calibration_kernel") or events.
- * scratch_dev: >= 256 floats per CU.  What the result is for: MI355X is power-limited, the matrix pipes sustain 0.55-0.62
+ * scratch_dev: >= 256 floats per CU; with 4 more floats per CU the launch also leaves, behind those 256 * CUs floats, two
+ * uint64 per workgroup: shader-clock ticks (s_memtime) and 100 MHz wall ticks (s_memrealtime) across the MFMA loop --
+ * their ratio is the core clock the chip sustained under the load.  What the result is for: MI355X is power-limited, the matrix pipes sustain 0.55-0.62
  * of the nominal fp16 peak on changing operands -- the ceiling the discriminator GEMMs' roofline fraction is read against. */
 int amp_calibrate_mfma_f16(int32_t random_operands, int32_t iters, float* scratch_dev, int64_t scratch_floats,
                            double* flops_out, amp_stream_t stream);
@@ -212,8 +214,10 @@ typedef struct {
    * disc_input receives v = clamp((amp_obs - mean) / den, -clip, clip) for the K*D columns in the layout
    * amp_disc_input_layout() reports (every field below comes from it; scaler_mean == NULL copies unscaled):
    *   AMP_DISC_INPUT_F32_ROWS   float       [N, disc_input_stride]   <- v
-   *   AMP_DISC_INPUT_F16_PAIRS  _Float16[2] [N, disc_input_stride]   <- {p0 = rn16(s v), p1 = rn16(s v - p0)}, s = disc_plane_scale
-   * (both 4 bytes per element, one store).  The padding columns are never written: zero the buffer once.  Feed it to
+   *   AMP_DISC_INPUT_F16_BLOCKS _Float16 [N, disc_input_stride / 32, 2, 32]: per row and k-block of 32 columns the plane
+   *                             p0 = rn16(s v) of the 32 columns, then the plane p1 = rn16(s v - p0), s = disc_plane_scale
+   *                             -- the 128-B "block layout" the GEMM kernels fill their LDS stages from
+   * (both 4 bytes per element).  The padding columns are never written: zero the buffer once.  Feed it to
    * amp_disc_style_reward_prescaled(). */
   void* disc_input;
   int64_t disc_input_stride;
@@ -328,17 +332,17 @@ enum { AMP_DISC_F16X3 = 0, AMP_DISC_FP32 = 1 };
 int amp_disc_set_precision(AmpDisc* h, int32_t mode, amp_stream_t stream);
 int64_t amp_disc_workspace_bytes(const AmpDisc* h, int64_t rows);
 /* Layout of the scaled input the GEMMs consume, for producers that write it directly (amp_env_step's fused scaler).
- * AMP_DISC_F16X3 with a clamping scaler consumes one (p0, p1) fp16 pair per element (the clamp bounds the plane
+ * AMP_DISC_F16X3 with a clamping scaler consumes the two fp16 planes in block layout (the clamp bounds the plane
  * scale); every other configuration consumes fp32 rows.  Device pointers stay valid until the next
  * amp_disc_set_scaler / destroy. */
-enum { AMP_DISC_INPUT_F32_ROWS = 0, AMP_DISC_INPUT_F16_PAIRS = 1 };
+enum { AMP_DISC_INPUT_F32_ROWS = 0, AMP_DISC_INPUT_F16_BLOCKS = 1 };
 typedef struct {
   int32_t format;          /* AMP_DISC_INPUT_* */
   int32_t padded_dim;      /* row length in elements: K*D zero-padded to the layer-1 k-tile; rows 16-B aligned */
   const float* mean_dev;   /* fp32 scaler vectors; NULL mean when no scaler is set */
   const float* den_dev;
   float clip;
-  float plane_scale;       /* F16_PAIRS: the power of two s with s * clip < 2^15 */
+  float plane_scale;       /* F16_BLOCKS: the power of two s with s * clip < 2^15 */
 } AmpDiscInputLayout;
 int amp_disc_input_layout(const AmpDisc* h, AmpDiscInputLayout* out);
 /* amp_obs_dev [rows, in_dim] (row stride in elements) -> logits [rows], style [rows] =
@@ -354,7 +358,7 @@ int amp_disc_style_reward(const AmpDisc* h, const float* amp_obs_dev, int64_t ro
                           amp_event_t inputs_consumed, amp_stream_t stream);
 
 /* Same as amp_disc_style_reward for an input that is already scaled, padded and in the layout amp_disc_input_layout()
- * reports (amp_env_step's disc_input; fp32 rows or fp16 pairs [rows, padded_dim], padding columns zero): skips the
+ * reports (amp_env_step's disc_input; fp32 rows or fp16 plane blocks, padding columns zero): skips the
  * scaler pass. */
 int amp_disc_style_reward_prescaled(const AmpDisc* h, const void* scaled_dev, int64_t rows, float reward_scale,
                                     const float* task_reward_dev, float task_weight, float style_weight,

@@ -133,8 +133,10 @@ def test_fused_scaler_matches_separate_pass(workload, envs):
         hot.synchronize()
         res[fused] = (outs[-1]["style"].clone(), outs[-1]["combined"].clone(), hot.kernel.amp_observation_buffer.clone())
         if fused:
-            xs = hot.kernel.disc_input
-            assert xs.shape[1] == kd or float(xs[:, kd:].abs().max()) == 0.0  # padding untouched
+            xs = hot.kernel.disc_input  # [N, padded / 32, 2, 32] plane blocks: column c = block c // 32, lane c % 32
+            flat = xs.permute(0, 2, 1, 3).reshape(xs.shape[0], 2, -1)  # [N, plane, padded]
+            assert flat.shape[2] == kd or float(flat[:, :, kd:].abs().max()) == 0.0  # padding untouched
+            assert float(flat[:, 0, :kd].abs().max()) > 0.0
     for a, b in zip(res[False], res[True]):
         assert torch.equal(a, b)
 
@@ -197,11 +199,13 @@ def test_gemm_engines_vs_fp64(precision, bar, in_dim, rows):
     lay = d.input_layout()
     xs = torch.zeros(rows, lay.padded_dim)
     xs[:, :in_dim] = odisc.scale_states(x, mean, var)
-    if lay.format == nat.AMP_DISC_INPUT_F16_PAIRS:
+    if lay.format == nat.AMP_DISC_INPUT_F16_BLOCKS:
         assert precision == "f16x3" and lay.plane_scale == 4096.0  # 4096 * clip(5) < 2^15
         v = xs * lay.plane_scale
         p0 = v.half()
-        xs = torch.stack([p0, (v - p0.float()).half()], dim=-1).contiguous()
+        p1 = (v - p0.float()).half()
+        # block layout: [rows, padded / 32, plane, 32]
+        xs = torch.stack([p0.view(rows, -1, 32), p1.view(rows, -1, 32)], dim=2).contiguous()
     pre = d.style_reward_prescaled(xs.cuda(), task.cuda(), want_logits=True)
     assert float((pre["logits"] - out["logits"]).abs().max()) <= bar * scale  # host-scaled vs device-scaled input
 

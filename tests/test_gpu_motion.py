@@ -37,11 +37,14 @@ def test_tables_and_meta(tag, loaders):
 @pytest.mark.parametrize("tag", list(gu.CLIPSETS))
 def test_frame_blend_bit_exact(tag, loaders):
     fx = gu.golden(f"frame_blend_{tag}")
+    # numpy in -> numpy out, like the reference's private helper (motion_loader.py:281-307)
     i0, i1, b = loaders[tag]._compute_frame_blend(fx["times"], fx["motion_ids"])
-    assert i0.dtype == torch.int64 and b.dtype == torch.float64
-    assert np.array_equal(i0.cpu().numpy(), fx["index_0"])
-    assert np.array_equal(i1.cpu().numpy(), fx["index_1"])
-    assert np.array_equal(b.cpu().numpy(), fx["blend"])
+    assert isinstance(i0, np.ndarray) and i0.dtype == np.int64 and i1.dtype == np.int64 and b.dtype == np.float64
+    assert np.array_equal(i0, fx["index_0"]) and np.array_equal(i1, fx["index_1"]) and np.array_equal(b, fx["blend"])
+    # device tensors in -> device tensors out (no host round trip), same bits
+    d0, d1, db = loaders[tag]._compute_frame_blend(torch.from_numpy(fx["times"]).cuda(), torch.from_numpy(fx["motion_ids"]).cuda())
+    assert d0.is_cuda and d0.dtype == torch.int64 and db.dtype == torch.float64
+    assert np.array_equal(d0.cpu().numpy(), i0) and np.array_equal(d1.cpu().numpy(), i1) and np.array_equal(db.cpu().numpy(), b)
 
 
 @pytest.mark.parametrize("tag", list(gu.CLIPSETS))

@@ -7,7 +7,7 @@
 
 namespace amp {
 
-// Args: A = activations, row pitch 2 * lda halves (MODE 0: lda pairs per row; MODE 1: block layout of lda values);
+// Args: A = activations in block layout, row pitch 2 * lda halves;
 // W = weights in block layout, row pitch 2 * Kp halves; MODE 0 output H in block layout, row pitch 2 * ldh halves.
 // XP != 0: ablations for tools/gemm_f16_bench.hip (wrong results): 1 = no fills in the loop, 2 = also no fragment reads,
 // 3 = MODE 0 without the global stores of the epilogue, 4 = MODE 0 epilogue only (one k-block), 5 = no ping-pong (free-running
@@ -62,11 +62,11 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN>::kWgPerCu)) void disc
   // chunk 4 pl + 2 s + lh.  Pair layout (MODE 0 activations): the lane's eight values are chunks 4 s + 2 lh, + 1.
   const int swz = (li >> 1) & 7;
   const int arow = (wm * (32 * TM) + li) * 128, brow = kOpA + (wn * (32 * TN) + li) * 128;
-  int ca[2][2], cb[2][2];  // [k-step][plane, or first / second chunk of the pairs] byte offsets inside a row
+  int ca[2][2], cb[2][2];  // [k-step][plane] byte offsets inside a row
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    ca[s][0] = ((MODE == 1 ? 2 * s + lh : 4 * s + 2 * lh) ^ swz) * 16;
-    ca[s][1] = ((MODE == 1 ? 4 + 2 * s + lh : 4 * s + 2 * lh + 1) ^ swz) * 16;
+    ca[s][0] = ((2 * s + lh) ^ swz) * 16;
+    ca[s][1] = ((4 + 2 * s + lh) ^ swz) * 16;
     cb[s][0] = ((2 * s + lh) ^ swz) * 16;
     cb[s][1] = ((4 + 2 * s + lh) ^ swz) * 16;
   }
@@ -83,20 +83,8 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN>::kWgPerCu)) void disc
   auto read_frags = [&](const unsigned char* sb, const int s) {
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
-      if (MODE == 1) {
-        x0[a] = *reinterpret_cast<const h8*>(sb + arow + a * 32 * 128 + ca[s][0]);
-        x1[a] = *reinterpret_cast<const h8*>(sb + arow + a * 32 * 128 + ca[s][1]);
-      } else {
-        const uv4 lo = *reinterpret_cast<const uv4*>(sb + arow + a * 32 * 128 + ca[s][0]);
-        const uv4 hi = *reinterpret_cast<const uv4*>(sb + arow + a * 32 * 128 + ca[s][1]);
-        uv4 q0, q1;
-        q0[0] = __builtin_amdgcn_perm(lo[1], lo[0], 0x05040100u); q1[0] = __builtin_amdgcn_perm(lo[1], lo[0], 0x07060302u);
-        q0[1] = __builtin_amdgcn_perm(lo[3], lo[2], 0x05040100u); q1[1] = __builtin_amdgcn_perm(lo[3], lo[2], 0x07060302u);
-        q0[2] = __builtin_amdgcn_perm(hi[1], hi[0], 0x05040100u); q1[2] = __builtin_amdgcn_perm(hi[1], hi[0], 0x07060302u);
-        q0[3] = __builtin_amdgcn_perm(hi[3], hi[2], 0x05040100u); q1[3] = __builtin_amdgcn_perm(hi[3], hi[2], 0x07060302u);
-        x0[a] = __builtin_bit_cast(h8, q0);
-        x1[a] = __builtin_bit_cast(h8, q1);
-      }
+      x0[a] = *reinterpret_cast<const h8*>(sb + arow + a * 32 * 128 + ca[s][0]);
+      x1[a] = *reinterpret_cast<const h8*>(sb + arow + a * 32 * 128 + ca[s][1]);
     }
 #pragma unroll
     for (int b = 0; b < TN; ++b) {

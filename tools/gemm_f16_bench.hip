@@ -10,6 +10,7 @@
 
 #include "../tools/experiments/disc_gemm_f16_dma4.hpp"
 #include "../tools/experiments/disc_gemm_f16_w4.hpp"
+#include "../tools/experiments/disc_gemm_f16_panel.hpp"
 #include "../tools/experiments/disc_gemm_f16_dma_xp.hpp"
 
 using namespace amp;
@@ -250,13 +251,15 @@ static bool g_dma_last = false;  // the last kernel run wrote H in block layout 
 template <int MODE, int XP = 0, int TM = 4, int TN = 2>
 static void run_dma(GemmF16Args g, int64_t M, int N, int K, bool quiet) {
   using T = DmaTile<TM, TN>;
-  if (MODE == 1) g.A = g_Ab;  // block layout; MODE 0 reads the (p0, p1) pairs as they are
+  if (MODE == 1) g.A = g_Ab;  // block layout (MODE 0: g.A already is)
   g.W = g_Wb;
   g_dma_last = true;
   g.n_tiles = N / T::BN;
   g.m_tiles = (int)((M + T::BM - 1) / T::BM);
   const unsigned grid = (unsigned)(((int64_t)g.m_tiles * g.n_tiles + 7) / 8 * 8);
-  auto kern = disc_gemm_f16_dma_xp_kernel<MODE, XP, TM, TN>;  // XP = 0 is the product schedule (tools/experiments copy)
+  // XP = 0: the PRODUCT kernel; XP != 0: the ablation copy under tools/experiments (round-1 epilogue)
+  void (*kern)(GemmF16Args) = disc_gemm_f16_dma_xp_kernel<MODE, XP, TM, TN>;
+  if (XP == 0) kern = disc_gemm_f16_dma_kernel<MODE, TM, TN>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, T::kLds));
   hipEvent_t a, b;
   CK(hipEventCreate(&a));
@@ -281,7 +284,7 @@ static void run_dma(GemmF16Args g, int64_t M, int N, int K, bool quiet) {
 
 template <int MODE, int NA, int NW>
 static void run_dma4(GemmF16Args g, int64_t M, int N, int K, bool quiet) {
-  if (MODE == 1) g.A = g_Ab;  // block layout; MODE 0 reads the (p0, p1) pairs as they are
+  if (MODE == 1) g.A = g_Ab;  // block layout (MODE 0: g.A already is)
   g.W = g_Wb;
   g_dma_last = true;
   g.n_tiles = N / kDma4BN;
@@ -339,11 +342,39 @@ static void run_w4(GemmF16Args g, int64_t M, int N, int K, bool quiet) {
   }
 }
 
+template <int KS, int TM>
+static void run_panel(GemmF16Args g, int64_t M, int N, int K, bool quiet) {
+  g.W = g_Wb;  // block layout weights; the activations (g.A) are in block layout already
+  g_dma_last = true;
+  const unsigned grid = (unsigned)((M + kPanelBM - 1) / kPanelBM);
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gemm_f16_panel_kernel<KS, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, kPanelLdsBytes));
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a));
+  CK(hipEventCreate(&b));
+  for (int i = 0; i < 3; ++i) disc_gemm_f16_panel_kernel<KS, TM><<<grid, panel_threads<TM>(), kPanelLdsBytes>>>(g);
+  CK(hipDeviceSynchronize());
+  const int reps = 10;
+  CK(hipEventRecord(a));
+  for (int i = 0; i < reps; ++i) disc_gemm_f16_panel_kernel<KS, TM><<<grid, panel_threads<TM>(), kPanelLdsBytes>>>(g);
+  CK(hipEventRecord(b));
+  CK(hipEventSynchronize(b));
+  float ms;
+  CK(hipEventElapsedTime(&ms, a, b));
+  g_us = ms * 1e3 / reps;
+  if (!quiet) {
+    const double tf = 2.0 * M * N * K / (g_us * 1e-6) / 1e12;
+    printf("PANEL 128 rows x N, %2d k-steps, 8-stage weight ring, %d waves of %dx64 per chunk  %8.1f us   %6.1f TF(alg)  %.3f of fp16 peak executed\n",
+           KS, panel_threads<TM>() / 64, 32 * TM, g_us, tf, 3 * tf / 2516.6);
+    fflush(stdout);
+  }
+}
+
 int main(int argc, char** argv) {
   const int64_t M = argc > 1 ? atoll(argv[1]) : 65536;
   const int N = argc > 2 ? atoi(argv[2]) : 512;
   const int K = argc > 3 ? atoi(argv[3]) : 1024;
   const int mode = N == 512 ? 1 : 0;
+  if (K % 32 != 0 || N % 256 != 0 || M % 256 != 0) { puts("need K % 32 == 0, N % 256 == 0, M % 256 == 0 (the kernels index whole k-blocks / tiles)"); return 1; }
   printf("f16-split GEMM M=%lld N=%d K=%d mode %d\n", (long long)M, N, K, mode);
   std::vector<float> hA((size_t)M * K), hW((size_t)N * K), hb(N), hw3(N);
   unsigned s = 12345;
@@ -386,7 +417,7 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(sc, &hr, sizeof(DiscRange), hipMemcpyHostToDevice));
   float s2[2] = {sa, sw};
   CK(hipMemcpy(one, s2, 8, hipMemcpyHostToDevice));
-  if (mode == 0) split_rows_pairs_kernel<<<(unsigned)((M * K / 4 + 255) / 256), 256>>>(A, M, K, K, one, (uint32_t*)Ap, K);
+  if (mode == 0) split_rows_blocks_kernel<<<(unsigned)((M * K / 4 + 255) / 256), 256>>>(A, M, K, K, one, Ap, K);  // the scaled input: block layout
   else split_rows_f16_kernel<<<(unsigned)((M * K / 4 + 255) / 256), 256>>>(A, M, K, K, one, Ap, K, M * K);
   split_rows_f16_kernel<<<(unsigned)(((int64_t)N * K / 4 + 255) / 256), 256>>>(W, N, K, K, one + 1, Wp, K, (int64_t)N * K);
   if (mode == 1) split_rows_blocks_kernel<<<(unsigned)((M * K / 4 + 255) / 256), 256>>>(A, M, K, K, one, Ab, K);
@@ -522,6 +553,13 @@ int main(int argc, char** argv) {
       V(2, 1, 32, 3, 1); check(N / 64);
       V(1, 2, 32, 3, 1); check(N / 128);
       V(2, 1, 64, 3, 1); check(N / 64);
+    }
+    return 0;
+  }
+  if (getenv("PANEL") && mode == 0) {
+    for (int rep = 0; rep < 3; ++rep) {
+      if (K == 192) { run_panel<12, 2>(g, M, N, K, false); check(0); run_panel<12, 1>(g, M, N, K, false); check(0); }
+      run_dma<0, 0, 4, 2>(g, M, N, K, false); check(0);
     }
     return 0;
   }
