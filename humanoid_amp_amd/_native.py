@@ -56,7 +56,8 @@ class AmpHotStepArgs(C.Structure):
                 ("times", C.c_void_p), ("motion_ids", C.c_void_p), ("n_samples", C.c_int64), ("K", C.c_int32), ("reserved", C.c_int32),
                 ("expert_out", C.c_void_p), ("disc", C.c_void_p), ("reward_scale", C.c_float), ("task_weight", C.c_float),
                 ("style_weight", C.c_float), ("reserved2", C.c_int32), ("logits", C.c_void_p), ("style", C.c_void_p),
-                ("combined", C.c_void_p), ("workspace", C.c_void_p), ("compact", C.c_void_p)]
+                ("combined", C.c_void_p), ("workspace", C.c_void_p), ("compact", C.c_void_p), ("disc_stream", C.c_void_p),
+                ("wait_before_env", C.c_void_p), ("env_done", C.c_void_p), ("disc_done", C.c_void_p)]
 
 
 class AmpCommandArgs(C.Structure):

@@ -12,6 +12,9 @@ int amp_hot_step(const AmpHotStepArgs* a, amp_stream_t stream) {
   AMP_REQUIRE(a && a->cfg && a->state && a->bufs && a->disc && a->compact, "amp_hot_step: null argument");
   AMP_REQUIRE(a->bufs->disc_input && a->bufs->reward, "amp_hot_step: the env buffers need disc_input (fused scaler) and reward");
   int rc;
+  const bool two = a->disc_stream != nullptr;
+  AMP_REQUIRE(!two || (a->env_done && a->disc_done), "amp_hot_step: the two-stream schedule needs env_done and disc_done events");
+  if (two && a->wait_before_env) AMP_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)a->wait_before_env, 0));
   if (a->motion) {
     rc = amp_env_step_with_reference(a->cfg, a->state, a->bufs, a->num_envs, AMP_PHASE_DONES | AMP_PHASE_REWARD | AMP_PHASE_OBS, a->motion,
                                      a->times, a->motion_ids, a->n_samples, a->K, a->expert_out, stream);
@@ -19,9 +22,17 @@ int amp_hot_step(const AmpHotStepArgs* a, amp_stream_t stream) {
     rc = amp_env_step(a->cfg, a->state, a->bufs, a->num_envs, AMP_PHASE_DONES | AMP_PHASE_REWARD | AMP_PHASE_OBS, stream);
   }
   if (rc != AMP_OK) return rc;
-  return amp_disc_style_reward_prescaled_compact(a->disc, a->bufs->disc_input, a->num_envs, a->reward_scale, a->bufs->reward,
+  amp_stream_t ds = stream;
+  if (two) {
+    AMP_HIP(hipEventRecord((hipEvent_t)a->env_done, (hipStream_t)stream));
+    AMP_HIP(hipStreamWaitEvent((hipStream_t)a->disc_stream, (hipEvent_t)a->env_done, 0));
+    ds = a->disc_stream;
+  }
+  rc = amp_disc_style_reward_prescaled_compact(a->disc, a->bufs->disc_input, a->num_envs, a->reward_scale, a->bufs->reward,
                                                  a->task_weight, a->style_weight, a->logits, a->style, a->combined, a->workspace,
-                                                 a->compact, stream);
+                                                 a->compact, ds);
+  if (rc == AMP_OK && two) AMP_HIP(hipEventRecord((hipEvent_t)a->disc_done, (hipStream_t)a->disc_stream));
+  return rc;
 }
 
 }  // extern "C"

@@ -408,6 +408,17 @@ typedef struct {
   float* combined;              /* dev [num_envs] or NULL */
   void* workspace;              /* amp_disc_workspace_bytes(disc, num_envs) */
   const AmpCompactArgs* compact;
+  /* Optional two-stream schedule (all four NULL = everything on `stream`): the discriminator half runs on disc_stream so
+   * that the NEXT step's env launch (latency-bound on a small shard) executes under this step's GEMMs.  The caller
+   * double-buffers what the two halves hand over (bufs->disc_input / reward / reset mask + tile counts, compact outputs,
+   * style / combined) by step parity and passes, per parity, two events:
+   *   env launch:   waits wait_before_env (the disc_done of the step that last used this parity's buffers; NULL on the
+   *                 first use), then records env_done on `stream`;
+   *   disc launches: disc_stream waits env_done, runs layer 1 / layer 2 / tail, records disc_done. */
+  amp_stream_t disc_stream;
+  amp_event_t wait_before_env;
+  amp_event_t env_done;
+  amp_event_t disc_done;
 } AmpHotStepArgs;
 int amp_hot_step(const AmpHotStepArgs* args, amp_stream_t stream);
 

@@ -8,9 +8,11 @@ from humanoid_amp_amd.workloads import WORKLOADS, HotPath
 
 envs = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
-graph = (sys.argv[3] if len(sys.argv) > 3 else "graph") == "graph"
+mode = sys.argv[3] if len(sys.argv) > 3 else "graph"   # graph | eager | two (two-stream schedule of amp_hot_step)
+graph = mode == "graph"
 with contextlib.redirect_stdout(io.StringIO()):
-    hot = HotPath(WORKLOADS[sys.argv[4] if len(sys.argv) > 4 else "g1_walk"], envs, "cuda:0", seed=1, state_sets=3)
+    hot = HotPath(WORKLOADS[sys.argv[4] if len(sys.argv) > 4 else "g1_walk"], envs, "cuda:0", seed=1, state_sets=3,
+                  two_streams=mode == "two")
 if graph:
     hot.capture()
 for _ in range(50):
@@ -20,4 +22,4 @@ t0 = time.perf_counter()
 for _ in range(steps):
     hot.step()
 torch.cuda.synchronize()
-print(f"{envs} envs, {'graph' if graph else 'eager'}: {(time.perf_counter() - t0) / steps * 1e6:.1f} us / step")
+print(f"{envs} envs, {mode}: {(time.perf_counter() - t0) / steps * 1e6:.1f} us / step")
