@@ -2,6 +2,7 @@
 #include "amp_common.hpp"
 
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -22,11 +23,13 @@ std::vector<TraceRec> g_recs;   // capacity fixed at amp_trace_begin: events are
 int64_t g_used = 0;
 bool g_on = false;
 std::string g_filter;
+std::mutex g_mu;  // launches may come from several host threads (one per stream): record slots are handed out under it
 }  // namespace
 
 bool trace_enabled() { return g_on; }
 
 int trace_open(const char* kernel, hipStream_t st) {
+  std::lock_guard<std::mutex> lock(g_mu);
   if (!g_on || g_used >= (int64_t)g_recs.size()) return -1;
   if (!g_filter.empty() && std::strstr(kernel, g_filter.c_str()) == nullptr) return -1;
   const int i = (int)g_used++;
@@ -43,6 +46,7 @@ extern "C" {
 int amp_trace_begin(int64_t capacity, const char* filter) {
   using namespace amp;
   if (capacity < 0 || capacity > (1 << 20)) return fail(AMP_ERR_INVALID, "amp_trace_begin: capacity out of range");
+  std::lock_guard<std::mutex> lock(g_mu);
   g_on = false;
   for (auto& r : g_recs) {
     (void)hipEventDestroy(r.start);
@@ -62,6 +66,7 @@ int amp_trace_begin(int64_t capacity, const char* filter) {
 }
 
 int amp_trace_end(void) {
+  std::lock_guard<std::mutex> lock(amp::g_mu);
   amp::g_on = false;
   return AMP_OK;
 }

@@ -307,7 +307,11 @@ int gemm_nt(hipStream_t st, const float* A, int64_t lda, int64_t M, const float*
   GemmArgs g{};
   g.A = A; g.lda = lda; g.M = M; g.K = Kp; g.W = W; g.Kp = Kp; g.N = N; g.C = C; g.ldc = ldc;
   g.mask = mask; g.ldmask = ldmask; g.accumulate = accumulate;
-  g.n_tiles = N / 64; g.m_tiles = (int)((M + 63) / 64);
+  // 128 x 128 tiles (0.8+ of the fp32 matrix peak) when they still give every CU two workgroups, else 64 x 64
+  // (tools/gemm_bench.hip, profiles/r01_gemm_variants.txt); the element arithmetic does not depend on the tile
+  const bool big = !split && N % 128 == 0 && (M + 127) / 128 * (N / 128) >= 512;
+  const int bt = big ? 128 : 64;
+  g.n_tiles = N / bt; g.m_tiles = (int)((M + bt - 1) / bt);
   const int tiles = g.m_tiles * g.n_tiles, nk = Kp / 16;
   int slices = 1;
   if (split && !mask) {
@@ -319,7 +323,8 @@ int gemm_nt(hipStream_t st, const float* A, int64_t lda, int64_t M, const float*
   const unsigned grid = (unsigned)(((int64_t)tiles * slices + 7) / 8 * 8);
   {
     amp::TraceScope trace__("disc_gemm_kernel<2>", st);
-    disc_gemm_kernel<64, 64, 16, 1, 2, 4><<<grid, kBlock, 0, st>>>(g);
+    if (big) disc_gemm_kernel<128, 128, 16, 1, 2, 4><<<grid, kBlock, 0, st>>>(g);
+    else disc_gemm_kernel<64, 64, 16, 1, 2, 4><<<grid, kBlock, 0, st>>>(g);
   }
   int rc = launch_status("disc_gemm_kernel<2>");
   if (rc != AMP_OK || slices == 1) return rc;
@@ -331,10 +336,13 @@ int gemm_nt(hipStream_t st, const float* A, int64_t lda, int64_t M, const float*
 int gemm_fwd(hipStream_t st, const float* A, int64_t lda, int64_t M, const float* W, int Kp, int N, const float* bias, float* C) {
   GemmArgs g{};
   g.A = A; g.lda = lda; g.M = M; g.K = Kp; g.W = W; g.Kp = Kp; g.bias = bias; g.N = N; g.C = C; g.ldc = N;
-  g.n_tiles = N / 64; g.m_tiles = (int)((M + 63) / 64);
+  const bool big = N % 128 == 0 && (M + 127) / 128 * (N / 128) >= 512;
+  const int bt = big ? 128 : 64;
+  g.n_tiles = N / bt; g.m_tiles = (int)((M + bt - 1) / bt);
   const unsigned grid = (unsigned)(((int64_t)g.m_tiles * g.n_tiles + 7) / 8 * 8);
   amp::TraceScope trace__("disc_gemm_kernel<0>", st);
-  disc_gemm_kernel<64, 64, 16, 1, 0, 8><<<grid, kBlock, 0, st>>>(g);
+  if (big) disc_gemm_kernel<128, 128, 16, 1, 0, 4><<<grid, kBlock, 0, st>>>(g);
+  else disc_gemm_kernel<64, 64, 16, 1, 0, 8><<<grid, kBlock, 0, st>>>(g);
   return launch_status("disc_gemm_kernel<0>");
 }
 

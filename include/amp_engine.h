@@ -49,7 +49,8 @@ int amp_device_name(char* buf, int64_t buf_len);
  * Kernel tracer (the reference has none: train.py:281,300 only wraps the whole run in time.time()).
  * While tracing is on, every kernel launch whose name contains `filter` (NULL / "" = all) is bracketed by a
  * pair of HIP events on its own stream.  Read the durations after synchronising those streams.
- * Not thread-safe; do not toggle while another thread is launching.
+ * Record slots are handed out under a mutex (launches may come from several host threads); begin / end are meant
+ * to be called from one controlling thread.
  * ------------------------------------------------------------------------------------------------ */
 int amp_trace_begin(int64_t capacity, const char* filter);
 int amp_trace_end(void);                 /* stop recording (records stay readable until the next begin) */
