@@ -49,6 +49,7 @@ BASELINE_CONFIG = {("g1_walk", 65536, 1): "configs[4] on 1 GPU", ("g1_walk", 655
 # back to back (rocprofv3: gaps <= 0.6 us), while a graph replay pays ~8.5 us between replays (profiles/r02_small_shard_gaps.md):
 # 8 192 envs 63.6 us eager vs 67.7 us replayed, 4 096 envs 48.7 vs 53.2
 GRAPH_MAX_ENVS = 16384       # --graph replays shards up to this size as one hipGraph
+TRACE_EVERY = 5              # large shards: every 5th discriminator-GEMM launch of the timed region carries an event pair
 
 
 def parse_args():
@@ -335,22 +336,21 @@ def main():
         # and the dominant kernel is timed in an eager traced pass of the same steps right after it
         dt = timed_steps(hot, args.steps, args.warmup, world, collective)
         hot._graphs = None  # eager launches for the traced pass
+        trace_every = 1
         with nat.KernelTrace(capacity=8 * (args.steps + args.warmup) + 8, kernel_filter=dominant_filter) as tr:
             for _ in range(args.steps + args.warmup):
                 hot.step()
         timing = ("eager traced pass of the same steps right after the timed region (small shard: the timed region itself runs "
                   "untraced" + (", as a hipGraph replay)" if use_graph else ")"))
     else:
-        with nat.KernelTrace(capacity=8 * (args.steps + args.warmup) + 8, kernel_filter=dominant_filter) as tr:
+        # an event pair is a barrier packet on the queue (~4 us each, measured: every launch bracketed costs a 356-us step
+        # 18 us): bracket every TRACE_EVERY-th discriminator GEMM launch (coprime with the 2 or 4 launches of a step, so
+        # both layers and every chunk are visited) -- still live, inside the timed region, on the launching stream
+        trace_every = TRACE_EVERY
+        with nat.KernelTrace(capacity=8 * (args.steps + args.warmup) + 8, kernel_filter=dominant_filter, every=trace_every) as tr:
             dt = timed_steps(hot, args.steps, args.warmup, world, collective)
-        timing = "HIP events around every launch of the kernel inside the timed region"
-    # the engine may run a large shard as several row chunks: launches per step = records / steps over the timed region
-    allrecs = [r for r in tr.records() if r[0].endswith("<1>")]  # layer 2
-    if allrecs:
-        dominant = allrecs[-1][0]
-    per_step = max(1, round(len(allrecs) / (args.steps + args.warmup)))
-    recs = allrecs[-args.steps * per_step:]
-    gemm2_ms = sum(ms for _, ms in recs) / max(len(recs), 1)
+        timing = (f"HIP events around every {trace_every}th discriminator-GEMM launch inside the timed region (layer-2 launches of "
+                  "the timed steps averaged)")
     value = global_envs * args.steps / dt
     n_sets = len(hot.states)
     # ---- per-kernel picture of one step (all kernels traced, eager; outside the timed region, clocks settled) -----
@@ -358,7 +358,18 @@ def main():
     with nat.KernelTrace(capacity=16 * 16) as tr_all:
         for _ in range(16):
             hot.step()
-    per_kernel = {k: round(t / 16 * 1e3, 2) for k, (c, t) in tr_all.summary().items()}  # us per step (all launches of the kernel)
+    summary_all = tr_all.summary()
+    per_kernel = {k: round(t / 16 * 1e3, 2) for k, (c, t) in summary_all.items()}  # us per step (all launches of the kernel)
+    # the engine may run a large shard as several row chunks: layer-2 launches per step, from the all-kernel pass
+    allrecs = [r for r in tr.records() if r[0].endswith("<1>")]  # layer 2
+    if allrecs:
+        dominant = allrecs[-1][0]
+    per_step = max(1, round(sum(c for k, (c, t) in summary_all.items() if k.endswith("<1>") and dominant_filter in k) / 16))
+    if trace_every == 1:
+        recs = allrecs[-args.steps * per_step:]                        # small shards: traced pass = warmup + steps
+    else:
+        recs = allrecs[len(allrecs) * args.warmup // (args.steps + args.warmup):]  # samples of the timed steps
+    gemm2_ms = sum(ms for _, ms in recs) / max(len(recs), 1)
 
     out = None
     sustained = None

@@ -148,6 +148,7 @@ SIGNATURES = {
     "amp_last_error": (C.c_char_p, []),
     "amp_device_name": (C.c_int, [C.c_char_p, _i64]),
     "amp_trace_begin": (C.c_int, [_i64, C.c_char_p]),
+    "amp_trace_sample": (C.c_int, [_i64]),
     "amp_trace_end": (C.c_int, []),
     "amp_trace_count": (_i64, []),
     "amp_trace_get": (C.c_int, [_i64, C.c_char_p, _i64, C.POINTER(C.c_float)]),
@@ -281,11 +282,14 @@ class KernelTrace:
     >>> tr.summary()   # {name: (calls, total_ms)} -- synchronises the current device first
     """
 
-    def __init__(self, capacity: int = 4096, kernel_filter: str | None = None):
-        self.capacity, self.filter = int(capacity), kernel_filter
+    def __init__(self, capacity: int = 4096, kernel_filter: str | None = None, every: int = 1):
+        """``every`` > 1: bracket only every ``every``-th matching launch (``amp_trace_sample``)."""
+        self.capacity, self.filter, self.every = int(capacity), kernel_filter, int(every)
 
     def __enter__(self):
         check(load().amp_trace_begin(self.capacity, self.filter.encode() if self.filter else None), "amp_trace_begin")
+        if self.every > 1:
+            check(load().amp_trace_sample(self.every), "amp_trace_sample")
         return self
 
     def __exit__(self, *exc):

@@ -24,6 +24,7 @@ int64_t g_used = 0;
 bool g_on = false;
 std::string g_filter;
 std::mutex g_mu;  // launches may come from several host threads (one per stream): record slots are handed out under it
+int64_t g_every = 1, g_seen = 0;  // sampling: only every g_every-th matching launch is bracketed (amp_trace_sample)
 }  // namespace
 
 bool trace_enabled() { return g_on; }
@@ -32,6 +33,7 @@ int trace_open(const char* kernel, hipStream_t st) {
   std::lock_guard<std::mutex> lock(g_mu);
   if (!g_on || g_used >= (int64_t)g_recs.size()) return -1;
   if (!g_filter.empty() && std::strstr(kernel, g_filter.c_str()) == nullptr) return -1;
+  if (g_every > 1 && (g_seen++ % g_every) != 0) return -1;  // an event pair costs the queue a few us: sample
   const int i = (int)g_used++;
   g_recs[i].name = kernel;
   (void)hipEventRecord(g_recs[i].start, st);
@@ -61,7 +63,18 @@ int amp_trace_begin(int64_t capacity, const char* filter) {
       return fail(AMP_ERR_HIP, "amp_trace_begin: hipEventCreate failed");
   }
   g_filter = filter ? filter : "";
+  g_every = 1;
+  g_seen = 0;
   g_on = capacity > 0;
+  return AMP_OK;
+}
+
+int amp_trace_sample(int64_t every) {
+  using namespace amp;
+  if (every < 1) return fail(AMP_ERR_INVALID, "amp_trace_sample: every must be >= 1");
+  std::lock_guard<std::mutex> lock(g_mu);
+  g_every = every;
+  g_seen = 0;
   return AMP_OK;
 }
 

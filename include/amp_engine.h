@@ -53,6 +53,9 @@ int amp_device_name(char* buf, int64_t buf_len);
  * to be called from one controlling thread.
  * ------------------------------------------------------------------------------------------------ */
 int amp_trace_begin(int64_t capacity, const char* filter);
+/* Bracket only every `every`-th matching launch from now on (1 = all; reset to 1 by amp_trace_begin): an event pair
+ * costs the queue a few microseconds, which a timed region of 300-us steps notices (bench.py samples its dominant kernel). */
+int amp_trace_sample(int64_t every);
 int amp_trace_end(void);                 /* stop recording (records stay readable until the next begin) */
 int64_t amp_trace_count(void);
 /* name and duration in milliseconds of record i; AMP_ERR_HIP if its events have not completed yet */
