@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libamp_engine.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 AMP_DISC_F16X3, AMP_DISC_FP32 = 0, 1
 AMP_DISC_INPUT_F32_ROWS, AMP_DISC_INPUT_F16_BLOCKS = 0, 1
@@ -172,7 +172,7 @@ SIGNATURES = {
     "amp_reset_compact_workspace_bytes": (_i64, [_i64]),
     "amp_reset_compact": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "amp_reset_compact_tiles": (C.c_int, [_vp, _vp, _i32, _i64, _vp, _vp, _vp]),
-    "amp_env_step_tile_envs": (_i32, [_i64]),
+    "amp_env_step_tile_envs": (_i32, [C.POINTER(AmpEnvCfg), _i64]),
     "amp_disc_create": (C.c_int, [C.POINTER(AmpDiscDesc), _vp, C.POINTER(_vp)]),
     "amp_disc_destroy": (C.c_int, [_vp]),
     "amp_disc_set_weights": (C.c_int, [_vp, C.POINTER(AmpDiscDesc), _vp]),

@@ -49,7 +49,7 @@ int amp_reset_compact_tiles(const uint8_t* mask, const int32_t* counts, int32_t 
     return AMP_OK;
   }
   AMP_REQUIRE(mask && counts && ids, "amp_reset_compact: null buffer");
-  AMP_REQUIRE(tile_envs == 16 || tile_envs == 32 || tile_envs == 64, "amp_reset_compact: tile_envs must be 16, 32 or 64");
+  AMP_REQUIRE(tile_envs == 8 || tile_envs == 16 || tile_envs == 32 || tile_envs == 64, "amp_reset_compact: tile_envs must be 8, 16, 32 or 64");
   const int sub = kTile / tile_envs;
   const int64_t n_counts = (N + tile_envs - 1) / tile_envs;
   const int64_t n_tiles = (N + kTile - 1) / kTile;

@@ -6,7 +6,7 @@ namespace amp {
 
 constexpr int kTile = 64;
 
-// counts[] holds one entry per `64 / sub` envs (sub = 1, 2 or 4 count entries per 64-env wave tile).  `block` = index of
+// counts[] holds one entry per `64 / sub` envs (sub = 1, 2, 4 or 8 count entries per 64-env wave tile).  `block` = index of
 // the 4-tile group this 256-thread workgroup owns.
 __device__ __forceinline__ void compact_scatter_body(const int64_t block, const uint8_t* __restrict__ mask,
                                                      const int32_t* __restrict__ counts, int64_t N, int64_t n_tiles, int sub,

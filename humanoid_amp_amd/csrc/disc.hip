@@ -750,7 +750,7 @@ int amp_disc_style_reward_prescaled_compact(const AmpDisc* h, const void* xs_any
                                             void* workspace, const AmpCompactArgs* c, amp_stream_t stream) {
   AMP_REQUIRE(h && c, "amp_disc_style_reward_prescaled_compact: null argument");
   AMP_REQUIRE(c->num_envs >= 1 && c->mask && c->tile_counts && c->ids && c->count, "amp_disc_style_reward_prescaled_compact: null compaction buffer");
-  AMP_REQUIRE(c->tile_envs == 16 || c->tile_envs == 32 || c->tile_envs == 64, "amp_disc_style_reward_prescaled_compact: tile_envs must be 16, 32 or 64");
+  AMP_REQUIRE(c->tile_envs == 8 || c->tile_envs == 16 || c->tile_envs == 32 || c->tile_envs == 64, "amp_disc_style_reward_prescaled_compact: tile_envs must be 8, 16, 32 or 64");
   AMP_REQUIRE(rows >= 1, "amp_disc_style_reward_prescaled_compact: needs at least one row");
   CompactLaunch cl;
   cl.mask = c->mask; cl.counts = c->tile_counts; cl.N = c->num_envs;

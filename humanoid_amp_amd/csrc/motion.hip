@@ -143,6 +143,14 @@ __global__ __launch_bounds__(kBlock) void collect_reference_kernel(MotionView v,
   collect_reference_body(v, times, ids, n, K, out, dst_rows, n_dev, (int64_t)blockIdx.x, s_img);
 }
 
+// the hot-path form (contiguous rows, < 2^31 samples): 256-sample workgroups, see collect_reference_wide_body
+__global__ __launch_bounds__(kBlock) void collect_reference_wide_kernel(MotionView v, const double* __restrict__ times,
+                                                                        const int64_t* __restrict__ ids, int64_t n, int K,
+                                                                        float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float s_img[];
+  collect_reference_wide_body(v, times, ids, n, K, out, (int64_t)blockIdx.x, s_img);
+}
+
 // ------------------------------------------------------------------------------------------------
 // reference-state init of reset envs (g1_amp_env.py:385-411)
 // ------------------------------------------------------------------------------------------------
@@ -391,7 +399,10 @@ int amp_collect_reference(const AmpMotion* h, const double* times, const int64_t
   if (n == 0) return AMP_OK;
   AMP_REQUIRE(times && out, "amp_collect_reference: null buffer");
   { amp::TraceScope trace__("collect_reference_kernel", (hipStream_t)stream);
-    collect_reference_kernel<<<grid_for(n * K, kExpertTile), kBlock, expert_lds(h->v.D), (hipStream_t)stream>>>(h->v, times, ids, n, K, out, dst_rows, nullptr);
+    if (!dst_rows && n * K < (int64_t)1 << 31 && expert_wide_lds(h->v.D) <= 64 * 1024)
+      collect_reference_wide_kernel<<<grid_for(n * K, kExpertWide), kBlock, expert_wide_lds(h->v.D), (hipStream_t)stream>>>(h->v, times, ids, n, K, out);
+    else
+      collect_reference_kernel<<<grid_for(n * K, kExpertTile), kBlock, expert_lds(h->v.D), (hipStream_t)stream>>>(h->v, times, ids, n, K, out, dst_rows, nullptr);
   }
   return launch_status("collect_reference_kernel");
 }

@@ -172,6 +172,125 @@ __device__ __forceinline__ void collect_reference_body(const MotionView& v, cons
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wide tile body of the same sample (contiguous output rows, fewer than 2^31 samples: the hot path).  The body above
+// spends a 64-sample workgroup's life in phase A's dependent chain (times -> clip table -> two row gathers -> SLERP)
+// on one wave, and ~90 VALU instructions per 16 B of phase B on row/column arithmetic and per-column branches.  Here
+//   * a workgroup owns 256 samples: phase A runs once, one sample per lane on all four waves;
+//   * the 256 samples go through the LDS image in four 64-sample passes.  In phase B a lane owns ONE quad of columns
+//     (its gather offset, which of its columns are key-body columns, where they land) and walks the pass's samples:
+//     the key-body subtraction reads a per-sample strip {0,0,0,0, rp, rp} at a per-lane offset (non-key columns
+//     subtract +0.0f, which changes no bit), and the seven SLERP-derived columns are redirected to a scratch word
+//     and filled from phase A's values by a separate 448-element pass -- no per-column branch in the loop.
+// Bit-identical to collect_reference_body (tests/test_gpu_motion.py).
+// ------------------------------------------------------------------------------------------------
+constexpr int kExpertWide = 256;
+constexpr int kExpertStrip = 11;  // floats per sample of the subtraction strip (10 used; odd pitch)
+
+__host__ __device__ inline int expert_wide_lds_floats(int D) {
+  return ((kExpertTile * D + 3) & ~3) + kExpertWide * 4 + kExpertWide * kExpertStrip + kExpertWide * 7 + 4;
+}
+
+__device__ __forceinline__ void collect_reference_wide_body(const MotionView& v, const double* __restrict__ times,
+                                                            const int64_t* __restrict__ ids, int64_t n, int K,
+                                                            float* __restrict__ out, int64_t block, float* smem) {
+  const int D = v.D, HP = v.HP, nd2 = 2 * v.n_dof, QP = HP >> 2;
+  const int tid = threadIdx.x;
+  float* s_img = smem;                                   // [64][D] output image of one pass
+  float* s_slot = s_img + ((kExpertTile * D + 3) & ~3);  // [256][4] i0 | i1 | blend | -
+  float* s_strip = s_slot + kExpertWide * 4;             // [256][11] 0 0 0 0 | rp | rp
+  float* s_tn = s_strip + kExpertWide * kExpertStrip;    // [256][7] height | tangent | normal
+  float* s_trash = s_tn + kExpertWide * 7;               // [4]
+  const int64_t total = n * K;
+  const int64_t tile_base = block * kExpertWide;
+  if (tile_base >= total) return;  // uniform for the whole workgroup
+  const int n_tile = (int)((total - tile_base) < kExpertWide ? (total - tile_base) : kExpertWide);
+  const float* __restrict__ hot = v.hot;
+  // ---- phase A: one sample per lane (fp64 frame/blend, SLERP of the reference quaternion, tangent/normal) -------
+  if (tid < n_tile) {
+    const uint32_t sidx = (uint32_t)(tile_base + tid);  // total < 2^31 (host)
+    const uint32_t r = sidx / (uint32_t)K;
+    const int k = (int)(sidx - r * (uint32_t)K);
+    const double t = times[r] - v.clips.dt * (double)k;  // history time t - dt*k in fp64 (g1_amp_env.py:454-457)
+    int64_t a, b;
+    double w;
+    frame_blend_ref(v.clips, t, ids ? ids[r] : 0, a, b, w);
+    const float blend = (float)w;
+    const float* r0 = hot + a * HP + nd2;
+    const float* r1 = hot + b * HP + nd2;
+    const float p0 = lerp_ref(r0[0], r1[0], blend), p1 = lerp_ref(r0[1], r1[1], blend), p2 = lerp_ref(r0[2], r1[2], blend);
+    const Quat q = slerp_ref(Quat{r0[3], r0[4], r0[5], r0[6]}, Quat{r1[3], r1[4], r1[5], r1[6]}, blend);
+    const Vec3 tg = quat_apply_ref(q, Vec3{1.0f, 0.0f, 0.0f});
+    const Vec3 nm = quat_apply_ref(q, Vec3{0.0f, 0.0f, 1.0f});
+    f4 sl;
+    sl[0] = __int_as_float((int32_t)a); sl[1] = __int_as_float((int32_t)b); sl[2] = blend; sl[3] = 0.0f;
+    *reinterpret_cast<f4*>(s_slot + tid * 4) = sl;
+    float* st = s_strip + tid * kExpertStrip;
+    st[0] = 0.0f; st[1] = 0.0f; st[2] = 0.0f; st[3] = 0.0f;
+    st[4] = p0; st[5] = p1; st[6] = p2; st[7] = p0; st[8] = p1; st[9] = p2;
+    float* tn = s_tn + tid * 7;
+    tn[0] = p2;  // root height = lerped z
+    tn[1] = tg.x; tn[2] = tg.y; tn[3] = tg.z; tn[4] = nm.x; tn[5] = nm.y; tn[6] = nm.z;
+  }
+  __syncthreads();
+  // ---- per-lane constants of phase B: the quad this lane owns --------------------------------------------
+  const int G = kBlock / QP, g = (int)(((float)tid + 0.5f) * (1.0f / (float)QP)), q = tid - g * QP;
+  const bool walker = g < G;
+  const int j0 = 4 * q, jk = nd2 + 13;  // first key-body column (:552)
+  const int strip0 = j0 + 3 < jk ? 0 : (j0 >= jk ? 4 + (j0 - jk) % 3 : 4 - (jk - j0));
+  int woff[4], wstep[4];  // float offsets from smem: where column j0 + c lands / how far it moves per sample step
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int j = j0 + c;
+    const bool keep = j < D && !(j >= nd2 && j <= nd2 + 6);
+    woff[c] = keep ? g * D + j : (int)(s_trash - smem) + c;
+    wstep[c] = keep ? G * D : 0;
+  }
+  const f4* __restrict__ hot4 = reinterpret_cast<const f4*>(hot);
+#pragma unroll 1
+  for (int u = 0; u < n_tile; u += kExpertTile) {
+    const int n_sub = n_tile - u < kExpertTile ? n_tile - u : kExpertTile;
+    if (walker) {
+      float* w0 = smem + woff[0]; float* w1 = smem + woff[1]; float* w2 = smem + woff[2]; float* w3 = smem + woff[3];
+      const float* slot = s_slot + (u + g) * 4;
+      const float* strip = s_strip + (u + g) * kExpertStrip + strip0;
+#pragma unroll 2
+      for (int s = g; s < n_sub; s += G) {
+        const f4 sl = *reinterpret_cast<const f4*>(slot);
+        const f4 a = hot4[(int64_t)__float_as_int(sl[0]) * QP + q];
+        const f4 b = hot4[(int64_t)__float_as_int(sl[1]) * QP + q];
+        const float t = sl[2];
+        // lerp_ref, then the key-body columns relative to the reference body (:552); others subtract +0.0f
+        *w0 = lerp_ref(a[0], b[0], t) - strip[0];
+        *w1 = lerp_ref(a[1], b[1], t) - strip[1];
+        *w2 = lerp_ref(a[2], b[2], t) - strip[2];
+        *w3 = lerp_ref(a[3], b[3], t) - strip[3];
+        w0 += wstep[0]; w1 += wstep[1]; w2 += wstep[2]; w3 += wstep[3];
+        slot += G * 4;
+        strip += G * kExpertStrip;
+      }
+    }
+    for (int e = tid; e < n_sub * 7; e += kBlock) {  // the SLERP-derived columns nd2 .. nd2 + 6
+      const int s = (int)(((float)e + 0.5f) * (1.0f / 7.0f)), k = e - 7 * s;
+      s_img[s * D + nd2 + k] = s_tn[(u + s) * 7 + k];
+    }
+    __syncthreads();
+    // ---- stream the pass's image out: rows of consecutive samples are one contiguous run ------------------
+    float* dst = out + (tile_base + u) * D;
+    const int count = n_sub * D;
+    if ((count & 3) == 0 && (((uintptr_t)dst) & 15) == 0) {
+      const f4* src4 = reinterpret_cast<const f4*>(s_img);
+      f4* dst4 = reinterpret_cast<f4*>(dst);
+      for (int e = tid; e < (count >> 2); e += kBlock) dst4[e] = src4[e];
+    } else {
+      for (int e = tid; e < count; e += kBlock) dst[e] = s_img[e];
+    }
+    __syncthreads();  // the image is free for the next pass
+  }
+}
+
+static inline size_t expert_wide_lds(int D) { return sizeof(float) * (size_t)expert_wide_lds_floats(D); }
+
 static inline size_t expert_lds(int D) { return sizeof(float) * (size_t)((kExpertTile * D + 3) & ~3) + sizeof(ExpertSlot) * kExpertTile; }
 
 }  // namespace amp

@@ -97,7 +97,7 @@ class EnvStepKernel:
         self.died = torch.zeros(N, dtype=torch.bool, device=dev)
         self.time_out = torch.zeros(N, dtype=torch.bool, device=dev)
         self.reset_mask = torch.zeros(N, dtype=torch.bool, device=dev)
-        self.tile_envs = int(self._lib.amp_env_step_tile_envs(N))
+        self.tile_envs = int(self._lib.amp_env_step_tile_envs(C.byref(self._c), N))
         self.reset_tile_counts = torch.zeros((N + self.tile_envs - 1) // self.tile_envs, dtype=torch.int32, device=dev)
         self.reward_terms = torch.zeros((len(REWARD_TERMS), N), device=dev) if log_reward_terms else None
         if cfg.num_actor_observations > 1:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define AMP_ABI_VERSION 6
+#define AMP_ABI_VERSION 7
 
 typedef void* amp_stream_t; /* hipStream_t */
 typedef void* amp_event_t;  /* hipEvent_t  */
@@ -213,7 +213,7 @@ typedef struct {
   uint8_t* died;             /* [N] bool */
   uint8_t* time_out;         /* [N] bool */
   uint8_t* reset_mask;       /* [N] died | time_out */
-  int32_t* reset_tile_counts; /* optional [ceil(N / amp_env_step_tile_envs(N))]: reset envs per tile (feeds amp_reset_compact_tiles) */
+  int32_t* reset_tile_counts; /* optional [ceil(N / amp_env_step_tile_envs(cfg, N))]: reset envs per tile (feeds amp_reset_compact_tiles) */
   /* Optional fusion of the discriminator's input scaler into the OBS phase (saves one pass over amp_obs):
    * disc_input receives v = clamp((amp_obs - mean) / den, -clip, clip) for the K*D columns in the layout
    * amp_disc_input_layout() reports (every field below comes from it; scaler_mean == NULL copies unscaled):
@@ -243,9 +243,9 @@ int amp_env_step_with_reference(const AmpEnvCfg* cfg, const AmpSimState* state, 
                                 const int64_t* motion_ids_dev, int64_t n_samples, int32_t K, float* expert_out_dev,
                                 amp_stream_t stream);
 
-/* Envs per workgroup tile amp_env_step uses for a shard of num_envs (16, 32 or 64): the granularity of
- * reset_tile_counts. */
-int32_t amp_env_step_tile_envs(int64_t num_envs);
+/* Envs per workgroup tile amp_env_step uses for this configuration and a shard of num_envs (8, 16 or 32; -1 for an
+ * invalid cfg): the granularity of reset_tile_counts. */
+int32_t amp_env_step_tile_envs(const AmpEnvCfg* cfg, int64_t num_envs);
 /* Size of one policy observation row for a configuration (g1_amp_env_cfg.py:186-206). */
 int64_t amp_policy_obs_size(const AmpEnvCfg* cfg);
 /* Size of one actor-history frame (g1_amp_env.py:96-107); 0 when num_actor_observations == 1. */
@@ -299,7 +299,7 @@ int64_t amp_reset_compact_workspace_bytes(int64_t num_envs);
 int amp_reset_compact(const uint8_t* mask_dev, int64_t num_envs, int64_t* ids_dev, int64_t* count_dev,
                       void* workspace_dev, amp_stream_t stream);
 /* Same, re-using the per-tile counts amp_env_step(AMP_PHASE_DONES) already produced (tile_envs =
- * amp_env_step_tile_envs(num_envs)). */
+ * amp_env_step_tile_envs(cfg, num_envs): 8, 16, 32 or 64). */
 int amp_reset_compact_tiles(const uint8_t* mask_dev, const int32_t* tile_counts_dev, int32_t tile_envs, int64_t num_envs,
                             int64_t* ids_dev, int64_t* count_dev, amp_stream_t stream);
 
@@ -376,7 +376,7 @@ int amp_disc_style_reward_prescaled(const AmpDisc* h, const void* scaled_dev, in
 typedef struct {
   const uint8_t* mask;         /* dev [num_envs] reset mask (AmpEnvBuffers.reset_mask) */
   const int32_t* tile_counts;  /* dev: AmpEnvBuffers.reset_tile_counts of the same step */
-  int32_t tile_envs;           /* amp_env_step_tile_envs(num_envs) */
+  int32_t tile_envs;           /* amp_env_step_tile_envs(cfg, num_envs) */
   int32_t reserved;
   int64_t num_envs;
   int64_t* ids;                /* dev [num_envs] out, ascending */

@@ -35,3 +35,25 @@ def test_gemm_kernels_use_no_scratch(tmp_path):
     assert not spilled, spilled
     dma = {k: v for k, v in found.items() if "disc_gemm_f16_dma_kernel" in k}
     assert len(dma) >= 5 and all(v[1] <= 256 for v in dma.values()), dma   # 8 waves per workgroup: 256 registers each
+
+
+def test_env_step_dma_kernels_use_no_scratch(tmp_path):
+    """The env-step DMA tile body went through scratch twice while it was written (a dynamically indexed by-value struct
+    member, a compiler-built pointer table) and reached 320 registers with per-key branches around loads; the guard: no
+    private segment and at least five waves per SIMD (<= 96 VGPRs) for every instantiation, the expert body included."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = tmp_path / "env_step.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "--offload-device-only", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
+                    os.path.join(CSRC, "env_step.hip"), "-o", str(out)], check=True, cwd=CSRC)
+    found = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", out.read_text(), flags=re.S):
+        name, body = m.group(1), m.group(2)
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
+        vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
+        found[name] = (scratch, vgpr)
+    dma = {k: v for k, v in found.items() if "env_step_dma" in k}
+    assert len(dma) == 6, sorted(found)                         # {plain, fused with the expert sample} x tile {32, 16, 8}
+    assert all(v[0] == 0 for v in found.values()), found
+    assert all(v[1] <= 96 for v in dma.values()), dma

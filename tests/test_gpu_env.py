@@ -178,11 +178,12 @@ def test_env_step_full_size_properties(N):
     from humanoid_amp_amd import _native as nat
 
     nd, K = 29, 2
-    assert nat.load().amp_env_step_tile_envs(N) == {65536: 32, 40000: 32, 4097: 16}[N]
     g = torch.Generator(device="cuda").manual_seed(3)
     r = lambda *s: torch.randn(*s, generator=g, device="cuda")  # noqa: E731
     cfg = EnvStepConfig(n_dof=nd, num_amp_observations=K, max_episode_length=300, rew_termination=-1.0, rew_action_l2=-0.1,
                         rew_joint_pos_limits=-10.0, rew_joint_acc_l2=-1e-6, rew_joint_vel_l2=-1e-3, rew_track_vel=1.0)
+    import ctypes
+    assert nat.load().amp_env_step_tile_envs(ctypes.byref(cfg.to_c()), N) == {65536: 32, 40000: 32, 4097: 16}[N]
     st = dict(joint_pos=r(N, nd), joint_vel=r(N, nd), joint_acc=r(N, nd) * 30, actions=r(N, nd) * 0.5,
               root_pos=torch.cat([r(N, 2), torch.rand(N, 1, generator=g, device="cuda") * 0.6 + 0.35], 1).contiguous(),
               root_quat=torch.nn.functional.normalize(r(N, 4), dim=1), root_lin_vel=r(N, 3), root_ang_vel=r(N, 3),
@@ -231,12 +232,13 @@ def test_fused_expert_launch_is_bit_identical(workload, envs):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("N,K", [(4097, 2), (40000, 2), (1000, 10)])  # 16- / 32-env tiles, ragged last tiles; K = 10: generic both ways
+@pytest.mark.parametrize("N,K", [(4097, 2), (40000, 2), (1000, 10), (33000, 10), (777, 1)])  # 16- / 32- / 8-env tiles, ragged last tiles
 @pytest.mark.parametrize("precision", ["f16x3", "f32"])
-def test_fast_tile_body_matches_generic_body(N, K, precision):
-    """The hot-path configuration (all phases, K = 2, contiguous inputs) runs env_step_fast_body; the same values handed
-    over as row-strided views take the generic body.  Every output, including the discriminator's fused scaled input
-    (fp16 plane pairs / fp32 rows), must agree bit for bit."""
+def test_dma_tile_body_matches_generic_body(N, K, precision):
+    """The hot-path configuration (all phases, contiguous actions / joint_acc) runs env_step_dma_pass (LDS-DMA staging,
+    column-major output walks); the same values handed over as row-strided views take the generic body.  Every output,
+    including the discriminator's fused scaled input (fp16 plane blocks / fp32 rows) and the per-tile reset counts, must
+    agree bit for bit."""
     from humanoid_amp_amd.engine import AmpDiscriminator, EnvStepConfig, EnvStepKernel
     from humanoid_amp_amd import _native as nat
     from humanoid_amp_amd.workloads import make_disc_weights
