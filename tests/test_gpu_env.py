@@ -232,9 +232,10 @@ def test_fused_expert_launch_is_bit_identical(workload, envs):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("N,K", [(4097, 2), (40000, 2), (1000, 10), (33000, 10), (777, 1)])  # 16- / 32- / 8-env tiles, ragged last tiles
+@pytest.mark.parametrize("N,K,nd", [(4097, 2, 29), (40000, 2, 29), (1000, 10, 29), (33000, 10, 29), (777, 1, 29),
+                                    (2100, 2, 70), (3000, 3, 12)])  # 16- / 32- / 8-env tiles, ragged last tiles, > 64 DoFs
 @pytest.mark.parametrize("precision", ["f16x3", "f32"])
-def test_dma_tile_body_matches_generic_body(N, K, precision):
+def test_dma_tile_body_matches_generic_body(N, K, nd, precision):
     """The hot-path configuration (all phases, contiguous actions / joint_acc) runs env_step_dma_pass (LDS-DMA staging,
     column-major output walks); the same values handed over as row-strided views take the generic body.  Every output,
     including the discriminator's fused scaled input (fp16 plane blocks / fp32 rows) and the per-tile reset counts, must
@@ -243,7 +244,6 @@ def test_dma_tile_body_matches_generic_body(N, K, precision):
     from humanoid_amp_amd import _native as nat
     from humanoid_amp_amd.workloads import make_disc_weights
 
-    nd = 29
     g = torch.Generator(device="cuda").manual_seed(5)
     r = lambda *s: torch.randn(*s, generator=g, device="cuda")  # noqa: E731
     cfg = EnvStepConfig(n_dof=nd, num_amp_observations=K, max_episode_length=300, rew_termination=-1.0, rew_action_l2=-0.1,
@@ -257,6 +257,9 @@ def test_dma_tile_body_matches_generic_body(N, K, precision):
               body_pos=r(N, 4, 3), key_body_indexes=[0, 1, 2, 3],
               soft_limits=torch.tensor([[-1.41, 1.41]] * nd, device="cuda"),
               episode_length=torch.randint(0, 300, (N,), generator=g, device="cuda"), command=r(N, 2), last_actions=r(N, nd))
+    if N % 2:  # per-env soft limits (Isaac Lab's [N, n_dof, 2] layout) on the odd sizes, one shared row on the others
+        lo = -1.41 + 0.2 * torch.rand(N, nd, 1, generator=g, device="cuda")
+        st["soft_limits"] = torch.cat([lo, lo + 2.6], dim=2).contiguous()
     strided = dict(st)
     for name in ("joint_pos", "joint_vel", "joint_acc", "actions"):  # [N, nd] views of [N, nd + 3] rows: not flat
         wide = torch.zeros(N, nd + 3, device="cuda")
