@@ -79,6 +79,14 @@ struct GemmF16Args {
   // operands; a k-step made of padding only adds exact zeros to every accumulator and is skipped (K = 166 -> 11 of 12
   // k-steps: 8 % of layer 1's MFMAs).  0 = all of Kp / 16.
   int32_t ksteps;
+  // MODE 2 of the LDS-DMA kernel (training step: C = A W^T as a plain fp32 product; disc_train.hip).  A and W are planes
+  // of s_a A and s_w W with s = plane_scale(abs-max of the operand): the kernel reads the two abs-max words itself.
+  float* C; int64_t ldc;                       // fp32 output
+  const float* amax_a; const float* amax_w;    // device abs-max of A / W
+  const float* mask; int64_t ldmask;           // optional gate: C = (mask > 0) ? C : 0
+  int32_t relu;                                // C = max(C + bias, 0) (bias != nullptr: C + bias)
+  int32_t accumulate;                          // C += (not with k_slices > 1)
+  int32_t k_slices; int64_t slice_stride;      // split-K: slice s reduces its run of k-blocks into C + s * slice_stride
 };
 
 // rn16(v), rn16(v - rn16(v)) for four values
@@ -108,7 +116,7 @@ __device__ __forceinline__ void relu_split4(const fv4 acc, const float ds, const
 
 // planes of scale[0] * src[rows, cols] (row pitch ld_src floats) -> dst + p * plane, rows of ld_dst halves; columns in
 // [cols, ld_dst) are zero.  One thread per four columns.
-__global__ __launch_bounds__(kBlock) void split_rows_f16_kernel(const float* __restrict__ src, int64_t rows, int cols,
+static __global__ __launch_bounds__(kBlock) void split_rows_f16_kernel(const float* __restrict__ src, int64_t rows, int cols,
                                                                 int64_t ld_src, const float* __restrict__ scale,
                                                                 _Float16* __restrict__ dst, int64_t ld_dst, int64_t plane) {
   const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x, per_row = ld_dst / 4;

@@ -53,14 +53,15 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // planes of scale[0] * src[rows, cols] (row pitch ld_src floats) -> block layout dst[rows][kp / 32][2][32] halves;
 // columns in [cols, kp) are zero.  One thread per four columns.
-__global__ __launch_bounds__(kBlock) void split_rows_blocks_kernel(const float* __restrict__ src, int64_t rows, int cols,
+// `scale_is_amax`: scale[0] is the operand's abs-max, the scale is plane_scale() of it (training-step operands).
+static __global__ __launch_bounds__(kBlock) void split_rows_blocks_kernel(const float* __restrict__ src, int64_t rows, int cols,
                                                                    int64_t ld_src, const float* __restrict__ scale,
-                                                                   _Float16* __restrict__ dst, int kp) {
+                                                                   _Float16* __restrict__ dst, int kp, int scale_is_amax = 0) {
   const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x, per_row = kp / 4;
   if (q >= rows * per_row) return;
   const int64_t r = q / per_row;
   const int c = (int)(q - r * per_row) * 4;
-  const float s = scale[0];
+  const float s = scale_is_amax ? plane_scale(scale[0]) : scale[0];
   fv4 v;
 #pragma unroll
   for (int i = 0; i < 4; ++i) v[i] = c + i < cols ? src[r * ld_src + c + i] * s : 0.0f;
@@ -80,16 +81,26 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN>::kWgPerCu)) void disc
   using T = DmaTile<TM, TN>;
   constexpr int BM = T::BM, BN = T::BN, kOpA = T::kA, kStage = T::kStage;
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-  int mt, nt;
-  if (!f16_tile_of_block(g, mt, nt)) return;
+  int mt, nt, slice = 0;
+  if (MODE == 2 && g.k_slices > 1) {
+    // split-K: the grid is k_slices copies of the tile grid; slice s owns the k-blocks [s * nq, (s + 1) * nq)
+    const int m_tiles = g.m_tiles;
+    g.m_tiles = m_tiles * g.k_slices;
+    if (!f16_tile_of_block(g, mt, nt)) return;
+    slice = mt / m_tiles;
+    mt -= slice * m_tiles;
+  } else if (!f16_tile_of_block(g, mt, nt)) {
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;
   const int li = lane & 31, lh = lane >> 5;
   const int grp = wave >> 2;
   const int64_t m0 = (int64_t)mt * BM;
   const int n0 = nt * BN;
-  const int nq = g.Kp / kDmaKB;  // k-blocks
-  const int ksteps = g.ksteps > 0 ? g.ksteps : 2 * nq;
+  const int nq = (MODE == 2 && g.k_slices > 1) ? g.Kp / kDmaKB / g.k_slices : g.Kp / kDmaKB;  // k-blocks (of this slice)
+  const int q0 = slice * nq;
+  const int ksteps = (MODE != 2 && g.ksteps > 0) ? g.ksteps : 2 * nq;
 
   // ---- fill plan: a piece is 8 rows x 128 B.  Group 0's wave w fills a quarter of the activation rows, group 1's
   // wave 4 + w a quarter of the weight rows: NP pieces each.  lane l: row 8 j + (l >> 3) of the wave's quarter, stored
@@ -105,9 +116,9 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN>::kWgPerCu)) void disc
       const int c = (lane & 7) ^ ((r >> 1) & 7);
       if (grp == 0) {
         const int64_t m = m0 + r < last ? m0 + r : last;
-        src[j] = g.A + m * (2 * g.lda) + 8 * c;
+        src[j] = g.A + m * (2 * g.lda) + 8 * c + (int64_t)q0 * 64;
       } else {
-        src[j] = g.W + (int64_t)(n0 + r) * (2 * (int64_t)g.Kp) + 8 * c;
+        src[j] = g.W + (int64_t)(n0 + r) * (2 * (int64_t)g.Kp) + 8 * c + (int64_t)q0 * 64;
       }
     }
   }
@@ -171,19 +182,19 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN>::kWgPerCu)) void disc
     for (int a = 0; a < TM; ++a)
 #pragma unroll
       for (int b = 0; b < TN; ++b)
-        acc[a][b] = MODE == 0 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(x1[a], w0[b], acc[a][b], 0, 0, 0)
+        acc[a][b] = MODE != 1 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(x1[a], w0[b], acc[a][b], 0, 0, 0)
                               : __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[b], x1[a], acc[a][b], 0, 0, 0);
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
       for (int b = 0; b < TN; ++b)
-        acc[a][b] = MODE == 0 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(x0[a], w1[b], acc[a][b], 0, 0, 0)
+        acc[a][b] = MODE != 1 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(x0[a], w1[b], acc[a][b], 0, 0, 0)
                               : __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[b], x0[a], acc[a][b], 0, 0, 0);
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
       for (int b = 0; b < TN; ++b)
-        acc[a][b] = MODE == 0 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(x0[a], w0[b], acc[a][b], 0, 0, 0)
+        acc[a][b] = MODE != 1 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(x0[a], w0[b], acc[a][b], 0, 0, 0)
                               : __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[b], x0[a], acc[a][b], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
@@ -229,6 +240,34 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN>::kWgPerCu)) void disc
   if (grp == 0) __builtin_amdgcn_s_barrier();
   __syncthreads();  // every wave is done with the stages: the scratch below reuses them
 
+  if (MODE == 2) {
+    // ---- plain fp32 product (training step).  Same register map as MODE 0: register r of lane (li, lh) is output ROW
+    // (r & 3) + 8 (r >> 2) + 4 lh of the 32 x 32 block and COLUMN li, so a wave store covers two 128-B row segments.
+    const float descale = 1.0f / (plane_scale(g.amax_a[0]) * plane_scale(g.amax_w[0]));  // powers of two: exact
+    float* const C = g.C + (int64_t)slice * g.slice_stride;
+    const int col0 = n0 + wn * (32 * TN);
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int col = col0 + b * 32 + li;
+      const float bias = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = m0 + wm * (32 * TM) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (row < g.M) {
+            float v = acc[a][b][r] * descale;
+            if (g.bias) v += bias;
+            if (g.relu) v = fmaxf(v, 0.0f);
+            if (g.mask) v = g.mask[row * g.ldmask + col] > 0.0f ? v : 0.0f;
+            float* dst = C + row * g.ldc + col;
+            if (g.accumulate) v += *dst;
+            *dst = v;
+          }
+        }
+    }
+    return;
+  }
   const LayerScales sc = layer_scales(g.range, g.amax, g.layer);
   const float descale = sc.descale;
   if (MODE == 0) {

@@ -12,6 +12,8 @@
 //   a2 = m2 * w3,  a1 = m1 * (a2 W2),  g = a1 W1,  P = mean |g|^2,  dg = 2 g / B
 //   dW1 += a1^T dg,  e1 = m1 * (dg W1^T),  dW2 += a2^T e1,  dw3 += colsum(m2 * (e1 W2^T)).
 #include "disc_gemm.hpp"
+#include <cstdlib>
+#include "disc_gemm_f16_dma.hpp"
 
 struct AmpDisc;  // defined in disc.hip; accessed through the accessors below
 
@@ -295,9 +297,111 @@ struct AmpDiscTrainer {
   float* ws;                     // workspace
   int64_t ws_floats;
   int kN;
+  // fp16-split GEMM path (gemm_f16x3): block-layout planes of the two operands of the running product + abs-max slots
+  _Float16* planes[2];
+  int64_t plane_halves;          // capacity of each
+  float* amax;                   // [kAmaxSlots]
+  int amax_next;
 };
 
 namespace {
+
+unsigned blocks(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+constexpr int kAmaxSlots = 64;
+
+// abs-max of a [rows, cols] block (row pitch ld) into out[0] (zeroed before): non-negative floats order like their bit
+// patterns, so one integer atomicMax per workgroup does it
+__global__ __launch_bounds__(kBlock) void amax_kernel(const float* __restrict__ x, int64_t rows, int cols, int64_t ld,
+                                                      float* __restrict__ out) {
+  __shared__ float s_part[kBlock / 64];
+  float m = 0.0f;
+  const int64_t n = rows * cols;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (int64_t)gridDim.x * kBlock) {
+    const int64_t r = e / cols;
+    m = fmaxf(m, fabsf(x[r * ld + (e - r * cols)]));
+  }
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < kBlock / 64; ++i) m = fmaxf(m, s_part[i]);
+    atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
+  }
+}
+
+template <int TM, int TN>
+int f16x3_kernel_init() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gemm_f16_dma_kernel<2, TM, TN>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, DmaTile<TM, TN>::kLds) == hipSuccess ? AMP_OK : AMP_ERR_HIP;
+}
+// the tiles' LDS exceeds the 64 KB default: the limit is raised once per device
+int f16x3_init() {
+  static bool done[64] = {};
+  int dev = 0;
+  AMP_HIP(hipGetDevice(&dev));
+  if (dev >= 0 && dev < 64 && done[dev]) return AMP_OK;
+  if (f16x3_kernel_init<4, 2>() != AMP_OK || f16x3_kernel_init<4, 1>() != AMP_OK || f16x3_kernel_init<2, 1>() != AMP_OK)
+    return fail(AMP_ERR_HIP, "amp_disc_trainer: raising the dynamic LDS limit of the fp16-split GEMM failed");
+  if (dev >= 0 && dev < 64) done[dev] = true;
+  return AMP_OK;
+}
+
+// C[M, N] (ld = ldc) = A W^T at fp32 accuracy on the fp16 matrix pipe: both operands are split into two fp16 planes in
+// block layout (scale = the power of two that brings the operand's abs-max below 2^15) and multiplied by the LDS-DMA
+// kernel of the inference path (three MFMAs per product, disc_gemm_f16_dma.hpp, MODE 2).  A is [M, K] (row pitch lda),
+// W is [N, K] (row pitch ldw); K is padded to 32 with zeros.  Returns AMP_ERR_UNSUPPORTED-like 1 when the shape does not
+// fit the kernel (the caller then takes the fp32 engine).
+int gemm_f16x3(hipStream_t st, AmpDiscTrainer* t, const float* A, int64_t lda, int64_t M, const float* W, int64_t ldw, int N,
+               int K, const float* bias, int relu, float* C, int64_t ldc, const float* mask, int64_t ldmask, int accumulate,
+               float* split, int64_t split_floats) {
+  const int Kp = (int)up(K, 32);
+  if (!t->planes[0] || N % 128 != 0 || M < 128 || M * (int64_t)Kp * 2 > t->plane_halves || (int64_t)N * Kp * 2 > t->plane_halves)
+    return 1;
+  if (t->amax_next + 2 > kAmaxSlots) return 1;
+  float* am_a = t->amax + t->amax_next++;
+  float* am_w = t->amax + t->amax_next++;
+  const int64_t na = M * (int64_t)K, nw = (int64_t)N * K;
+  amax_kernel<<<(unsigned)std::min<int64_t>(1024, (na + kBlock - 1) / kBlock), kBlock, 0, st>>>(A, M, K, lda, am_a);
+  amax_kernel<<<(unsigned)std::min<int64_t>(1024, (nw + kBlock - 1) / kBlock), kBlock, 0, st>>>(W, N, K, ldw, am_w);
+  split_rows_blocks_kernel<<<blocks(M * (Kp / 4)), kBlock, 0, st>>>(A, M, K, lda, am_a, t->planes[0], Kp, 1);
+  split_rows_blocks_kernel<<<blocks((int64_t)N * (Kp / 4)), kBlock, 0, st>>>(W, N, K, ldw, am_w, t->planes[1], Kp, 1);
+  GemmF16Args g{};
+  g.A = t->planes[0]; g.lda = Kp; g.M = M;
+  g.W = t->planes[1]; g.Kp = Kp; g.N = N;
+  g.bias = bias; g.relu = relu;
+  g.C = C; g.ldc = ldc; g.amax_a = am_a; g.amax_w = am_w;
+  g.mask = mask; g.ldmask = ldmask; g.accumulate = accumulate;
+  // tile: 256 x 256 when that still gives ~3/4 of the CUs a workgroup, then 256 x 128, else 128 x 128; split-K (only the
+  // weight-gradient products: a few output tiles, thousands of k-blocks) on 128 x 128 tiles
+  const int nq = Kp / 32;
+  int tm = 2, tn = 1, slices = 1;
+  auto tiles = [&](int bm, int bn) { return (int)((M + bm - 1) / bm) * (N / bn); };
+  if (split && !mask && !bias) {
+    while (slices < 16 && tiles(128, 128) * slices * 2 <= 512 && nq % (slices * 2) == 0 && nq / (slices * 2) >= 8 &&
+           (int64_t)(slices * 2) * M * ldc <= split_floats)
+      slices *= 2;
+  }
+  if (slices == 1) {
+    if (N % 256 == 0 && tiles(256, 256) >= 192) { tm = 4; tn = 2; }
+    else if (tiles(256, 128) >= 192) { tm = 4; tn = 1; }
+  }
+  const int bm = 64 * tm, bn = 128 * tn;
+  g.m_tiles = (int)((M + bm - 1) / bm); g.n_tiles = N / bn;
+  if (slices > 1) { g.k_slices = slices; g.slice_stride = M * ldc; g.C = split; g.accumulate = 0; }
+  const unsigned grid = (unsigned)(((int64_t)g.m_tiles * g.n_tiles * slices + 7) / 8 * 8);
+  {
+    amp::TraceScope trace__("disc_gemm_f16_dma_kernel<2>", st);
+    if (tm == 4 && tn == 2) disc_gemm_f16_dma_kernel<2, 4, 2><<<grid, kDmaThreads, DmaTile<4, 2>::kLds, st>>>(g);
+    else if (tm == 4) disc_gemm_f16_dma_kernel<2, 4, 1><<<grid, kDmaThreads, DmaTile<4, 1>::kLds, st>>>(g);
+    else disc_gemm_f16_dma_kernel<2, 2, 1><<<grid, kDmaThreads, DmaTile<2, 1>::kLds, st>>>(g);
+  }
+  int rc = launch_status("disc_gemm_f16_dma_kernel<2>");
+  if (rc != AMP_OK || slices == 1) return rc;
+  const int64_t n = M * ldc;
+  sum_slices_kernel<<<(unsigned)((n + kBlock - 1) / kBlock), kBlock, 0, st>>>(split, slices, n, n, C, accumulate);
+  return launch_status("sum_slices_kernel");
+}
 
 // C[M, N] (ld = ldc) = A W^T, optionally gated / accumulated.  `split` (scratch of k_slices * M * ldc floats) enables
 // split-K for the weight-gradient products whose reduction runs over the 4096..12288 batch rows while the output is
@@ -351,8 +455,6 @@ void transpose(hipStream_t st, const float* in, int64_t rows, int cols, int64_t 
   transpose_pad_kernel<<<grid, kBlock, 0, st>>>(in, rows, cols, ld_in, out, ld_out, out_rows);
 }
 
-unsigned blocks(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
-
 }  // namespace
 
 extern "C" {
@@ -368,6 +470,9 @@ int amp_disc_trainer_destroy(AmpDiscTrainer* t) {
   (void)hipFree(t->mean64);
   (void)hipFree(t->var64);
   (void)hipFree(t->ws);
+  (void)hipFree(t->planes[0]);
+  (void)hipFree(t->planes[1]);
+  (void)hipFree(t->amax);
   delete t;
   return AMP_OK;
 }
@@ -412,6 +517,15 @@ int amp_disc_trainer_create(AmpDisc* disc, const AmpDiscTrainCfg* cfg, const dou
                     (int64_t)p.h1 * t->kN + p.h1 + (int64_t)p.h2 * p.h1 + p.h2 + p.h2 + 1 + 64;    // grads + loss
   t->ws_floats = f + (int64_t)16 * p.h2 * p.h1 + (int64_t)kChunks * 1024 + 1024 + (int64_t)kChunks * p.in_dim * 4 + 16 + 16 * 40;
   if (e == hipSuccess) e = hipMalloc(&t->ws, sizeof(float) * t->ws_floats);
+  if (e == hipSuccess && !cfg->gemm_fp32) {
+    // fp16-split GEMM path: planes of the largest operand ([3B (padded), max(h1, h2)] or its transpose), twice
+    const int64_t rows = up(Mp, 32), cols = up(std::max<int64_t>(std::max(p.h1, p.h2), up(t->kN, 32)), 32);
+    t->plane_halves = 2 * rows * cols;
+    e = hipMalloc(&t->planes[0], sizeof(_Float16) * t->plane_halves);
+    if (e == hipSuccess) e = hipMalloc(&t->planes[1], sizeof(_Float16) * t->plane_halves);
+    if (e == hipSuccess) e = hipMalloc(&t->amax, sizeof(float) * kAmaxSlots);
+    if (e == hipSuccess && f16x3_init() != AMP_OK) e = hipErrorUnknown;
+  }
   if (e != hipSuccess) {
     amp_disc_trainer_destroy(t);
     return fail(AMP_ERR_HIP, "amp_disc_trainer_create: %s", hipGetErrorString(e));
@@ -497,7 +611,26 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
     scalar_final_kernel<<<1, 256, 0, st>>>(part, nb, scale, loss, slot, accumulate);
   };
   int rc;
-
+  // The BACKWARD products whose shape fits run at fp32 accuracy on the fp16 matrix pipe (gemm_f16x3) unless cfg.gemm_fp32;
+  // the others (output width kN = 192: the W1-gradient products and g) and the two FORWARD GEMMs stay on the fp32 pipe.
+  // The forward decides the ReLU masks: a pre-activation within rounding of zero flips its mask with any change of the
+  // summation (measured: one of 786 432 H2 entries between the two engines at 3 x 512 rows), and one flipped unit moves its
+  // column of the bias / weight gradients by ~1 / sqrt(rows) of the column sum -- 6e-3 here, two orders above the parity bar
+  // although both forwards are 1e-6 from fp64.  The backward products are linear in their operands: no such cliff.
+  const bool f16 = t->planes[0] != nullptr;
+  if (f16) {
+    t->amax_next = 0;
+    AMP_HIP(hipMemsetAsync(t->amax, 0, sizeof(float) * kAmaxSlots, st));
+  }
+  const int64_t split_floats = (int64_t)16 * H2n * H1n;
+  auto nt = [&](const float* A, int64_t lda, int64_t Mr, const float* W, int Kp, int N, float* C, int64_t ldc, const float* mask,
+                int64_t ldmask, int accumulate, float* split_ws = nullptr) -> int {
+    if (f16) {
+      const int r = gemm_f16x3(st, t, A, lda, Mr, W, Kp, N, Kp, nullptr, 0, C, ldc, mask, ldmask, accumulate, split_ws, split_floats);
+      if (r != 1) return r;
+    }
+    return gemm_nt(st, A, lda, Mr, W, Kp, N, C, ldc, mask, ldmask, accumulate, split_ws);
+  };
   // ---- 1. scaler (train=True): update the running statistics with each batch, then scale it --------------------
   const float* mean32 = nullptr;
   const float* den32 = nullptr;
@@ -538,16 +671,16 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
   colsum(dH2, M, H2n, H2n, nullptr, nullptr, 0, gb2, 0);
   transpose(st, p.w2, H2n, H1n, H1n, t->w2t, H2n, H1n);               // W2^T [h1, h2]
   transpose(st, p.w1p, H1n, k1p, k1p, t->w1t, H1n, kN);               // W1^T [kN, h1] (zero rows >= k1p)
-  rc = gemm_nt(st, dH2, H2n, M, t->w2t, H2n, H1n, dH1, H1n, H1, H1n, 0);   // dH1 = (dH2 W2) * (H1 > 0)
+  rc = nt(dH2, H2n, M, t->w2t, H2n, H1n, dH1, H1n, H1, H1n, 0);   // dH1 = (dH2 W2) * (H1 > 0)
   if (rc != AMP_OK) return rc;
   colsum(dH1, M, H1n, H1n, nullptr, nullptr, 0, gb1, 0);
   transpose(st, dH2, M, H2n, H2n, dH2T, Mp, H2n);
   transpose(st, H1, M, H1n, H1n, H1T, Mp, H1n);
-  rc = gemm_nt(st, dH2T, Mp, H2n, H1T, (int)Mp, H1n, gW2, H1n, nullptr, 0, 0, split);   // gW2 = dH2^T H1
+  rc = nt(dH2T, Mp, H2n, H1T, (int)Mp, H1n, gW2, H1n, nullptr, 0, 0, split);   // gW2 = dH2^T H1
   if (rc != AMP_OK) return rc;
   transpose(st, dH1, M, H1n, H1n, dH1T, Mp, H1n);
   transpose(st, Xs, M, k1p, k1p, XsT, Mp, kN);
-  rc = gemm_nt(st, dH1T, Mp, H1n, XsT, (int)Mp, kN, gW1, kN, nullptr, 0, 0, split);     // gW1 = dH1^T Xs
+  rc = nt(dH1T, Mp, H1n, XsT, (int)Mp, kN, gW1, kN, nullptr, 0, 0, split);     // gW1 = dH1^T Xs
   if (rc != AMP_OK) return rc;
 
   // ---- 4. gradient penalty on the motion rows ------------------------------------------------------------------
@@ -555,23 +688,23 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
     const float* H1m = H1 + 2 * B * H1n;
     const float* H2m = H2 + 2 * B * H2n;
     a2_kernel<<<blocks(B * H2n), kBlock, 0, st>>>(p.w3, H2m, B, H2n, a2);
-    rc = gemm_nt(st, a2, H2n, B, t->w2t, H2n, H1n, a1, H1n, H1m, H1n, 0);        // a1 = (a2 W2) * m1
+    rc = nt(a2, H2n, B, t->w2t, H2n, H1n, a1, H1n, H1m, H1n, 0);        // a1 = (a2 W2) * m1
     if (rc != AMP_OK) return rc;
-    rc = gemm_nt(st, a1, H1n, B, t->w1t, H1n, kN, g, kN, nullptr, 0, 0);         // g = a1 W1      [B, kN]
+    rc = nt(a1, H1n, B, t->w1t, H1n, kN, g, kN, nullptr, 0, 0);         // g = a1 W1      [B, kN]
     if (rc != AMP_OK) return rc;
     // loss[1] = gp_scale * mean_rows |g|^2 ;  g <- dL/dg = (2 gp_scale loss_scale / B) g
     sumsq(g, B, p.in_dim, kN, 2.0f * c.grad_penalty_scale * c.loss_scale / (float)B, 1, c.grad_penalty_scale / (float)B, 1, 0);
     transpose(st, a1, B, H1n, H1n, a1T, Bp, H1n);
     transpose(st, g, B, kN, kN, dgT, Bp, kN);
-    rc = gemm_nt(st, a1T, Bp, H1n, dgT, (int)Bp, kN, gW1, kN, nullptr, 0, 1, split);    // gW1 += a1^T dg
+    rc = nt(a1T, Bp, H1n, dgT, (int)Bp, kN, gW1, kN, nullptr, 0, 1, split);    // gW1 += a1^T dg
     if (rc != AMP_OK) return rc;
-    rc = gemm_nt(st, g, kN, B, p.w1p, k1p, H1n, e1, H1n, H1m, H1n, 0);           // e1 = (dg W1^T) * m1   (K = k1p <= kN)
+    rc = nt(g, kN, B, p.w1p, k1p, H1n, e1, H1n, H1m, H1n, 0);           // e1 = (dg W1^T) * m1   (K = k1p <= kN)
     if (rc != AMP_OK) return rc;
     transpose(st, a2, B, H2n, H2n, a2T, Bp, H2n);
     transpose(st, e1, B, H1n, H1n, e1T, Bp, H1n);
-    rc = gemm_nt(st, a2T, Bp, H2n, e1T, (int)Bp, H1n, gW2, H1n, nullptr, 0, 1, split);  // gW2 += a2^T e1
+    rc = nt(a2T, Bp, H2n, e1T, (int)Bp, H1n, gW2, H1n, nullptr, 0, 1, split);  // gW2 += a2^T e1
     if (rc != AMP_OK) return rc;
-    rc = gemm_nt(st, e1, H1n, B, p.w2, H1n, H2n, da2, H2n, nullptr, 0, 0);       // da2 = e1 W2^T
+    rc = nt(e1, H1n, B, p.w2, H1n, H2n, da2, H2n, nullptr, 0, 0);       // da2 = e1 W2^T
     if (rc != AMP_OK) return rc;
     colsum(da2, B, H2n, H2n, nullptr, H2m, H2n, gw3, 1);  // gw3 += colsum(m2 * da2)
   } else {

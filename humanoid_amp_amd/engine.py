@@ -533,9 +533,17 @@ class AmpDiscriminatorTrainer:
                  discriminator_gradient_penalty_scale: float = 5.0, discriminator_weight_decay_scale: float = 1e-4,
                  betas=(0.9, 0.999), adam_epsilon: float = 1e-8, use_scaler: bool = True, update_scaler: bool = True,
                  running_mean: Optional[torch.Tensor] = None, running_variance: Optional[torch.Tensor] = None,
-                 current_count: float = 1.0, apply_update: bool = True):
+                 current_count: float = 1.0, apply_update: bool = True, gemm_precision: str = "f32"):
+        """``gemm_precision``: "f32" (default) runs every GEMM on the fp32 matrix pipe; "f16x3" runs the large BACKWARD
+        products at fp32 accuracy on the fp16 matrix pipe (two fp16 planes per operand, three MFMAs per product -- the
+        inference path's engine).  Same gradients to 1e-6, but at BASELINE's minibatch (3 x 4 096 rows) the extra operand
+        passes (abs-max + plane split per operand) cost more than the faster products save: 1.20 vs 1.02 ms per step
+        (DESIGN.md section 7b), so it is opt-in."""
+        if gemm_precision not in ("f16x3", "f32"):
+            raise ValueError(f"gemm_precision must be 'f16x3' or 'f32', got {gemm_precision!r}")
         self.disc, self.device, self._lib = disc, disc.device, nat.load()
         self.batch_size = int(batch_size)
+        self.gemm_precision = gemm_precision
         c = nat.AmpDiscTrainCfg()
         c.max_rows_per_group = self.batch_size
         c.learning_rate, c.beta1, c.beta2, c.adam_epsilon = learning_rate, betas[0], betas[1], adam_epsilon
@@ -543,6 +551,7 @@ class AmpDiscriminatorTrainer:
         c.grad_penalty_scale, c.weight_decay_scale = discriminator_gradient_penalty_scale, discriminator_weight_decay_scale
         c.scaler_epsilon, c.scaler_clip = disc.epsilon, disc.clip_threshold
         c.use_scaler, c.update_scaler, c.apply_update = int(use_scaler), int(update_scaler), int(apply_update)
+        c.gemm_fp32 = int(gemm_precision == "f32")
         self.loss_scale = float(discriminator_loss_scale)
         m = None if running_mean is None else running_mean.detach().to(device=self.device, dtype=torch.float64).contiguous()
         v = None if running_variance is None else running_variance.detach().to(device=self.device, dtype=torch.float64).contiguous()

@@ -29,14 +29,16 @@ def _split(flat, weights):
     return out
 
 
+@pytest.mark.parametrize("gemm_precision", ["f16x3", "f32"])  # fp16-split GEMMs (default) / everything on the fp32 pipe
 @pytest.mark.parametrize("in_dim,B", [(166, 512), (830, 256), (162, 1000)])
-def test_gradients_and_loss_no_scaler(in_dim, B):
+def test_gradients_and_loss_no_scaler(in_dim, B, gemm_precision):
     from humanoid_amp_amd.engine import AmpDiscriminator, AmpDiscriminatorTrainer
 
     w = odisc.make_weights(in_dim, seed=in_dim)
     p, r, m = _batches(in_dim, B, seed=B)
     disc = AmpDiscriminator([(a.cuda(), b.cuda()) for a, b in w], "cuda:0")
-    tr = AmpDiscriminatorTrainer(disc, batch_size=B, use_scaler=False, update_scaler=False, apply_update=False)
+    tr = AmpDiscriminatorTrainer(disc, batch_size=B, use_scaler=False, update_scaler=False, apply_update=False,
+                                 gemm_precision=gemm_precision)
     out = tr.step(p.cuda(), r.cuda(), m.cuda(), want_grads=True)
     L, G = odt.loss_and_grads(w, p, r, m, None, None)
     L64, G64 = odt.loss_and_grads(w, p, r, m, None, None, dtype=torch.float64)
@@ -55,7 +57,8 @@ def test_gradients_and_loss_no_scaler(in_dim, B):
         assert torch.equal(a.cpu(), c) and torch.equal(b.cpu(), d)
 
 
-def test_full_step_with_scaler_and_adam():
+@pytest.mark.parametrize("gemm_precision", ["f16x3", "f32"])
+def test_full_step_with_scaler_and_adam(gemm_precision):
     from humanoid_amp_amd.engine import AmpDiscriminator, AmpDiscriminatorTrainer
 
     in_dim, B = 166, 768
@@ -66,7 +69,7 @@ def test_full_step_with_scaler_and_adam():
     count0 = 1000.0
     disc = AmpDiscriminator([(a.cuda(), b.cuda()) for a, b in w], "cuda:0", running_mean=mean0, running_variance=var0)
     tr = AmpDiscriminatorTrainer(disc, batch_size=B, running_mean=mean0, running_variance=var0, current_count=count0,
-                                 learning_rate=1e-3)
+                                 learning_rate=1e-3, gemm_precision=gemm_precision)
     # oracle state
     params = [t.clone() for wb in w for t in wb]
     mo = [torch.zeros_like(t) for t in params]
@@ -100,3 +103,27 @@ def test_full_step_with_scaler_and_adam():
     ref = odisc.forward([(params[0], params[1]), (params[2], params[3]), (params[4], params[5])], x, mean, var)
     got = disc.style_reward(x.cuda(), want_logits=True)
     assert float((got["logits"].cpu() - ref["logits"]).abs().max()) <= 5e-5
+
+
+@pytest.mark.parametrize("in_dim", [166, 830])
+def test_f16x3_gemms_match_the_fp32_pipe_at_full_size(in_dim):
+    """BASELINE's minibatch (3 x 4096 rows): the step whose large GEMMs run on the fp16 matrix pipe (two planes per operand,
+    three MFMAs per product, split-K weight gradients) against the same step on the fp32 pipe -- loss terms and every
+    gradient tensor agree to 1e-5 of the tensor's scale (both are ~1e-6 from an fp64 evaluation at the small sizes above)."""
+    from humanoid_amp_amd.engine import AmpDiscriminator, AmpDiscriminatorTrainer
+
+    B = 4096
+    w = odisc.make_weights(in_dim, seed=3)
+    p, r, m = _batches(in_dim, B, seed=77)
+    outs = {}
+    for prec in ("f16x3", "f32"):
+        disc = AmpDiscriminator([(a.cuda(), b.cuda()) for a, b in w], "cuda:0")
+        tr = AmpDiscriminatorTrainer(disc, batch_size=B, use_scaler=False, update_scaler=False, apply_update=False,
+                                     gemm_precision=prec)
+        outs[prec] = tr.step(p.cuda(), r.cuda(), m.cuda(), want_grads=True)
+    for name in ("prediction", "grad_penalty", "logit_reg", "weight_decay", "loss"):
+        a, b = float(outs["f16x3"][name]), float(outs["f32"][name])
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (name, a, b)
+    ga, gb = _split(outs["f16x3"]["grads"].cpu(), w), _split(outs["f32"]["grads"].cpu(), w)
+    for i, (a, b) in enumerate(zip(ga, gb)):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), i
