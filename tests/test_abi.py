@@ -81,7 +81,7 @@ def test_errors_are_codes_not_exceptions_and_need_no_gpu():
     assert b"null" in lib.amp_last_error()
     assert lib.amp_reset_compact_workspace_bytes(65536) == 4 * (1024 + 1)
     cfg = nat.AmpEnvCfg(n_dof=29, n_key=4, num_amp_observations=2, num_actor_observations=1)
-    assert [lib.amp_env_step_tile_envs(ctypes.byref(cfg), n) for n in (1, 4096, 32768, 65536, 1 << 20)] == [16, 16, 32, 32, 32]
+    assert [lib.amp_env_step_tile_envs(ctypes.byref(cfg), n) for n in (1, 4096, 16383, 16384, 65536, 1 << 20)] == [16, 16, 16, 32, 32, 32]
     cfg.num_amp_observations = 10  # the [tile, K*D] LDS image of the DMA body bounds the tile
     assert [lib.amp_env_step_tile_envs(ctypes.byref(cfg), n) for n in (4096, 65536)] == [8, 8]
     assert lib.amp_env_step_tile_envs(None, 4096) == -1
