@@ -395,8 +395,8 @@ def main():
             wg = ((rows + 255) // 256 * 2 + 7) // 8 * 8
             traffic = (tj.get(f"disc_gemm_f16_dma_kernel<1, 4, 2>@{wg}") or {}).get("hbm_bytes")
         if spec.K == 2 and envs >= 32768 and envs % 32 == 0:
-            wg = envs // 32 + envs * spec.K // 64
-            hbm_traffic = (tj.get(f"env_step_fast_reference_kernel<32>@{wg}") or {}).get("hbm_bytes")
+            wg = envs // 32 + (envs * spec.K + 255) // 256  # 32-env tiles + 256-sample expert tiles of the fused launch
+            hbm_traffic = (tj.get(f"env_step_dma_reference_kernel<32>@{wg}") or {}).get("hbm_bytes")
         flops2 = (2.0 * envs * 1024 * 512 + 2.0 * envs * 512) / per_step   # layer 2 + the fused 512 -> 1 dot, per launch
         achieved = flops2 / (gemm2_ms * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS[args.disc_precision]

@@ -14,8 +14,8 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_A
   --output-format csv -d "$R/pmc_sq" -- python3 bench.py $ARGS > "$R/pmc_sq.json" 2> "$R/pmc_sq.err" || exit 2
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$R/pmc_fetch" -- python3 bench.py $ARGS > "$R/pmc_fetch.json" 2> "$R/pmc_fetch.err" || exit 3
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$R/pmc_write" -- python3 bench.py $ARGS > "$R/pmc_write.json" 2> "$R/pmc_write.err" || exit 4
-python3 bench.py > "$R/bench_plain.json" 2> "$R/bench_plain.err" || exit 5
 unset AMP_BENCH_NO_CALIBRATION
+python3 bench.py > "$R/bench_plain.json" 2> "$R/bench_plain.err" || exit 5
 python3 tools/prof_summary.py "$R"/trace/*/*_kernel_trace.csv > "$R/kernel_trace_by_grid.md"
 python3 tools/pmc_summary.py "$R"/pmc_sq/*/*_counter_collection.csv "$R"/pmc_fetch/*/*_counter_collection.csv "$R"/pmc_write/*/*_counter_collection.csv > "$R/pmc_per_kernel.md"
 python3 tools/pmc_summary.py --traffic-json "$R/pmc_traffic.json" "$R"/pmc_fetch/*/*_counter_collection.csv "$R"/pmc_write/*/*_counter_collection.csv
