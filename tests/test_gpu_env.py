@@ -249,8 +249,11 @@ def test_dma_tile_body_matches_generic_body(N, K, nd, precision):
     cfg = EnvStepConfig(n_dof=nd, num_amp_observations=K, max_episode_length=300, rew_termination=-1.0, rew_action_l2=-0.1,
                         rew_joint_pos_limits=-10.0, rew_joint_acc_l2=-1e-6, rew_joint_vel_l2=-1e-3, rew_track_vel=1.0)
     D = cfg.amp_frame_size
-    disc = AmpDiscriminator(make_disc_weights(K * D, seed=0), "cuda:0", running_mean=torch.randn(K * D, dtype=torch.float64) * 0.1,
-                            running_variance=torch.rand(K * D, dtype=torch.float64) + 0.5, precision=precision)
+    if N == 2100:  # no scaler attached: the fused input is the raw AMP row (plane-split / copied)
+        disc = AmpDiscriminator(make_disc_weights(K * D, seed=0), "cuda:0", precision=precision)
+    else:
+        disc = AmpDiscriminator(make_disc_weights(K * D, seed=0), "cuda:0", running_mean=torch.randn(K * D, dtype=torch.float64) * 0.1,
+                                running_variance=torch.rand(K * D, dtype=torch.float64) + 0.5, precision=precision)
     st = dict(joint_pos=r(N, nd), joint_vel=r(N, nd), joint_acc=r(N, nd) * 30, actions=r(N, nd) * 0.5,
               root_pos=torch.cat([r(N, 2), torch.rand(N, 1, generator=g, device="cuda") * 0.6 + 0.35], 1).contiguous(),
               root_quat=torch.nn.functional.normalize(r(N, 4), dim=1), root_lin_vel=r(N, 3), root_ang_vel=r(N, 3),
