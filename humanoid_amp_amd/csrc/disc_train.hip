@@ -192,23 +192,77 @@ __global__ __launch_bounds__(kBlock) void sumsq_part_kernel(float* __restrict__ 
   if (threadIdx.x == 0) part[blockIdx.x] = red[0];
 }
 
-// Adam on one tensor; the L2-type regularisers enter as grad += reg2 * p  (reg2 = 2 * loss_scale * coefficient)
-__global__ __launch_bounds__(kBlock) void adam_kernel(float* __restrict__ p, int64_t ld_p, const float* __restrict__ g, int64_t ld_g,
-                                                      float* __restrict__ m, float* __restrict__ v, int64_t rows, int cols,
-                                                      float reg2, float lr, float b1, float b2, float eps, float bc1, float bc2,
-                                                      float* __restrict__ grad_out) {
+// Adam; the L2-type regularisers enter as grad += reg2 * p  (reg2 = 2 * loss_scale * coefficient).
+// The six parameter tensors in ONE launch (they are 4-6 us each alone, launch-bound): segment s covers the flat indices
+// [start[s], start[s + 1]).
+struct AdamSegs {
+  float* p[6]; const float* g[6]; float* m[6]; float* v[6];
+  int64_t ld_p[6], ld_g[6], start[7];
+  int32_t cols[6];
+  float reg2[6];
+};
+__global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamSegs a, float lr, float b1, float b2, float eps, float bc1, float bc2,
+                                                            float* __restrict__ grad_out) {
   const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (e >= rows * cols) return;
-  const int64_t r = e / cols;
-  const int c = (int)(e - r * cols);
-  const float pv = p[r * ld_p + c];
-  const float gr = g[r * ld_g + c] + reg2 * pv;
-  if (grad_out) grad_out[e] = gr;
-  const float mi = b1 * m[e] + (1.0f - b1) * gr;
-  const float vi = b2 * v[e] + (1.0f - b2) * gr * gr;
-  m[e] = mi;
-  v[e] = vi;
-  p[r * ld_p + c] = pv - lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+  if (e >= a.start[6]) return;
+  int s = 0;
+#pragma unroll
+  for (int k = 1; k < 6; ++k) s += e >= a.start[k];
+  const int64_t i = e - a.start[s];
+  const int64_t r = i / a.cols[s];
+  const int c = (int)(i - r * a.cols[s]);
+  float* pp = a.p[s] + r * a.ld_p[s] + c;
+  const float pv = *pp;
+  const float gr = a.g[s][r * a.ld_g[s] + c] + a.reg2[s] * pv;
+  if (grad_out) grad_out[e] = gr;  // parameter order, logical shapes: the segments are laid out that way
+  const float mi = b1 * a.m[s][i] + (1.0f - b1) * gr;
+  const float vi = b2 * a.v[s][i] + (1.0f - b2) * gr * gr;
+  a.m[s][i] = mi;
+  a.v[s][i] = vi;
+  *pp = pv - lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+}
+
+// sums of squares of W1 (logical [h1, in_dim] inside rows of k1p), W2 and w3 in one launch -> part[3][gridDim.x]
+__global__ __launch_bounds__(kBlock) void reg_sumsq_kernel(const float* __restrict__ w1, int64_t rows1, int cols1, int64_t ld1,
+                                                           const float* __restrict__ w2, int64_t n2, const float* __restrict__ w3,
+                                                           int64_t n3, float* __restrict__ part) {
+  __shared__ float red[3][kBlock];
+  float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+  const int64_t stride = (int64_t)gridDim.x * kBlock, t0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  for (int64_t e = t0; e < rows1 * cols1; e += stride) {
+    const int64_t i = e / cols1;
+    const float v = w1[i * ld1 + (e - i * cols1)];
+    s1 += v * v;
+  }
+  for (int64_t e = t0; e < n2; e += stride) s2 += w2[e] * w2[e];
+  for (int64_t e = t0; e < n3; e += stride) s3 += w3[e] * w3[e];
+  red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2; red[2][threadIdx.x] = s3;
+  __syncthreads();
+  for (int off = kBlock / 2; off > 0; off >>= 1) {
+    if (threadIdx.x < off)
+      for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) part[threadIdx.x * gridDim.x + blockIdx.x] = red[threadIdx.x][0];
+}
+// loss[2] = logit_reg * sum w3^2 ; loss[3] = weight_decay * (sum W1^2 + sum W2^2 + sum w3^2)
+__global__ void reg_final_kernel(const float* __restrict__ part, int n, float logit_reg, float weight_decay, float* __restrict__ loss) {
+  __shared__ float red[3][256];
+  for (int k = 0; k < 3; ++k) {
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 256) s += part[k * n + i];
+    red[k][threadIdx.x] = s;
+  }
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off)
+      for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    loss[2] = logit_reg * red[2][0];
+    loss[3] = ((weight_decay * red[0][0]) + weight_decay * red[1][0]) + weight_decay * red[2][0];
+  }
 }
 
 // RunningStandardScaler update (train=True), two stages.  Stage 1: grid (ceil(cols/64), kChunks): per-chunk column sums
@@ -236,10 +290,17 @@ __global__ __launch_bounds__(kBlock) void scaler_part_kernel(const float* __rest
     part[((int64_t)blockIdx.y * cols + c) * 2 + 1] = (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
   }
 }
+// (+ the fp32 vectors the scaling pass reads -- mean32 / den32 [np], same formulas as disc_scaler_kernel -- so that a group's
+//  batch is scaled with the statistics that include it without a round trip through the discriminator handle)
 __global__ __launch_bounds__(kBlock) void scaler_merge_kernel(const double* __restrict__ part, int64_t rows, int cols,
-                                                              double* __restrict__ mean, double* __restrict__ var, double count) {
+                                                              double* __restrict__ mean, double* __restrict__ var, double count,
+                                                              int np, float eps, float* __restrict__ mean32,
+                                                              float* __restrict__ den32) {
   const int c = blockIdx.x * kBlock + threadIdx.x;
-  if (c >= cols) return;
+  if (c >= cols) {
+    if (mean32 && c < np) { mean32[c] = 0.0f; den32[c] = 1.0f; }
+    return;
+  }
   double s = 0.0, q = 0.0;
   for (int ch = 0; ch < kChunks; ++ch) {
     s += part[((int64_t)ch * cols + c) * 2 + 0];
@@ -249,8 +310,13 @@ __global__ __launch_bounds__(kBlock) void scaler_merge_kernel(const double* __re
   const double bv = (q - n * bm * bm) / (n - 1.0);  // fp64 sums of fp32 data: the cancellation is harmless
   const double total = count + n, delta = bm - mean[c];
   const double m2 = var[c] * count + bv * n + delta * delta * count * n / total;
-  mean[c] = mean[c] + delta * n / total;
-  var[c] = m2 / total;
+  const double mean_new = mean[c] + delta * n / total, var_new = m2 / total;
+  mean[c] = mean_new;
+  var[c] = var_new;
+  if (mean32) {
+    mean32[c] = (float)mean_new;
+    den32[c] = sqrtf((float)var_new) + eps;
+  }
 }
 
 __global__ void scaler_to_f32_kernel(const double* __restrict__ mean64, const double* __restrict__ var64, int n, int np, float eps,
@@ -515,7 +581,8 @@ int amp_disc_trainer_create(AmpDisc* disc, const AmpDiscTrainCfg* cfg, const dou
                     B * p.h2 + B * p.h1 + B * t->kN + B * p.h1 + B * p.h2 +                        // a2 a1 g e1 da2
                     (int64_t)p.h1 * Bp + (int64_t)t->kN * Bp + (int64_t)p.h2 * Bp + (int64_t)p.h1 * Bp +  // a1T dgT a2T e1T
                     (int64_t)p.h1 * t->kN + p.h1 + (int64_t)p.h2 * p.h1 + p.h2 + p.h2 + 1 + 64;    // grads + loss
-  t->ws_floats = f + (int64_t)16 * p.h2 * p.h1 + (int64_t)kChunks * 1024 + 1024 + (int64_t)kChunks * p.in_dim * 4 + 16 + 16 * 40;
+  t->ws_floats = f + (int64_t)16 * p.h2 * p.h1 + (int64_t)kChunks * 1024 + 1024 + (int64_t)kChunks * p.in_dim * 4 + 16 + 16 * 40 +
+                 2 * up(p.k1p, 16);
   if (e == hipSuccess) e = hipMalloc(&t->ws, sizeof(float) * t->ws_floats);
   if (e == hipSuccess && !cfg->gemm_fp32) {
     // fp16-split GEMM path: planes of the largest operand ([3B (padded), max(h1, h2)] or its transpose), twice
@@ -598,6 +665,8 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
   float* split = take((int64_t)16 * H2n * H1n);                  // split-K partial products (largest: gW2)
   float* part = take((int64_t)kChunks * 1024 + 1024);          // column-sum / scalar partials
   double* dpart = reinterpret_cast<double*>(take((int64_t)kChunks * p.in_dim * 4 + 16));
+  float* mean32w = take(k1p);  // the running statistics as the scaling pass reads them (refreshed per group)
+  float* den32w = take(k1p);
   AMP_REQUIRE(w - t->ws <= t->ws_floats, "amp_disc_train_step: internal workspace overflow");
   AMP_REQUIRE(H1n <= 1024 && H2n <= 1024, "amp_disc_train_step: hidden sizes above 1024 are not supported");
   auto colsum = [&](const float* A, int64_t rows_, int cols_, int64_t lda_, const float* rowscale, const float* mask, int64_t ldm,
@@ -636,22 +705,31 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
   const float* den32 = nullptr;
   float clip = 0.0f;
   const float* groups[3] = {policy, replay, motion};
+  if (c.use_scaler && !c.update_scaler) {
+    // frozen statistics: the fp32 vectors already live in the discriminator handle
+    rc = amp_disc_set_scaler(t->disc, t->mean64, t->var64, c.scaler_epsilon, c.scaler_clip, stream);
+    if (rc != AMP_OK) return rc;
+    AmpDiscInputLayout lay;
+    amp_disc_input_layout(t->disc, &lay);
+    mean32 = lay.mean_dev; den32 = lay.den_dev; clip = lay.clip;
+  }
   for (int gi = 0; gi < 3; ++gi) {
     if (c.update_scaler) {
+      // each batch updates the running statistics, then is scaled with them (skrl order); the merge also writes the fp32
+      // vectors the scaling pass reads
       scaler_part_kernel<<<dim3((p.in_dim + 63) / 64, kChunks), kBlock, 0, st>>>(groups[gi], B, p.in_dim, row_stride, dpart);
-      scaler_merge_kernel<<<(p.in_dim + kBlock - 1) / kBlock, kBlock, 0, st>>>(dpart, B, p.in_dim, t->mean64, t->var64, t->count);
+      scaler_merge_kernel<<<(k1p + kBlock - 1) / kBlock, kBlock, 0, st>>>(dpart, B, p.in_dim, t->mean64, t->var64, t->count, k1p,
+                                                                         c.scaler_epsilon, c.use_scaler ? mean32w : nullptr, den32w);
       t->count += (double)B;
-    }
-    if (c.use_scaler) {
-      // the fp32 vectors live in the discriminator handle: refresh them there so inference sees the same scaler
-      rc = amp_disc_set_scaler(t->disc, t->mean64, t->var64, c.scaler_epsilon, c.scaler_clip, stream);
-      if (rc != AMP_OK) return rc;
-      AmpDiscInputLayout lay;
-      amp_disc_input_layout(t->disc, &lay);
-      mean32 = lay.mean_dev; den32 = lay.den_dev; clip = lay.clip;
+      if (c.use_scaler) { mean32 = mean32w; den32 = den32w; clip = c.scaler_clip; }
     }
     scale_rows_kernel<<<blocks(B * k1p), kBlock, 0, st>>>(groups[gi], row_stride, B, p.in_dim, k1p, mean32, den32, clip,
                                                          Xs + gi * B * k1p);
+  }
+  if (c.use_scaler && c.update_scaler) {
+    // the discriminator handle serves inference with the statistics after the third batch
+    rc = amp_disc_set_scaler(t->disc, t->mean64, t->var64, c.scaler_epsilon, c.scaler_clip, stream);
+    if (rc != AMP_OK) return rc;
   }
   rc = launch_status("scale_rows_kernel");
   if (rc != AMP_OK) return rc;
@@ -712,37 +790,32 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
   }
 
   // ---- 5. regularisers (values for the report; their gradients are folded into the Adam kernel) ----------------
-  sumsq(p.w3, 1, H2n, H2n, 0.0f, 0, c.logit_reg_scale, 2, 0);
-  sumsq(p.w1p, H1n, p.in_dim, k1p, 0.0f, 0, c.weight_decay_scale, 3, 0);
-  sumsq(p.w2, H2n, H1n, H1n, 0.0f, 0, c.weight_decay_scale, 3, 1);
-  sumsq(p.w3, 1, H2n, H2n, 0.0f, 0, c.weight_decay_scale, 3, 1);
+  reg_sumsq_kernel<<<64, kBlock, 0, st>>>(p.w1p, H1n, p.in_dim, k1p, p.w2, (int64_t)H2n * H1n, p.w3, H2n, part);
+  reg_final_kernel<<<1, 256, 0, st>>>(part, 64, c.logit_reg_scale, c.weight_decay_scale, loss);
   if (loss_dev) AMP_HIP(hipMemcpyAsync(loss_dev, loss, 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
 
   // ---- 6. Adam -------------------------------------------------------------------------------------------------
   t->step += 1;
   const float bc1 = 1.0f - powf(c.beta1, (float)t->step), bc2 = 1.0f - powf(c.beta2, (float)t->step);
   const float wd2 = 2.0f * c.loss_scale * c.weight_decay_scale, lr2 = 2.0f * c.loss_scale * c.logit_reg_scale;
-  float* go = grads_dev;  // optional export, in parameter order, logical shapes
-  const int64_t n1 = (int64_t)H1n * p.in_dim, n2 = (int64_t)H2n * H1n;
   const float lr = c.apply_update ? c.learning_rate : 0.0f;
-  adam_kernel<<<blocks(n1), kBlock, 0, st>>>(p.w1p, k1p, gW1, kN, t->mom[0], t->vel[0], H1n, p.in_dim, wd2, lr, c.beta1, c.beta2,
-                                            c.adam_epsilon, bc1, bc2, go);
-  if (go) go += n1;
-  adam_kernel<<<blocks(H1n), kBlock, 0, st>>>(p.b1, H1n, gb1, H1n, t->mom[1], t->vel[1], 1, H1n, 0.0f, lr, c.beta1, c.beta2,
-                                             c.adam_epsilon, bc1, bc2, go);
-  if (go) go += H1n;
-  adam_kernel<<<blocks(n2), kBlock, 0, st>>>(p.w2, H1n, gW2, H1n, t->mom[2], t->vel[2], H2n, H1n, wd2, lr, c.beta1, c.beta2,
-                                            c.adam_epsilon, bc1, bc2, go);
-  if (go) go += n2;
-  adam_kernel<<<blocks(H2n), kBlock, 0, st>>>(p.b2, H2n, gb2, H2n, t->mom[3], t->vel[3], 1, H2n, 0.0f, lr, c.beta1, c.beta2,
-                                             c.adam_epsilon, bc1, bc2, go);
-  if (go) go += H2n;
-  adam_kernel<<<blocks(H2n), kBlock, 0, st>>>(p.w3, H2n, gw3, H2n, t->mom[4], t->vel[4], 1, H2n, wd2 + lr2, lr, c.beta1, c.beta2,
-                                             c.adam_epsilon, bc1, bc2, go);
-  if (go) go += H2n;
-  adam_kernel<<<1, kBlock, 0, st>>>(p.b3, 1, gb3, 1, t->mom[5], t->vel[5], 1, 1, 0.0f, lr, c.beta1, c.beta2, c.adam_epsilon, bc1, bc2,
-                                   go);
-  rc = launch_status("adam_kernel");
+  {
+    AdamSegs a{};
+    float* ps[6] = {p.w1p, p.b1, p.w2, p.b2, p.w3, p.b3};
+    const float* gs[6] = {gW1, gb1, gW2, gb2, gw3, gb3};
+    const int64_t ldp[6] = {k1p, H1n, H1n, H2n, H2n, 1}, ldg[6] = {kN, H1n, H1n, H2n, H2n, 1};
+    const int64_t rows_[6] = {H1n, 1, H2n, 1, 1, 1};
+    const int cols_[6] = {p.in_dim, H1n, H1n, H2n, H2n, 1};
+    const float reg[6] = {wd2, 0.0f, wd2, 0.0f, wd2 + lr2, 0.0f};
+    a.start[0] = 0;
+    for (int k = 0; k < 6; ++k) {
+      a.p[k] = ps[k]; a.g[k] = gs[k]; a.m[k] = t->mom[k]; a.v[k] = t->vel[k];
+      a.ld_p[k] = ldp[k]; a.ld_g[k] = ldg[k]; a.cols[k] = cols_[k]; a.reg2[k] = reg[k];
+      a.start[k + 1] = a.start[k] + rows_[k] * cols_[k];
+    }
+    adam_multi_kernel<<<blocks(a.start[6]), kBlock, 0, st>>>(a, lr, c.beta1, c.beta2, c.adam_epsilon, bc1, bc2, grads_dev);
+  }
+  rc = launch_status("adam_multi_kernel");
   if (rc != AMP_OK) return rc;
   return c.apply_update ? disc_refresh_derived(t->disc, st) : AMP_OK;
 }

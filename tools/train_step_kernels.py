@@ -24,3 +24,11 @@ for name, ms in t.records():
     print(f"{ms*1e3:8.1f} us  {name}")
     tot += ms
 print("kernel sum ms", tot, "launches", len(t.records()))
+import time
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(50): tr.step(*x)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print("host issue ms/step", (t1 - t0) / 50 * 1e3, " wall ms/step incl. drain", (t2 - t0) / 50 * 1e3)
