@@ -170,3 +170,28 @@ def test_product_never_imports_the_oracle():
     for fn in [n for n in tree.body if isinstance(n, ast.FunctionDef)]:
         uses = any(isinstance(n, ast.ImportFrom) and (n.module or "").startswith("oracle") for n in ast.walk(fn))
         assert uses == (fn.name == "cpu_baseline"), fn.name
+
+
+def test_shipped_clips_pass_the_surveys_self_checks():
+    """the only self-checks the reference's own data offers -- fps = 60 in every clip, the clips' frame
+    counts, unit body quaternions -- hold for the clips this package ships (read with allow_pickle=False)."""
+    import glob
+
+    import numpy as np
+
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "humanoid_amp_amd", "motions")
+    want = {"G1_walk.npz": (399, 29, 11), "G1_dance.npz": (601, 29, 39), "humanoid_dance.npz": (902, 28, 15),
+            "humanoid_run.npz": (82, 28, 15), "humanoid_walk.npz": (154, 28, 15)}
+    seen = {}
+    for path in sorted(glob.glob(os.path.join(root, "*.npz"))):
+        d = np.load(path, allow_pickle=False)
+        assert int(d["fps"]) == 60, path
+        frames, dofs = d["dof_positions"].shape
+        bodies = d["body_rotations"].shape[1]
+        seen[os.path.basename(path)] = (frames, dofs, bodies)
+        for key in ("dof_velocities", "body_positions", "body_linear_velocities", "body_angular_velocities"):
+            assert d[key].shape[0] == frames and d[key].dtype in (np.float32, np.float64), (path, key)
+        norm = np.linalg.norm(d["body_rotations"].astype(np.float64), axis=-1)
+        assert norm.min() > 1.0 - 1e-6 and norm.max() < 1.0 + 1e-6, (path, norm.min(), norm.max())
+        assert len(d["dof_names"]) == dofs and len(d["body_names"]) == bodies
+    assert seen == want
