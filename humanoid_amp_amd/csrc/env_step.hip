@@ -2,18 +2,18 @@
 // in-place K-frame history shift, policy observation (+ optional actor history with reset warm-start).
 // One pass, any subset of the three phases.  gfx950 only; -ffp-contract=off.
 //
-// Work decomposition: a workgroup (256 lanes) owns a TILE of 32 / 16 consecutive envs (amp_env_step_tile_envs).
-//   stage   the tile's [64, n_dof] rows of joint_pos / joint_vel (/ actions / joint_acc) are contiguous in
-//           HBM: lanes walk them flat (coalesced) into the LDS observation tile.
-//   per-env wave 0, one env per lane: root-body features (quat_apply x2), done bits, wave ballot ->
-//           reset count of the tile.  The four reward reductions run one (env, term) per lane on all 4 waves.
-//   write   every output (AMP buffer rows, policy obs, actor history) is walked flat from the LDS tile, so
-//           stores are contiguous runs of D (or P) floats per env.
+// Work decomposition: a workgroup (256 lanes) owns a TILE of 32 / 16 / 8 consecutive envs (amp_env_step_tile_envs).
+// Two bodies, bit-identical where both apply:
+//   * the GENERIC body (any phase subset, actor history, strided inputs, ragged last tile): lanes walk the tile's
+//     [tile, n_dof] rows flat into an LDS observation tile; wave 0, one env per lane, does the root-body features, done
+//     bits and the wave ballot -> reset count; the four reward reductions run one (env, term) per lane on all 4 waves;
+//     every output is walked flat from the LDS tile (contiguous runs of D or P floats per env);
+//   * the DMA tile body (the hot-path configuration: all three phases, no actor history, whole tiles): inputs by LDS-DMA,
+//     outputs walked column-major -- see env_step_dma_pass.
+// With an expert-sample request the launch also carries the expert tiles (collect_reference_*_body, motion_kernels.hpp).
 #include "amp_common.hpp"
 #include "motion_kernels.hpp"
-#include <cstdlib>
 #include <type_traits>
-#include <cstring>
 
 namespace amp {
 
