@@ -278,3 +278,54 @@ def test_dma_tile_body_matches_generic_body(N, K, nd, precision):
     for name in ("amp_observation_buffer", "policy_obs", "reward", "died", "time_out", "reset_mask", "reset_tile_counts", "disc_input"):
         assert torch.equal(getattr(a, name), getattr(b, name)), name
     assert a.disc_input.abs().sum() > 0
+
+
+@pytest.mark.parametrize("nd,n_key,K,last_actions,reward_mode,track,N", [
+    (5, 1, 4, True, 1, 1.0, 1000),      # tiny rows, one key body, K = 4
+    (64, 8, 2, True, 1, 0.0, 2000),     # 64 DoFs, the maximum of key bodies, odd policy width, no command
+    (33, 3, 6, True, 1, 1.0, 900),      # > 32 DoFs (two 16-B pieces per lane column), K = 6
+    (28, 4, 2, False, 0, 0.0, 5000),    # humanoid: policy obs = AMP frame (odd width), constant task reward
+    (12, 2, 2, True, 0, 0.0, 700),      # constant task reward with last_actions in the policy obs
+    (29, 4, 12, True, 1, 1.0, 400),     # K = 12: 8-env tiles
+    (7, 5, 3, True, 1, 1.0, 40000),     # K * D even with odd K, 32-env tiles
+])
+def test_dma_tile_body_config_sweep(nd, n_key, K, last_actions, reward_mode, track, N):
+    """One all-phase launch (the DMA tile body on every whole tile) against the three single-phase launches (the generic
+    body) over configurations the BASELINE workloads do not reach: every output bit-identical, with a fused discriminator
+    input on the all-phase side compared against the separate scaler pass."""
+    from humanoid_amp_amd.engine import AmpDiscriminator, EnvStepConfig, EnvStepKernel
+    from humanoid_amp_amd import _native as nat
+    from humanoid_amp_amd.workloads import make_disc_weights
+
+    g = torch.Generator(device="cuda").manual_seed(nd * 100 + K)
+    r = lambda *s: torch.randn(*s, generator=g, device="cuda")  # noqa: E731
+    cfg = EnvStepConfig(n_dof=nd, n_key=n_key, num_amp_observations=K, max_episode_length=300, use_last_actions=last_actions,
+                        reward_mode=reward_mode, rew_termination=-1.0, rew_action_l2=-0.1, rew_joint_pos_limits=-10.0,
+                        rew_joint_acc_l2=-1e-6, rew_joint_vel_l2=-1e-3, rew_track_vel=track)
+    D = cfg.amp_frame_size
+    st = dict(joint_pos=r(N, nd), joint_vel=r(N, nd), joint_acc=r(N, nd) * 30, actions=r(N, nd) * 0.5,
+              root_pos=torch.cat([r(N, 2), torch.rand(N, 1, generator=g, device="cuda") * 0.6 + 0.35], 1).contiguous(),
+              root_quat=torch.nn.functional.normalize(r(N, 4), dim=1), root_lin_vel=r(N, 3), root_ang_vel=r(N, 3),
+              body_pos=r(N, n_key + 2, 3), key_body_indexes=list(range(n_key, 0, -1)),
+              soft_limits=torch.tensor([[-1.41, 1.41]] * nd, device="cuda"),
+              episode_length=torch.randint(0, 300, (N,), generator=g, device="cuda"), command=r(N, 2), last_actions=r(N, nd))
+    disc = AmpDiscriminator(make_disc_weights(K * D, seed=0), "cuda:0", running_mean=torch.randn(K * D, dtype=torch.float64) * 0.1,
+                            running_variance=torch.rand(K * D, dtype=torch.float64) + 0.5)
+    a, b = EnvStepKernel(cfg, N, "cuda:0"), EnvStepKernel(cfg, N, "cuda:0")
+    init = r(N, K, D)
+    a.amp_observation_buffer.copy_(init)
+    b.amp_observation_buffer.copy_(init)
+    a.attach_discriminator(disc)
+    b.attach_discriminator(disc)
+    a.launch(nat.AMP_PHASE_ALL, **st)
+    for ph in (nat.AMP_PHASE_DONES, nat.AMP_PHASE_REWARD, nat.AMP_PHASE_OBS):
+        b.launch(ph, **st)
+    for name in ("amp_observation_buffer", "policy_obs", "reward", "died", "time_out", "reset_mask", "reset_tile_counts", "disc_input"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    for k in range(1, K):
+        assert torch.equal(a.amp_observation_buffer[:, k], init[:, k - 1])   # slot k <- old slot k - 1
+    assert torch.equal(a.amp_observation_buffer[:, 0, :nd], st["joint_pos"])
+    # the fused input equals the stand-alone scaler pass on the new rows
+    ref = disc.style_reward(a.amp_observation_buffer.view(N, -1), want_logits=True)["logits"]
+    got = disc.style_reward_prescaled(a.disc_input, want_logits=True)["logits"]
+    assert torch.equal(ref, got)
