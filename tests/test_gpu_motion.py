@@ -138,3 +138,21 @@ def test_collect_reference_vs_reference(name, tag, keys, loaders):
     untouched = torch.ones(100, dtype=torch.bool, device="cuda")
     untouched[rows] = False
     assert float(buf[untouched].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("n,K", [(1, 1), (31, 2), (129, 2), (1000, 3), (27, 10), (333, 10)])
+def test_collect_reference_wide_tiles_match_the_scatter_form(n, K, loaders):
+    """The contiguous form runs 256-sample workgroups (a lane owns a column quad and walks samples), the scatter form the
+    64-sample body: the same rows bit for bit over ragged sizes, several K and every clip set."""
+    for tag, keys in (("g1_walk", gu.G1_KEY_BODIES), ("g1_dance", gu.G1_KEY_BODIES), ("humanoid3", gu.HUM_KEY_BODIES)):
+        ml = loaders[tag]
+        fx = gu.golden(f"collect_{'g1_walk_k2' if tag == 'g1_walk' else 'g1_dance_k10' if tag == 'g1_dance' else 'humanoid3_k2'}")
+        D = ml.set_obs_layout(fx["motion_dof_indexes"].tolist(), int(fx["motion_ref_body_index"]), fx["motion_key_body_indexes"].tolist())
+        rng = np.random.default_rng(n * 31 + K)
+        ids = rng.integers(0, ml.num_trajectories, size=n)
+        t = rng.uniform(-0.1, 1.05, size=n) * ml.durations[ids]
+        wide = ml.collect_reference(t, ids, K)
+        buf = torch.zeros((n + 5, K, D), device="cuda")
+        rows = torch.from_numpy(rng.permutation(n + 5)[:n].astype(np.int64)).cuda()
+        ml.collect_reference(t, ids, K, out=buf, dst_rows=rows)
+        assert torch.equal(buf[rows].view(n, -1), wide), (tag, n, K)
