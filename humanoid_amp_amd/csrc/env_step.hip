@@ -762,7 +762,8 @@ static int pick_tile(const EnvPlan& p, int64_t num_envs) {
   // tiles; 16 384 envs 39 / 27 / 23 us.  DMA body inside the step: 16 384 envs 21.5 us with 16-env tiles, 17.7 us with 32
   // (per-workgroup setup and per-env work amortise over twice the rows); 8 192 envs 14.9 vs 14.1 us (equal: one workgroup
   // per CU either way).  Shards of 16 384 envs and more use 32, smaller ones are spread over the whole chip with 16
-  // (latency-bound there); the tile is halved (down to 8) until the DMA body's [tile, K*D] LDS image fits 64 KB.
+  // (latency-bound there); the tile is halved (down to 8) until the DMA body's [tile, K*D] LDS image fits 64 KB (K = 10
+  // with 16-env tiles in 70 KB, two workgroups per CU: 216 vs 192 us per launch at 65 536 envs -- 8-env tiles stay).
   int tile = num_envs >= 16 * 1024 ? 32 : 16;
   while (tile > 8 && sizeof(float) * (size_t)env_dma_lds_floats(tile, p.K * p.D, p.n_dof, true) > 64 * 1024) tile >>= 1;
   return tile;
