@@ -1,6 +1,6 @@
 """CSV -> npz converter: achieved parity against the reference's shipped clips and throughput (run on the GPU box)."""
 import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from humanoid_amp_amd.motions.convert import G1_MODEL, MotionConverter

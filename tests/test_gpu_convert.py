@@ -24,7 +24,7 @@ def test_converter_reproduces_the_shipped_clip(fixture, gen, ang_tol, tmp_path):
     ref = oc.convert(g["csv_rows"], oc.load_model(G1_MODEL), joints, bodies, fps=int(g["fps"]), promotion=f"numpy{gen}")
     for k in ("dof_positions", "dof_velocities", "body_positions", "body_rotations", "body_linear_velocities", "body_angular_velocities"):
         assert out[k].dtype == g[k].dtype and out[k].shape == g[k].shape, k
-    # --- against the reference's file.  Measured on MI355X (tools/convert_bench.py): every array below is BIT-IDENTICAL
+    # --- against the reference's file.  Measured on MI355X (tests/perf/convert_bench.py): every array below is BIT-IDENTICAL
     # to the shipped clip; the bars leave one float32 ulp for the FK-derived ones (device sin / cos are not libm's)
     assert np.array_equal(out["dof_positions"], g["dof_positions"])              # float64, scipy's interp1d arithmetic
     assert np.array_equal(out["dof_velocities"], g["dof_velocities"])            # float64, differences + scipy's Gaussian

@@ -152,8 +152,10 @@ def test_shard_bounds_cover_every_env_once():
 
 def test_product_never_imports_the_oracle():
     """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
-    pkg = os.path.join(ROOT, "humanoid_amp_amd")
-    for dirpath, _, files in os.walk(pkg):
+    import itertools
+
+    walk = itertools.chain(os.walk(os.path.join(ROOT, "humanoid_amp_amd")), os.walk(os.path.join(ROOT, "tools")))
+    for dirpath, _, files in walk:
         for f in files:
             if not f.endswith(".py"):
                 continue
