@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <vector>
+#include <chrono>
 
 #include "../tools/experiments/disc_gemm_f16_dma4.hpp"
 #include "../tools/experiments/disc_gemm_f16_w4.hpp"
@@ -369,6 +370,57 @@ static void run_panel(GemmF16Args g, int64_t M, int N, int K, bool quiet) {
   }
 }
 
+// CONC=1 (with W4=1, mode 1): does a streaming kernel (the env step's byte mix: 78 MB read + 158 MB written, ~16 VGPRs, no
+// LDS -- it fits beside either GEMM kernel on a CU) run UNDER a layer-2 GEMM on a second stream, or do the two add up?
+typedef float conc_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void conc_mix_kernel(const conc_f4* __restrict__ src, conc_f4* __restrict__ dst, long n_items) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_items; i += stride) {
+    const conc_f4 v = src[i];
+    dst[i] = v;
+    dst[n_items + i] = v * 2.0f;
+  }
+}
+static void run_conc(GemmF16Args g, int64_t M, int N, int K) {
+  GemmF16Args g8 = g, g4 = g;
+  g8.A = g_Ab; g8.W = g_Wb; g8.n_tiles = N / 256; g8.m_tiles = (int)((M + 255) / 256);
+  g4 = g8; g4.n_tiles = N / kW4BN; g4.m_tiles = (int)((M + kW4BM - 1) / kW4BM);
+  const unsigned grid8 = (unsigned)(((int64_t)g8.m_tiles * g8.n_tiles + 7) / 8 * 8);
+  const unsigned grid4 = (unsigned)(((int64_t)g4.m_tiles * g4.n_tiles + 7) / 8 * 8);
+  void (*k8)(GemmF16Args) = disc_gemm_f16_dma_kernel<1, 4, 2>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, DmaTile<4, 2>::kLds));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gemm_f16_w4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kW4LdsBytes));
+  const long n_items = (long)(78e6 / 16);
+  conc_f4 *src[3], *dst[3];
+  for (int i = 0; i < 3; ++i) {
+    CK(hipMalloc(&src[i], n_items * 16)); CK(hipMalloc(&dst[i], 2 * n_items * 16));
+    CK(hipMemset(src[i], 0, n_items * 16)); CK(hipMemset(dst[i], 0, 2 * n_items * 16));
+  }
+  hipStream_t s2;
+  CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+  const int reps = 12;
+  auto timed = [&](const char* label, int gemm, bool mix) {
+    for (int warm = 0; warm < 2; ++warm) {
+      CK(hipDeviceSynchronize());
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int i = 0; i < reps; ++i) {
+        if (gemm == 8) k8<<<grid8, kDmaThreads, DmaTile<4, 2>::kLds>>>(g8);
+        if (gemm == 4) disc_gemm_f16_w4_kernel<<<grid4, kW4Threads, kW4LdsBytes>>>(g4);
+        if (mix) conc_mix_kernel<<<2048, 256, 0, s2>>>(src[i % 3], dst[i % 3], n_items);
+      }
+      CK(hipDeviceSynchronize());
+      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+      if (warm) printf("%-58s %8.1f us per iteration\n", label, us);
+    }
+  };
+  timed("streaming kernel alone (236 MB)", 0, true);
+  timed("8-wave layer-2 GEMM alone", 8, false);
+  timed("8-wave layer-2 GEMM + streaming kernel on a second stream", 8, true);
+  timed("4-wave layer-2 GEMM alone", 4, false);
+  timed("4-wave layer-2 GEMM + streaming kernel on a second stream", 4, true);
+  fflush(stdout);
+}
+
 int main(int argc, char** argv) {
   const int64_t M = argc > 1 ? atoll(argv[1]) : 65536;
   const int N = argc > 2 ? atoi(argv[2]) : 512;
@@ -561,6 +613,10 @@ int main(int argc, char** argv) {
       if (K == 192) { run_panel<12, 2>(g, M, N, K, false); check(0); run_panel<12, 1>(g, M, N, K, false); check(0); }
       run_dma<0, 0, 4, 2>(g, M, N, K, false); check(0);
     }
+    return 0;
+  }
+  if (getenv("W4") && getenv("CONC") && mode == 1) {
+    run_conc(g, M, N, K);
     return 0;
   }
   if (getenv("W4")) {
