@@ -375,6 +375,7 @@ namespace {
 unsigned blocks(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
 constexpr int kAmaxSlots = 64;
+constexpr int kShapeNotSupported = 1;  // gemm_f16x3: "not for this shape" (not an error: the caller takes the fp32 engine)
 
 // abs-max of a [rows, cols] block (row pitch ld) into out[0] (zeroed before): non-negative floats order like their bit
 // patterns, so one integer atomicMax per workgroup does it
@@ -416,15 +417,15 @@ int f16x3_init() {
 // C[M, N] (ld = ldc) = A W^T at fp32 accuracy on the fp16 matrix pipe: both operands are split into two fp16 planes in
 // block layout (scale = the power of two that brings the operand's abs-max below 2^15) and multiplied by the LDS-DMA
 // kernel of the inference path (three MFMAs per product, disc_gemm_f16_dma.hpp, MODE 2).  A is [M, K] (row pitch lda),
-// W is [N, K] (row pitch ldw); K is padded to 32 with zeros.  Returns AMP_ERR_UNSUPPORTED-like 1 when the shape does not
-// fit the kernel (the caller then takes the fp32 engine).
+// W is [N, K] (row pitch ldw); K is padded to 32 with zeros.  Returns kShapeNotSupported when the shape does not
+// fit the kernel (kShapeNotSupported: the caller then takes the fp32 engine).
 int gemm_f16x3(hipStream_t st, AmpDiscTrainer* t, const float* A, int64_t lda, int64_t M, const float* W, int64_t ldw, int N,
                int K, const float* bias, int relu, float* C, int64_t ldc, const float* mask, int64_t ldmask, int accumulate,
                float* split, int64_t split_floats) {
   const int Kp = (int)up(K, 32);
   if (!t->planes[0] || N % 128 != 0 || M < 128 || M * (int64_t)Kp * 2 > t->plane_halves || (int64_t)N * Kp * 2 > t->plane_halves)
-    return 1;
-  if (t->amax_next + 2 > kAmaxSlots) return 1;
+    return kShapeNotSupported;
+  if (t->amax_next + 2 > kAmaxSlots) return kShapeNotSupported;
   float* am_a = t->amax + t->amax_next++;
   float* am_w = t->amax + t->amax_next++;
   const int64_t na = M * (int64_t)K, nw = (int64_t)N * K;
@@ -696,7 +697,7 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
                 int64_t ldmask, int accumulate, float* split_ws = nullptr) -> int {
     if (f16) {
       const int r = gemm_f16x3(st, t, A, lda, Mr, W, Kp, N, Kp, nullptr, 0, C, ldc, mask, ldmask, accumulate, split_ws, split_floats);
-      if (r != 1) return r;
+      if (r != kShapeNotSupported) return r;
     }
     return gemm_nt(st, A, lda, Mr, W, Kp, N, C, ldc, mask, ldmask, accumulate, split_ws);
   };
