@@ -334,6 +334,13 @@ __device__ __forceinline__ void dma4(const float* g, float* l) {   // 64 lanes x
 __device__ __forceinline__ void dma16(const float* g, float* l) {  // 64 lanes x 16 B -> LDS l + lane * 16
   __builtin_amdgcn_global_load_lds((env_gptr_t)g, (env_lptr_t)l, 16, 0, 0);
 }
+// the same with the non-temporal hint (gfx940+ cache policy bit 1): per-step state that no later kernel reads again
+__device__ __forceinline__ void dma4_nt(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((env_gptr_t)g, (env_lptr_t)l, 4, 0, 2);
+}
+__device__ __forceinline__ void dma16_nt(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((env_gptr_t)g, (env_lptr_t)l, 16, 0, 2);
+}
 
 // floats of LDS one tile of T envs needs (host and device agree through this one function)
 __host__ __device__ inline int env_dma_lds_floats(int T, int KD, int nd, bool per_env_limits) {
@@ -378,14 +385,14 @@ __device__ __forceinline__ void env_step_dma_pass(const EnvPlan& p, const AmpSim
     float* row = s_img + r * KD;
 #pragma unroll 1
     for (int c0 = 0; c0 < C; c0 += 64)  // slot k + 1 <- old slot k (g1_amp_env.py:187-190)
-      if (c0 + lane < C) dma4(buf + r * KD + c0 + lane, row + D + c0);
+      if (c0 + lane < C) dma4_nt(buf + r * KD + c0 + lane, row + D + c0);
     const float* gp = st.joint_pos + (tile_base + r) * st.joint_pos_stride;
     const float* gv = st.joint_vel + (tile_base + r) * st.joint_vel_stride;
 #pragma unroll 1
     for (int c0 = 0; c0 < nd; c0 += 64)
       if (c0 + lane < nd) {
-        dma4(gp + c0 + lane, row + c0);
-        dma4(gv + c0 + lane, row + nd + c0);
+        dma4_nt(gp + c0 + lane, row + c0);
+        dma4_nt(gv + c0 + lane, row + nd + c0);
       }
   }
   {
@@ -395,10 +402,10 @@ __device__ __forceinline__ void env_step_dma_pass(const EnvPlan& p, const AmpSim
       const int i = pc + lane;
       if (i < n16) {
         if (g1) {
-          dma16(st.actions + tile_base * nd + 4 * i, s_act + 4 * pc);
-          dma16(st.joint_acc + tile_base * nd + 4 * i, s_acc + 4 * pc);
+          dma16_nt(st.actions + tile_base * nd + 4 * i, s_act + 4 * pc);
+          dma16_nt(st.joint_acc + tile_base * nd + 4 * i, s_acc + 4 * pc);
         }
-        if (extra) dma16(st.last_actions + tile_base * nd + 4 * i, s_la + 4 * pc);
+        if (extra) dma16_nt(st.last_actions + tile_base * nd + 4 * i, s_la + 4 * pc);
       }
     }
     if (has_cmd && wave == 3 && lane < T / 2) dma16(st.command + tile_base * 2 + 4 * lane, s_cmd);
@@ -537,10 +544,12 @@ __device__ __forceinline__ void env_step_dma_pass(const EnvPlan& p, const AmpSim
   }
 
   // ---- outputs: LDS image -> HBM ----------------------------------------------------------------------------
-  {  // AMP buffer: the tile's rows are one contiguous 16-B aligned span
+  {  // AMP buffer: the tile's rows are one contiguous 16-B aligned span.  Non-temporal stores (here and for the policy
+     // observation): nothing in the step reads these rows back, and the lines they would claim in the Infinity Cache hold the
+     // hidden layer the GEMMs are about to stream through (measured: 328 -> 320 us per step at 65 536 envs)
     const f4* img4 = reinterpret_cast<const f4*>(s_img);
     f4* dst4 = reinterpret_cast<f4*>(buf);
-    for (int i = tid; i < T * KD / 4; i += kBlock) dst4[i] = img4[i];
+    for (int i = tid; i < T * KD / 4; i += kBlock) __builtin_nontemporal_store(img4[i], dst4 + i);
   }
   if (fused) {
     // the same rows, scaled, as the discriminator's input.  A lane owns the column pair (c, c + 1) -- c even, so both
@@ -620,10 +629,10 @@ __device__ __forceinline__ void env_step_dma_pass(const EnvPlan& p, const AmpSim
         float* dst = pol + (int64_t)r0 * P + c;
 #pragma unroll 2
         for (int r = r0; r < T; r += step, a += step * pa, b += step * pb, dst += step * P) {
-          float2 o;
+          env_f2 o;
           o.x = *a;
           o.y = *b;
-          *reinterpret_cast<float2*>(dst) = o;
+          __builtin_nontemporal_store(o, reinterpret_cast<env_f2*>(dst));
         }
       };
       const int PR = P >> 1;

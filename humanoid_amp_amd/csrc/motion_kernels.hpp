@@ -81,7 +81,8 @@ constexpr int kExpertTile = 64;  // samples per workgroup: many short workgroups
 // Phase B: a lane LERPs FOUR consecutive columns of one sample from two 16-B gathers (hot rows are padded to a
 //          16-B pitch) and drops them into an LDS image of the tile's output, which is contiguous in HBM
 //          ([64 samples][D floats], 16-B aligned) unless rows are scattered (dst_rows).
-// Phase C: the image is streamed out with 16-B stores, 1 KiB per wave instruction.
+// Phase C: the image is streamed out with 16-B non-temporal stores, 1 KiB per wave instruction (the expert rows feed the
+//          discriminator update, not the next kernels of the step).
 // `block` = index of the 64-sample tile, `s_img` = the workgroup's dynamic LDS (16-B aligned, expert_lds(D) bytes):
 // a device function so that it can also run as part of a horizontally fused launch (env_step.hip).
 __device__ __forceinline__ void collect_reference_body(const MotionView& v, const double* __restrict__ times,
@@ -159,7 +160,7 @@ __device__ __forceinline__ void collect_reference_body(const MotionView& v, cons
     if ((count & 3) == 0 && (((uintptr_t)dst) & 15) == 0) {
       const f4* src4 = reinterpret_cast<const f4*>(s_img);
       f4* dst4 = reinterpret_cast<f4*>(dst);
-      for (int e = threadIdx.x; e < (count >> 2); e += kBlock) dst4[e] = src4[e];
+      for (int e = threadIdx.x; e < (count >> 2); e += kBlock) __builtin_nontemporal_store(src4[e], dst4 + e);
     } else {
       for (int e = threadIdx.x; e < count; e += kBlock) dst[e] = s_img[e];
     }
@@ -281,7 +282,7 @@ __device__ __forceinline__ void collect_reference_wide_body(const MotionView& v,
     if ((count & 3) == 0 && (((uintptr_t)dst) & 15) == 0) {
       const f4* src4 = reinterpret_cast<const f4*>(s_img);
       f4* dst4 = reinterpret_cast<f4*>(dst);
-      for (int e = tid; e < (count >> 2); e += kBlock) dst4[e] = src4[e];
+      for (int e = tid; e < (count >> 2); e += kBlock) __builtin_nontemporal_store(src4[e], dst4 + e);
     } else {
       for (int e = tid; e < count; e += kBlock) dst[e] = s_img[e];
     }
