@@ -647,7 +647,7 @@ __device__ __forceinline__ void env_step_dma_pass(const EnvPlan& p, const AmpSim
         int pa;
         const float* a = source(c, pa) + r0 * pa;
         float* dst = pol + (int64_t)r0 * P + c;
-        for (int r = r0; r < T; r += step, a += step * pa, dst += step * P) *dst = *a;
+        for (int r = r0; r < T; r += step, a += step * pa, dst += step * P) __builtin_nontemporal_store(*a, dst);
       };
       if (P >= kBlock) {
         for (int c = tid; c < P; c += kBlock) column(c, 0, 1);
