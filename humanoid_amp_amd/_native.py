@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libamp_engine.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 AMP_DISC_F16X3, AMP_DISC_FP32 = 0, 1
 AMP_DISC_INPUT_F32_ROWS, AMP_DISC_INPUT_F16_BLOCKS = 0, 1
@@ -43,12 +43,19 @@ class AmpResetArgs(C.Structure):
         ("root_state", C.c_void_p), ("dof_pos", C.c_void_p), ("dof_vel", C.c_void_p), ("amp_obs_buffer", C.c_void_p),
         ("motion_ids", C.c_void_p), ("motion_times", C.c_void_p),
         ("env_motion_ids", C.c_void_p), ("env_motion_start_times", C.c_void_p), ("env_offset", C.c_int64),
+        ("episode_length", C.c_void_p), ("last_actions", C.c_void_p), ("just_reset", C.c_void_p), ("n_actions", C.c_int32),
+        ("reserved2", C.c_int32),
     ]
 
 
 class AmpCompactArgs(C.Structure):
     _fields_ = [("mask", C.c_void_p), ("tile_counts", C.c_void_p), ("tile_envs", C.c_int32), ("reserved", C.c_int32),
                 ("num_envs", C.c_int64), ("ids", C.c_void_p), ("count", C.c_void_p)]
+
+
+class AmpScatterRows(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("src_stride", C.c_int64), ("fill", C.c_float), ("width", C.c_int32), ("repeat", C.c_int32),
+                ("reserved", C.c_int32), ("add", C.c_void_p), ("dst", C.c_void_p), ("dst_stride", C.c_int64)]
 
 
 class AmpHotStepArgs(C.Structure):
@@ -162,6 +169,7 @@ SIGNATURES = {
     "amp_reset_reference_state": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _vp, _vp, _vp, _vp]),
     "amp_motion_sample_times": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _i32, _vp, _vp, _i64, _vp, _vp, _vp]),
     "amp_reset_apply": (C.c_int, [_vp, C.POINTER(AmpResetArgs), _vp]),
+    "amp_reset_compact_apply": (C.c_int, [_vp, C.POINTER(AmpCompactArgs), C.POINTER(AmpResetArgs), C.POINTER(AmpCommandArgs), _vp]),
     "amp_policy_obs_size": (_i64, [C.POINTER(AmpEnvCfg)]),
     "amp_actor_history_frame_size": (_i64, [C.POINTER(AmpEnvCfg)]),
     "amp_env_step": (C.c_int, [C.POINTER(AmpEnvCfg), C.POINTER(AmpSimState), C.POINTER(AmpEnvBuffers), _i64, C.c_uint32, _vp]),
@@ -172,6 +180,7 @@ SIGNATURES = {
     "amp_reset_compact_workspace_bytes": (_i64, [_i64]),
     "amp_reset_compact": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "amp_reset_compact_tiles": (C.c_int, [_vp, _vp, _i32, _i64, _vp, _vp, _vp]),
+    "amp_scatter_rows": (C.c_int, [C.POINTER(AmpScatterRows), _i32, _vp, _vp, _i64, _vp]),
     "amp_env_step_tile_envs": (_i32, [C.POINTER(AmpEnvCfg), _i64]),
     "amp_disc_create": (C.c_int, [C.POINTER(AmpDiscDesc), _vp, C.POINTER(_vp)]),
     "amp_disc_destroy": (C.c_int, [_vp]),

@@ -13,23 +13,9 @@
 //                    reward_terms [T, N] -> means [T] on the device (fp64 accumulation, fixed order: deterministic); the
 //                    host reads them only when extras["log"] is actually looked at.
 #include "amp_common.hpp"
+#include "command_kernels.hpp"
 
 namespace amp {
-
-constexpr uint32_t kCommandDomain = 0xA14C0000u;  // xor-ed into the key's high word: tick = +0, reset = +1
-
-__device__ __forceinline__ float u01_24(uint32_t r) { return (float)(r >> 8) * 5.9604644775390625e-08f; }  // [0, 1), 24 bits
-
-__device__ __forceinline__ void draw_command(uint64_t seed, uint64_t step, uint64_t env, uint32_t mode, float vel_lo,
-                                             float vel_span, float t_lo, float t_span, float& cx, float& cy, float& tl) {
-  uint32_t r[4];
-  philox4x32_10((uint32_t)env, (uint32_t)(env >> 32), (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)seed,
-                (uint32_t)(seed >> 32) ^ (kCommandDomain + mode), r);
-  // torch.rand(...) * (hi - lo) + lo: one fp32 multiply, one fp32 add (contraction is off)
-  cx = u01_24(r[0]) * vel_span + vel_lo;
-  cy = u01_24(r[1]) * vel_span + vel_lo;
-  tl = u01_24(r[2]) * t_span + t_lo;
-}
 
 __global__ __launch_bounds__(kBlock) void command_kernel(AmpCommandArgs a, int64_t N, int mode) {
   int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -58,33 +44,41 @@ __global__ __launch_bounds__(kBlock) void command_kernel(AmpCommandArgs a, int64
     return;
   }
   if (!a.env_ids && !(a.reset_mask && a.reset_mask[env])) return;
-  if (ranged) {
-    float cx, cy, tl;
-    draw_command(a.seed, a.step, (uint64_t)(a.env_offset + env), 1u, a.vel_lo, a.vel_span, a.t_lo, a.t_span, cx, cy, tl);
-    a.command[2 * env] = cx;
-    a.command[2 * env + 1] = cy;
-    a.time_left[env] = tl;
-  } else {  // fixed command (g1_amp_env.py:436-439)
-    a.command[2 * env] = a.vel_lo;
-    a.command[2 * env + 1] = 0.0f;
-    a.time_left[env] = __builtin_inff();
-  }
+  command_reset_env(a, env);
 }
 
-// one workgroup per term: thread t sums elements t, t + 256, ... in fp64, then a fixed binary tree over the 256 threads
-__global__ __launch_bounds__(kBlock) void reward_log_means_kernel(const float* __restrict__ terms, int64_t N,
-                                                                  float* __restrict__ means) {
-  __shared__ double red[kBlock];
+// One workgroup (1 024 lanes) per term.  Lane t owns elements t*4 .. t*4+3 of every 4 096-element trip and accumulates them
+// in fp64 in trip order; eight trips' 16-B loads are issued before the first add (the first version issued one dependent
+// 4-B load per trip and 256 lanes: 64 us at 65 536 envs, all latency), then a fixed binary tree over the lanes.
+constexpr int kMeansBlock = 1024;
+__global__ __launch_bounds__(kMeansBlock) void reward_log_means_kernel(const float* __restrict__ terms, int64_t N,
+                                                                       float* __restrict__ means) {
+  typedef float mf4 __attribute__((ext_vector_type(4)));
+  __shared__ double red[kMeansBlock];
   const float* row = terms + (int64_t)blockIdx.x * N;
   double s = 0.0;
-  for (int64_t i = threadIdx.x; i < N; i += kBlock) s += (double)row[i];
-  red[threadIdx.x] = s;
+  const int tid = threadIdx.x;
+  if ((reinterpret_cast<uintptr_t>(row) & 15) == 0) {
+    const mf4* row4 = reinterpret_cast<const mf4*>(row);
+    const int64_t n4 = N >> 2;
+    for (int64_t i = tid; i < n4; i += 8 * kMeansBlock) {
+      mf4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = i + k * kMeansBlock < n4 ? row4[i + k * kMeansBlock] : mf4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += ((double)v[k][0] + (double)v[k][1]) + ((double)v[k][2] + (double)v[k][3]);
+    }
+    for (int64_t i = (n4 << 2) + tid; i < N; i += kMeansBlock) s += (double)row[i];
+  } else {
+    for (int64_t i = tid; i < N; i += kMeansBlock) s += (double)row[i];
+  }
+  red[tid] = s;
   __syncthreads();
-  for (int o = kBlock / 2; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+  for (int o = kMeansBlock / 2; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) means[blockIdx.x] = (float)(red[0] / (double)N);
+  if (tid == 0) means[blockIdx.x] = (float)(red[0] / (double)N);
 }
 
 }  // namespace amp
@@ -116,7 +110,7 @@ int amp_reward_log_means(const float* reward_terms, int32_t n_terms, int64_t num
   AMP_REQUIRE(n_terms >= 1 && n_terms <= 64 && num_envs >= 1, "amp_reward_log_means: need 1..64 terms and >= 1 env");
   hipStream_t st = (hipStream_t)stream;
   { amp::TraceScope trace__("reward_log_means_kernel", st);
-    reward_log_means_kernel<<<(unsigned)n_terms, kBlock, 0, st>>>(reward_terms, num_envs, means);
+    reward_log_means_kernel<<<(unsigned)n_terms, kMeansBlock, 0, st>>>(reward_terms, num_envs, means);
   }
   return launch_status("reward_log_means_kernel");
 }

@@ -29,6 +29,28 @@ __global__ __launch_bounds__(kBlock) void compact_scatter_kernel(const uint8_t* 
   compact_scatter_body(blockIdx.x, mask, counts, N, n_tiles, sub, n_counts, ids, count_out);
 }
 
+// Device-count-bounded row scatter (amp_scatter_rows): item (i, r), i < min(max_n, *count), r < repeat, is one workgroup
+// pass over `width` floats.  Up to kMaxScatterOps independent ops share a launch (blockIdx.y = op).
+constexpr int kMaxScatterOps = 8;
+struct ScatterOps {
+  AmpScatterRows op[kMaxScatterOps];
+};
+__global__ __launch_bounds__(kBlock) void scatter_rows_kernel(ScatterOps ops, const int64_t* __restrict__ ids,
+                                                              const int64_t* __restrict__ count, int64_t max_n) {
+  const AmpScatterRows& o = ops.op[blockIdx.y];
+  const int64_t n = *count < max_n ? *count : max_n;
+  const int per = o.width * o.repeat;  // floats per destination row
+  // a thread owns one float of one destination row; rows are walked with a grid stride (n is only known on the device)
+  const int64_t total = n * per;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock) {
+    const int64_t i = e / per;
+    const int c = (int)(e - i * per), w = c % o.width;
+    float v = o.src ? o.src[i * o.src_stride + w] : o.fill;
+    if (o.add) v += o.add[c];
+    o.dst[ids[i] * o.dst_stride + c] = v;
+  }
+}
+
 }  // namespace amp
 
 using namespace amp;
@@ -58,6 +80,31 @@ int amp_reset_compact_tiles(const uint8_t* mask, const int32_t* counts, int32_t 
     compact_scatter_kernel<<<grid, kBlock, 0, (hipStream_t)stream>>>(mask, counts, N, n_tiles, sub, n_counts, ids, count);
   }
   return launch_status("compact_scatter_kernel");
+}
+
+int amp_scatter_rows(const AmpScatterRows* ops, int32_t n_ops, const int64_t* ids, const int64_t* count, int64_t max_n,
+                     amp_stream_t stream) {
+  AMP_REQUIRE(n_ops >= 0 && n_ops <= kMaxScatterOps, "amp_scatter_rows: at most %d ops per call", kMaxScatterOps);
+  AMP_REQUIRE(max_n >= 0, "amp_scatter_rows: negative max_n");
+  if (n_ops == 0 || max_n == 0) return AMP_OK;
+  AMP_REQUIRE(ops && ids && count, "amp_scatter_rows: null argument");
+  ScatterOps k{};
+  int per_max = 1;
+  for (int i = 0; i < n_ops; ++i) {
+    const AmpScatterRows& o = ops[i];
+    AMP_REQUIRE(o.dst && o.width >= 1 && o.repeat >= 1, "amp_scatter_rows: op %d needs dst, width >= 1 and repeat >= 1", i);
+    AMP_REQUIRE(o.dst_stride >= (int64_t)o.width * o.repeat, "amp_scatter_rows: op %d: dst_stride smaller than width * repeat", i);
+    AMP_REQUIRE(!o.src || o.src_stride >= o.width, "amp_scatter_rows: op %d: src_stride smaller than width", i);
+    k.op[i] = o;
+    per_max = o.width * o.repeat > per_max ? o.width * o.repeat : per_max;
+  }
+  // enough workgroups for a few hundred rows per pass; the grid-stride loop covers any count
+  int64_t want = (max_n * per_max + kBlock - 1) / kBlock;
+  const unsigned gx = (unsigned)(want < 1 ? 1 : (want > 256 ? 256 : want));
+  { amp::TraceScope trace__("scatter_rows_kernel", (hipStream_t)stream);
+    scatter_rows_kernel<<<dim3(gx, (unsigned)n_ops), kBlock, 0, (hipStream_t)stream>>>(k, ids, count, max_n);
+  }
+  return launch_status("scatter_rows_kernel");
 }
 
 int amp_reset_compact(const uint8_t* mask, int64_t N, int64_t* ids, int64_t* count, void* workspace, amp_stream_t stream) {

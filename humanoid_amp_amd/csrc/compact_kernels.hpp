@@ -8,10 +8,11 @@ constexpr int kTile = 64;
 
 // counts[] holds one entry per `64 / sub` envs (sub = 1, 2, 4 or 8 count entries per 64-env wave tile).  `block` = index of
 // the 4-tile group this 256-thread workgroup owns.
-__device__ __forceinline__ void compact_scatter_body(const int64_t block, const uint8_t* __restrict__ mask,
+// Returns this lane's slot in the ascending id list (-1: its env is not reset); `env_out` = the env the lane looks at.
+__device__ __forceinline__ int64_t compact_rank_body(const int64_t block, const uint8_t* __restrict__ mask,
                                                      const int32_t* __restrict__ counts, int64_t N, int64_t n_tiles, int sub,
                                                      int64_t n_counts, int64_t* __restrict__ ids,
-                                                     int64_t* __restrict__ count_out) {
+                                                     int64_t* __restrict__ count_out, int64_t& env_out) {
   __shared__ long long s_part[kBlock / kWave];
   __shared__ long long s_base;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -56,12 +57,24 @@ __device__ __forceinline__ void compact_scatter_body(const int64_t block, const 
   const int64_t i = my_tile * kTile + lane;
   const int bit = (i < N) ? (mask[i] != 0) : 0;
   const unsigned long long b = __ballot(bit);
+  int64_t slot = -1;
   if (bit) {
     const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
-    ids[base + rank] = i;
+    slot = base + rank;
+    ids[slot] = i;
   }
   // the workgroup holding the last tile publishes the total
   if (my_tile == n_tiles - 1 && lane == 0) *count_out = base + __popcll(b);
+  env_out = i;
+  return slot;
+}
+
+__device__ __forceinline__ void compact_scatter_body(const int64_t block, const uint8_t* __restrict__ mask,
+                                                     const int32_t* __restrict__ counts, int64_t N, int64_t n_tiles, int sub,
+                                                     int64_t n_counts, int64_t* __restrict__ ids,
+                                                     int64_t* __restrict__ count_out) {
+  int64_t env;
+  (void)compact_rank_body(block, mask, counts, N, n_tiles, sub, n_counts, ids, count_out, env);
 }
 
 }  // namespace amp

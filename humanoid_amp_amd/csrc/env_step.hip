@@ -307,8 +307,9 @@ __device__ __forceinline__ void env_step_body(const EnvPlan& p, const AmpSimStat
 }
 
 // ------------------------------------------------------------------------------------------------
-// DMA tile body -- the hot-path configuration: all three phases, any K >= 1, no actor history, whole tiles (checked on
-// the host; anything else runs the generic body).  Same arithmetic as the generic body, bit for bit.  The generic body
+// DMA tile body -- any phase subset (the hot path launches all three at once; the DirectRLEnv hooks launch DONES | REWARD
+// before the reset and OBS after it), any K >= 1, no actor history, whole tiles (checked on the host; anything else runs the
+// generic body).  Same arithmetic as the generic body, bit for bit.  The generic body
 // spends ~40 VALU instructions per output float on row/column splits, 64-bit addressing and 4-B stores and is bound by
 // instruction issue, and so was its first replacement (registers -> LDS scatter, ~1 900 VALU instructions per lane
 // around 86 KB of traffic per tile: PMC showed the SIMD issue slots ~94 % busy; profiles/r02_k_pmc_per_kernel.md).
@@ -343,9 +344,12 @@ __device__ __forceinline__ void dma16_nt(const float* g, float* l) {
 }
 
 // floats of LDS one tile of T envs needs (host and device agree through this one function)
-__host__ __device__ inline int env_dma_lds_floats(int T, int KD, int nd, bool per_env_limits) {
+// row pitch of the tile's LDS image: the whole [K*D] AMP row when observations are written, else just joint_pos | joint_vel
+// (+ 1: odd pitch, one-env-per-lane reads of the reward reductions stay conflict-free)
+__host__ __device__ inline int env_dma_row_pitch(int KD, int nd, bool obs) { return obs ? KD : ((2 * nd + 4) & ~3) + 1; }
+__host__ __device__ inline int env_dma_lds_floats(int T, int KD, int nd, bool per_env_limits, bool obs = true) {
   const int ndT = (T * nd + 3) & ~3;
-  return T * KD + 3 * ndT + 2 * T + 4 * T + 2 * ((KD + 3) & ~3) + (per_env_limits ? T : 1) * (2 * nd + 1);
+  return ((T * env_dma_row_pitch(KD, nd, obs) + 3) & ~3) + 3 * ndT + 2 * T + 4 * T + 2 * ((KD + 3) & ~3) + (per_env_limits ? T : 1) * (2 * nd + 1);
 }
 
 template <int T>
@@ -357,17 +361,21 @@ __device__ __forceinline__ void env_step_dma_pass(const EnvPlan& p, const AmpSim
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // the wave that does the per-env work rotates with the tile index: consecutive workgroups of a CU put it on different SIMDs
   const int role = (wave + (int)block) & 3;
-  const bool g1 = p.reward_mode == 1;
-  const bool extra = p.use_last_actions;  // policy obs = [obs[:Db] | last_actions | command]
+  // phase subset of this launch (wave-uniform): the hot path asks for all three, the DirectRLEnv hooks for DONES | REWARD
+  // before the reset and OBS after it
+  const bool do_dones = p.phases & AMP_PHASE_DONES, do_rew = p.phases & AMP_PHASE_REWARD, do_obs = p.phases & AMP_PHASE_OBS;
+  const bool g1 = do_rew && p.reward_mode == 1;
+  const bool extra = do_obs && p.use_last_actions;  // policy obs = [obs[:Db] | last_actions | command]
   const bool has_cmd = extra && p.use_command;
   const bool per_env_limits = g1 && st.soft_limits_stride != 0;
-  const bool fused = bf.disc_input != nullptr;
+  const bool fused = do_obs && bf.disc_input != nullptr;
   const bool scaled = fused && bf.scaler_mean != nullptr;
   const int lim_row = 2 * nd + 1;
   const int ndT = (T * nd + 3) & ~3;
+  const int RP = env_dma_row_pitch(KD, nd, do_obs);  // == KD whenever observations are written
 
   float* s_img = smem;                     // [T, K*D]  the tile's new AMP rows (== its span of the AMP buffer)
-  float* s_act = s_img + T * KD;           // [T, nd]   flat copies (reward / policy obs)
+  float* s_act = s_img + ((T * RP + 3) & ~3);  // [T, nd]   flat copies (reward / policy obs)
   float* s_acc = s_act + ndT;
   float* s_la = s_acc + ndT;
   float* s_cmd = s_la + ndT;               // [T, 2]
@@ -380,12 +388,15 @@ __device__ __forceinline__ void env_step_dma_pass(const EnvPlan& p, const AmpSim
   // (staging the 4-B granular pieces -- history and joint rows -- through registers instead, one column per lane, was
   //  measured equal at K = 2 and 13 % slower at K = 10)
   float* const buf = bf.amp_obs_buffer + tile_base * KD;
+  if (do_obs || g1) {
 #pragma unroll 1
   for (int r = wave; r < T; r += 4) {
-    float* row = s_img + r * KD;
+    float* row = s_img + r * RP;
+    if (do_obs) {
 #pragma unroll 1
-    for (int c0 = 0; c0 < C; c0 += 64)  // slot k + 1 <- old slot k (g1_amp_env.py:187-190)
-      if (c0 + lane < C) dma4_nt(buf + r * KD + c0 + lane, row + D + c0);
+      for (int c0 = 0; c0 < C; c0 += 64)  // slot k + 1 <- old slot k (g1_amp_env.py:187-190)
+        if (c0 + lane < C) dma4_nt(buf + r * KD + c0 + lane, row + D + c0);
+    }
     const float* gp = st.joint_pos + (tile_base + r) * st.joint_pos_stride;
     const float* gv = st.joint_vel + (tile_base + r) * st.joint_vel_stride;
 #pragma unroll 1
@@ -394,6 +405,7 @@ __device__ __forceinline__ void env_step_dma_pass(const EnvPlan& p, const AmpSim
         dma4_nt(gp + c0 + lane, row + c0);
         dma4_nt(gv + c0 + lane, row + nd + c0);
       }
+  }
   }
   {
     const int n16 = T * nd / 4;  // T * nd is a multiple of 4 (T >= 8)
@@ -434,54 +446,70 @@ __device__ __forceinline__ void env_step_dma_pass(const EnvPlan& p, const AmpSim
   // ---- per-env work: one env per lane of the role-0 wave, under the DMA's flight time -------------------------
   const bool env_lane = role == 0 && lane < T;
   const int64_t env = tile_base + lane;
+  const bool track = g1 && p.use_command;
   int died = 0;
   float rq[4], rl[3], cmd[2];
   if (role == 0) {
     int reset_bit = 0;
     if (env_lane) {
-      const int64_t ep_len = st.episode_length[env];
-      const float* g = st.root_pos + env * st.root_pos_stride;
-      const float px = g[0], py = g[1], pz = g[2];
-      const float* gq = st.root_quat + env * st.root_quat_stride;
-      rq[0] = gq[0]; rq[1] = gq[1]; rq[2] = gq[2]; rq[3] = gq[3];
-      const float* gl = st.root_lin_vel + env * st.root_lin_vel_stride;
-      rl[0] = gl[0]; rl[1] = gl[1]; rl[2] = gl[2];
-      const float* ga = st.root_ang_vel + env * st.root_ang_vel_stride;
-      const float ax = ga[0], ay = ga[1], az = ga[2];
-      const float* bp = st.body_pos + env * st.body_pos_stride;
+      // every load first (an un-needed one is skipped by a wave-uniform branch), then the arithmetic
+      int64_t ep_len = 0;
+      float px = 0.0f, py = 0.0f, pz = 0.0f, ax = 0.0f, ay = 0.0f, az = 0.0f;
       float kb[kMaxKey][3];
-#pragma unroll
-      for (int k = 0; k < kMaxKey; ++k) {  // branch-free: slots past n_key re-read key body 0 (a cache hit) and are dropped
-        const float* kp = bp + (int64_t)(k < p.n_key ? st.key_body[k] : st.key_body[0]) * 3;
-        kb[k][0] = kp[0]; kb[k][1] = kp[1]; kb[k][2] = kp[2];
+      if (do_dones) ep_len = st.episode_length[env];
+      if (do_obs || (do_dones && p.early_termination)) {
+        const float* g = st.root_pos + env * st.root_pos_stride;
+        px = g[0]; py = g[1]; pz = g[2];
       }
-      if (g1 && p.use_command) { cmd[0] = st.command[env * 2 + 0]; cmd[1] = st.command[env * 2 + 1]; }
-      // g1_amp_env.py:321-330
-      const int tout = ep_len >= p.max_episode_length - 1;
-      died = p.early_termination ? (pz < p.termination_height) : 0;
-      bf.died[env] = (uint8_t)died;
-      bf.time_out[env] = (uint8_t)tout;
-      reset_bit = died | tout;
-      if (bf.reset_mask) bf.reset_mask[env] = (uint8_t)reset_bit;
-      // compute_obs features that are not plain copies (g1_amp_env.py:545-555)
-      const Quat q{rq[0], rq[1], rq[2], rq[3]};
-      const Vec3 tg = quat_apply_ref(q, Vec3{1.0f, 0.0f, 0.0f});
-      const Vec3 nm = quat_apply_ref(q, Vec3{0.0f, 0.0f, 1.0f});
-      float* o = s_img + lane * KD + 2 * nd;
-      o[0] = pz;
-      o[1] = tg.x; o[2] = tg.y; o[3] = tg.z;
-      o[4] = nm.x; o[5] = nm.y; o[6] = nm.z;
-      o[7] = rl[0]; o[8] = rl[1]; o[9] = rl[2];
-      o[10] = ax; o[11] = ay; o[12] = az;
+      if (do_obs || track) {
+        const float* gq = st.root_quat + env * st.root_quat_stride;
+        rq[0] = gq[0]; rq[1] = gq[1]; rq[2] = gq[2]; rq[3] = gq[3];
+        const float* gl = st.root_lin_vel + env * st.root_lin_vel_stride;
+        rl[0] = gl[0]; rl[1] = gl[1]; rl[2] = gl[2];
+      }
+      if (do_obs) {
+        const float* ga = st.root_ang_vel + env * st.root_ang_vel_stride;
+        ax = ga[0]; ay = ga[1]; az = ga[2];
+        const float* bp = st.body_pos + env * st.body_pos_stride;
 #pragma unroll
-      for (int k = 0; k < kMaxKey; ++k)
-        if (k < p.n_key) {
-          o[13 + 3 * k + 0] = kb[k][0] - px;
-          o[13 + 3 * k + 1] = kb[k][1] - py;
-          o[13 + 3 * k + 2] = kb[k][2] - pz;
+        for (int k = 0; k < kMaxKey; ++k) {  // branch-free: slots past n_key re-read key body 0 (a cache hit) and are dropped
+          const float* kp = bp + (int64_t)(k < p.n_key ? st.key_body[k] : st.key_body[0]) * 3;
+          kb[k][0] = kp[0]; kb[k][1] = kp[1]; kb[k][2] = kp[2];
         }
+      }
+      if (track) { cmd[0] = st.command[env * 2 + 0]; cmd[1] = st.command[env * 2 + 1]; }
+      if (do_dones) {
+        // g1_amp_env.py:321-330
+        const int tout = ep_len >= p.max_episode_length - 1;
+        died = p.early_termination ? (pz < p.termination_height) : 0;
+        bf.died[env] = (uint8_t)died;
+        bf.time_out[env] = (uint8_t)tout;
+        reset_bit = died | tout;
+        if (bf.reset_mask) bf.reset_mask[env] = (uint8_t)reset_bit;
+      } else if (g1) {
+        died = bf.died[env];  // a REWARD launch after a separate DONES launch
+      }
+      if (do_obs) {
+        // compute_obs features that are not plain copies (g1_amp_env.py:545-555)
+        const Quat q{rq[0], rq[1], rq[2], rq[3]};
+        const Vec3 tg = quat_apply_ref(q, Vec3{1.0f, 0.0f, 0.0f});
+        const Vec3 nm = quat_apply_ref(q, Vec3{0.0f, 0.0f, 1.0f});
+        float* o = s_img + lane * KD + 2 * nd;
+        o[0] = pz;
+        o[1] = tg.x; o[2] = tg.y; o[3] = tg.z;
+        o[4] = nm.x; o[5] = nm.y; o[6] = nm.z;
+        o[7] = rl[0]; o[8] = rl[1]; o[9] = rl[2];
+        o[10] = ax; o[11] = ay; o[12] = az;
+#pragma unroll
+        for (int k = 0; k < kMaxKey; ++k)
+          if (k < p.n_key) {
+            o[13 + 3 * k + 0] = kb[k][0] - px;
+            o[13 + 3 * k + 1] = kb[k][1] - py;
+            o[13 + 3 * k + 2] = kb[k][2] - pz;
+          }
+      }
     }
-    if (bf.reset_tile_counts) {
+    if (do_dones && bf.reset_tile_counts) {
       const unsigned long long bits = __ballot(reset_bit);
       if (lane == 0) bf.reset_tile_counts[block] = __popcll(bits);
     }
@@ -491,7 +519,7 @@ __device__ __forceinline__ void env_step_dma_pass(const EnvPlan& p, const AmpSim
 
   // ---- task reward -------------------------------------------------------------------------------
   if (!g1) {
-    if (env_lane) bf.reward[env] = 1.0f;  // humanoid_amp_env.py:128-129
+    if (do_rew && env_lane) bf.reward[env] = 1.0f;  // humanoid_amp_env.py:128-129
   } else {
     // compute_rewards (g1_amp_env.py:564-606): the wave with role w reduces term w of env `lane` over the DoFs
     float acc = 0.0f;
@@ -501,7 +529,7 @@ __device__ __forceinline__ void env_step_dma_pass(const EnvPlan& p, const AmpSim
       } else if (role == 1) {
         const float* lim = s_lim + (per_env_limits ? lane * lim_row : 0);
         for (int j = 0; j < nd; ++j) {
-          const float x = s_img[lane * KD + j];
+          const float x = s_img[lane * RP + j];
           float o = -fminf(x - lim[2 * j], 0.0f);
           o += fmaxf(x - lim[2 * j + 1], 0.0f);
           acc += o;
@@ -509,7 +537,7 @@ __device__ __forceinline__ void env_step_dma_pass(const EnvPlan& p, const AmpSim
       } else if (role == 2) {
         for (int j = 0; j < nd; ++j) { const float a = s_acc[lane * nd + j]; acc += a * a; }
       } else {
-        for (int j = 0; j < nd; ++j) { const float a = s_img[lane * KD + nd + j]; acc += a * a; }
+        for (int j = 0; j < nd; ++j) { const float a = s_img[lane * RP + nd + j]; acc += a * a; }
       }
       s_red[role * T + lane] = acc;
     }
@@ -544,6 +572,7 @@ __device__ __forceinline__ void env_step_dma_pass(const EnvPlan& p, const AmpSim
   }
 
   // ---- outputs: LDS image -> HBM ----------------------------------------------------------------------------
+  if (!do_obs) return;
   {  // AMP buffer: the tile's rows are one contiguous 16-B aligned span.  Non-temporal stores (here and for the policy
      // observation): nothing in the step reads these rows back, and the lines they would claim in the Infinity Cache hold the
      // hidden layer the GEMMs are about to stream through (measured: 328 -> 320 us per step at 65 536 envs)
@@ -863,15 +892,18 @@ static int env_step_launch(const AmpEnvCfg* cfg, const AmpSimState* st, const Am
   // tile, and every other configuration, runs the generic body.
   auto aligned = [](const void* ptr, uintptr_t a) { return (reinterpret_cast<uintptr_t>(ptr) & (a - 1)) == 0; };
   auto rows16 = [&](const float* ptr, int64_t stride) { return stride == p.n_dof && aligned(ptr, 16); };
-  // DMA tile body: all phases, no actor history, whole tiles, K*D even
+  // DMA tile body: any phase subset, no actor history, whole tiles, K*D even; the alignment conditions of a phase's inputs
+  // and outputs apply only when that phase is asked for
   const int KD = p.K * p.D;
-  const size_t lds_dma = sizeof(float) * (size_t)env_dma_lds_floats(tile, KD, p.n_dof, per_env_limits);
-  bool dma = phases == (AMP_PHASE_DONES | AMP_PHASE_REWARD | AMP_PHASE_OBS) && p.n_actor == 1 && (KD & 1) == 0 && N >= tile &&
-             lds_dma <= 64 * 1024 && aligned(bf->amp_obs_buffer, 16) && aligned(st->joint_pos, 4) && aligned(st->joint_vel, 4);
-  if (dma && p.reward_mode == 1) dma = rows16(st->actions, st->actions_stride) && rows16(st->joint_acc, st->joint_acc_stride);
-  if (dma && p.use_last_actions) dma = aligned(st->last_actions, 16) && (!p.use_command || aligned(st->command, 16));
-  dma = dma && aligned(bf->policy_obs, 8);
-  if (dma && bf->disc_input) dma = aligned(bf->disc_input, 8) && (bf->disc_input_stride & 1) == 0;
+  const bool obs = phases & AMP_PHASE_OBS;
+  const size_t lds_dma = sizeof(float) * (size_t)env_dma_lds_floats(tile, KD, p.n_dof, per_env_limits, obs);
+  bool dma = p.n_actor == 1 && (KD & 1) == 0 && N >= tile && lds_dma <= 64 * 1024;
+  if (dma && g1_rew) dma = rows16(st->actions, st->actions_stride) && rows16(st->joint_acc, st->joint_acc_stride);
+  if (dma && obs) {
+    dma = aligned(bf->amp_obs_buffer, 16) && aligned(bf->policy_obs, 8);
+    if (dma && p.use_last_actions) dma = aligned(st->last_actions, 16) && (!p.use_command || aligned(st->command, 16));
+    if (dma && bf->disc_input) dma = aligned(bf->disc_input, 8) && (bf->disc_input_stride & 1) == 0;
+  }
   auto generic_tile = [&](unsigned g, unsigned block0) {
     if (tile == 32) env_step_kernel<32><<<g, kBlock, lds, (hipStream_t)stream>>>(p, *st, *bf, N, block0);
     else if (tile == 16) env_step_kernel<16><<<g, kBlock, lds, (hipStream_t)stream>>>(p, *st, *bf, N, block0);

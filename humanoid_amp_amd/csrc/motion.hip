@@ -10,6 +10,8 @@
 #include "amp_common.hpp"
 
 #include "motion_kernels.hpp"
+#include "compact_kernels.hpp"
+#include "command_kernels.hpp"
 
 namespace amp {
 
@@ -217,29 +219,142 @@ __global__ __launch_bounds__(kBlock) void reset_state_kernel(MotionView v, const
 // how many other envs reset in the same step.  Parity with the reference is distributional only (it uses numpy's
 // global MT19937); bit-exactness is defined against oracle/rng.py.
 // ------------------------------------------------------------------------------------------------
+// the (clip, time) draw of one reset env: key = seed, counter = (global env id, step)
+__device__ __forceinline__ void draw_clip_time(const ClipMeta& m, uint64_t seed, uint64_t step, int start, uint64_t ctr,
+                                               int64_t& clip, double& t) {
+  uint32_t r[4];
+  philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)seed,
+                (uint32_t)(seed >> 32), r);
+  clip = (int64_t)(((uint64_t)r[0] * (uint64_t)m.n_clips) >> 32);  // uniform in [0, n_clips)
+  // 53-bit uniform in [0, 1) from two words, numpy's random_sample construction
+  const double u = ((double)(r[1] >> 5) * 67108864.0 + (double)(r[2] >> 6)) / 9007199254740992.0;
+  t = start ? 0.0 : u * m.dur[clip];
+}
+
+// per-env clears of a reset env (DirectRLEnv._reset_idx: episode_length_buf[env_ids] = 0; g1_amp_env.py:352-358:
+// _just_reset_mask[env_ids] = True); the last_actions row is cleared by the caller's row loop or here (serial)
+struct ResetClears {
+  int64_t* episode_length;
+  float* last_actions;
+  uint8_t* just_reset;
+  int32_t n_actions;
+};
+
 __global__ __launch_bounds__(kBlock) void sample_times_kernel(ClipMeta m, uint64_t seed, uint64_t step, int start,
                                                               const int64_t* __restrict__ index, int64_t n,
                                                               const int64_t* __restrict__ n_dev,
                                                               int64_t* __restrict__ o_ids, double* __restrict__ o_t,
                                                               int64_t* __restrict__ env_ids_out,
-                                                              float* __restrict__ env_t_out, int64_t ctr_offset) {
+                                                              float* __restrict__ env_t_out, int64_t ctr_offset, ResetClears cl) {
   if (n_dev) n = *n_dev < n ? *n_dev : n;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const uint64_t idx = (uint64_t)(index ? index[i] : i);
-  const uint64_t ctr = idx + (uint64_t)ctr_offset;  // global env id of a shard's local env: the draw is shard-invariant
-  uint32_t r[4];
-  philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)seed,
-                (uint32_t)(seed >> 32), r);
-  const int64_t clip = (int64_t)(((uint64_t)r[0] * (uint64_t)m.n_clips) >> 32);  // uniform in [0, n_clips)
-  // 53-bit uniform in [0, 1) from two words, numpy's random_sample construction
-  const double u = ((double)(r[1] >> 5) * 67108864.0 + (double)(r[2] >> 6)) / 9007199254740992.0;
-  const double t = start ? 0.0 : u * m.dur[clip];
+  int64_t clip;
+  double t;
+  // counter = global env id of a shard's local env: the draw is shard-invariant
+  draw_clip_time(m, seed, step, start, idx + (uint64_t)ctr_offset, clip, t);
   o_ids[i] = clip;
   o_t[i] = t;
   // per-env mirrors (self.motion_ids[env_ids] = ..., self.motion_start_times[env_ids] = ..., g1_amp_env.py:377-382)
   if (env_ids_out) env_ids_out[idx] = clip;
   if (env_t_out) env_t_out[idx] = (float)t;
+  if (cl.episode_length) cl.episode_length[idx] = 0;
+  if (cl.just_reset) cl.just_reset[idx] = 1;
+  if (cl.last_actions)
+    for (int j = 0; j < cl.n_actions; ++j) cl.last_actions[idx * cl.n_actions + j] = 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The whole device-side reset as ONE launch (amp_reset_compact_apply): reset-id compaction + everything amp_reset_apply
+// does + the reset-side command resample + the per-env clears.  A workgroup owns 256 consecutive envs: compact_rank_body
+// gives every reset lane its slot in the ascending id list (and writes ids / count exactly as the stand-alone compaction
+// does); the lane then draws (clip, t), writes the root state of its slot and queues its env in an LDS list; the
+// workgroup's reset envs (0-3 of 256 in steady state) are then finished cooperatively: DoF rows, last_actions row, and
+// the K expert frames through collect_reference_body (times / clips / destination rows read from the LDS list).
+// Same device functions, same inputs per env as the separate launches: bit-identical results.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void reset_compact_apply_kernel(MotionView v, AmpCompactArgs c, AmpResetArgs a,
+                                                                     AmpCommandArgs cmd, int has_cmd, int64_t n_tiles, int sub,
+                                                                     int64_t n_counts) {
+  extern __shared__ __attribute__((aligned(16))) float s_img[];  // expert_lds(D): collect_reference_body's tile
+  __shared__ double s_t[kBlock];
+  __shared__ int64_t s_clip[kBlock], s_env[kBlock], s_slot[kBlock];
+  __shared__ SampleSlot s_fb[kBlock];
+  __shared__ int s_wcnt[kBlock / kWave];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int64_t env;
+  const int64_t slot = compact_rank_body((int64_t)blockIdx.x, c.mask, c.tile_counts, c.num_envs, n_tiles, sub, n_counts, c.ids,
+                                         c.count, env);
+  const unsigned long long b = __ballot(slot >= 0);
+  if (lane == 0) s_wcnt[wave] = __popcll(b);
+  __syncthreads();
+  int wbase = 0, cnt = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / kWave; ++w) {
+    wbase += w < wave ? s_wcnt[w] : 0;
+    cnt += s_wcnt[w];
+  }
+  if (cnt == 0) return;  // uniform: nothing to reset among this workgroup's envs
+  const int nd = v.n_dof;
+  const float* __restrict__ hot = v.hot;
+  if (slot >= 0) {
+    const int li = wbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+    int64_t clip;
+    double t;
+    draw_clip_time(v.clips, a.seed, a.step, a.start, (uint64_t)env + (uint64_t)a.env_offset, clip, t);
+    a.motion_ids[slot] = clip;
+    a.motion_times[slot] = t;
+    if (a.env_motion_ids) a.env_motion_ids[env] = clip;
+    if (a.env_motion_start_times) a.env_motion_start_times[env] = (float)t;
+    int64_t i0, i1;
+    double w;
+    frame_blend_ref(v.clips, t, clip, i0, i1, w);
+    const float bl = (float)w;
+    s_fb[li] = SampleSlot{(int32_t)i0, (int32_t)i1, bl};
+    s_t[li] = t;
+    s_clip[li] = clip;
+    s_env[li] = env;
+    s_slot[li] = slot;
+    if (a.root_state) {  // reset_state_kernel's root row (g1_amp_env.py:385-411)
+      const float* r0 = hot + i0 * v.HP + 2 * nd;
+      const float* r1 = hot + i1 * v.HP + 2 * nd;
+      float* o = a.root_state + slot * 13;
+      const float* og = a.env_origins ? a.env_origins + env * 3 : nullptr;
+      const float px = lerp_ref(r0[0], r1[0], bl), py = lerp_ref(r0[1], r1[1], bl), pz = lerp_ref(r0[2], r1[2], bl);
+      o[0] = og ? px + og[0] : px;
+      o[1] = og ? py + og[1] : py;
+      o[2] = (og ? pz + og[2] : pz) + a.z_lift;
+      const Quat q = slerp_ref(Quat{r0[3], r0[4], r0[5], r0[6]}, Quat{r1[3], r1[4], r1[5], r1[6]}, bl);
+      o[3] = q.w; o[4] = q.x; o[5] = q.y; o[6] = q.z;
+      for (int k = 7; k < 13; ++k) o[k] = lerp_ref(r0[k], r1[k], bl);
+    }
+    if (a.episode_length) a.episode_length[env] = 0;
+    if (a.just_reset) a.just_reset[env] = 1;
+    if (has_cmd) command_reset_env(cmd, env);
+  }
+  __syncthreads();
+  // DoF rows of the workgroup's reset envs: hot columns [0, nd) and [nd, 2 nd), already in robot order
+  for (int which = 0; which < 2; ++which) {
+    float* out = which ? a.dof_vel : a.dof_pos;
+    if (!out) continue;
+    const int off = which * nd;
+    for (int e = tid; e < cnt * nd; e += kBlock) {
+      const int li = e / nd, j = e - li * nd;
+      const SampleSlot sl = s_fb[li];
+      out[s_slot[li] * nd + j] = lerp_ref(hot[(int64_t)sl.i0 * v.HP + off + j], hot[(int64_t)sl.i1 * v.HP + off + j], sl.blend);
+    }
+  }
+  if (a.last_actions)
+    for (int e = tid; e < cnt * a.n_actions; e += kBlock) {
+      const int li = e / a.n_actions;
+      a.last_actions[s_env[li] * a.n_actions + (e - li * a.n_actions)] = 0.0f;
+    }
+  if (a.amp_obs_buffer)  // amp_observation_buffer[env] = K expert frames (g1_amp_env.py:414-419)
+    for (int chunk = 0; chunk * kExpertTile < cnt * a.K; ++chunk) {
+      collect_reference_body(v, s_t, s_clip, cnt, a.K, a.amp_obs_buffer, s_env, nullptr, chunk, s_img);
+      __syncthreads();
+    }
 }
 
 static inline unsigned grid_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
@@ -415,7 +530,7 @@ int amp_motion_sample_times(const AmpMotion* h, uint64_t seed, uint64_t step, in
   AMP_REQUIRE(motion_ids && times, "amp_motion_sample_times: null buffer");
   { amp::TraceScope trace__("sample_times_kernel", (hipStream_t)stream);
     sample_times_kernel<<<grid_for(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(h->v.clips, seed, step, start, index, n, n_dev,
-                                                                              motion_ids, times, nullptr, nullptr, 0);
+                                                                              motion_ids, times, nullptr, nullptr, 0, ResetClears{});
   }
   return launch_status("sample_times_kernel");
 }
@@ -426,12 +541,14 @@ int amp_reset_apply(const AmpMotion* h, const AmpResetArgs* a, amp_stream_t stre
   AMP_REQUIRE(a->max_n >= 0 && a->K >= 1, "amp_reset_apply: need max_n >= 0 and K >= 1");
   if (a->max_n == 0) return AMP_OK;
   AMP_REQUIRE(a->env_ids && a->count && a->motion_ids && a->motion_times, "amp_reset_apply: null buffer");
+  AMP_REQUIRE(!a->last_actions || a->n_actions >= 1, "amp_reset_apply: last_actions needs n_actions >= 1");
   hipStream_t st = (hipStream_t)stream;
   const int64_t n = a->max_n;
   { amp::TraceScope trace__("sample_times_kernel", st);
     sample_times_kernel<<<grid_for(n, kBlock), kBlock, 0, st>>>(h->v.clips, a->seed, a->step, a->start, a->env_ids, n, a->count,
                                                              a->motion_ids, a->motion_times, a->env_motion_ids,
-                                                             a->env_motion_start_times, a->env_offset);
+                                                             a->env_motion_start_times, a->env_offset,
+                                                             ResetClears{a->episode_length, a->last_actions, a->just_reset, a->n_actions});
   }
   int rc = launch_status("sample_times_kernel");
   if (rc != AMP_OK) return rc;
@@ -448,6 +565,39 @@ int amp_reset_apply(const AmpMotion* h, const AmpResetArgs* a, amp_stream_t stre
                                                                               a->amp_obs_buffer, a->env_ids, a->count);
   }
   return launch_status("collect_reference_kernel");
+}
+
+int amp_reset_compact_apply(const AmpMotion* h, const AmpCompactArgs* c, const AmpResetArgs* a, const AmpCommandArgs* cmd,
+                            amp_stream_t stream) {
+  AMP_REQUIRE(h && c && a, "amp_reset_compact_apply: null argument");
+  AMP_REQUIRE(h->has_layout, "amp_reset_compact_apply: call amp_motion_set_obs_layout first");
+  AMP_REQUIRE(c->num_envs >= 0 && a->K >= 1, "amp_reset_compact_apply: need num_envs >= 0 and K >= 1");
+  AMP_REQUIRE(c->count, "amp_reset_compact_apply: count pointer is null");
+  const int64_t N = c->num_envs;
+  hipStream_t st = (hipStream_t)stream;
+  if (N == 0) {
+    AMP_HIP(hipMemsetAsync(c->count, 0, sizeof(int64_t), st));
+    return AMP_OK;
+  }
+  AMP_REQUIRE(c->mask && c->tile_counts && c->ids, "amp_reset_compact_apply: null compaction buffer");
+  AMP_REQUIRE(c->tile_envs == 8 || c->tile_envs == 16 || c->tile_envs == 32 || c->tile_envs == 64,
+              "amp_reset_compact_apply: tile_envs must be 8, 16, 32 or 64");
+  AMP_REQUIRE(a->env_ids == c->ids && a->count == c->count && a->max_n >= N,
+              "amp_reset_compact_apply: the reset arguments must consume the compaction's ids / count (max_n >= num_envs)");
+  AMP_REQUIRE(a->motion_ids && a->motion_times, "amp_reset_compact_apply: null buffer");
+  AMP_REQUIRE(!a->last_actions || a->n_actions >= 1, "amp_reset_compact_apply: last_actions needs n_actions >= 1");
+  AMP_REQUIRE(!cmd || (cmd->command && cmd->time_left), "amp_reset_compact_apply: null command buffer");
+  AMP_REQUIRE(!cmd || !(cmd->vel_span > 0.0f) || cmd->t_span >= 0.0f, "amp_reset_compact_apply: negative resampling-time span");
+  const int sub = kTile / c->tile_envs;
+  const int64_t n_counts = (N + c->tile_envs - 1) / c->tile_envs;
+  const int64_t n_tiles = (N + kTile - 1) / kTile;
+  const unsigned grid = (unsigned)((n_tiles + 3) / 4);
+  const size_t lds = expert_lds(h->v.D);
+  AMP_REQUIRE(lds <= 48 * 1024, "amp_reset_compact_apply: expert tile needs %zu B of LDS", lds);
+  { amp::TraceScope trace__("reset_compact_apply_kernel", st);
+    reset_compact_apply_kernel<<<grid, kBlock, lds, st>>>(h->v, *c, *a, cmd ? *cmd : AmpCommandArgs{}, cmd ? 1 : 0, n_tiles, sub, n_counts);
+  }
+  return launch_status("reset_compact_apply_kernel");
 }
 
 int amp_reset_reference_state(const AmpMotion* h, const double* times, const int64_t* ids, const int64_t* env_ids, int64_t n,

@@ -166,6 +166,13 @@ class EnvStepKernel:
                                                                 loader._handle, nat.dptr(times), nat.dptr(ids), n, K, nat.dptr(out),
                                                                 nat.stream_ptr()), "amp_env_step_with_reference")
 
+    def bind(self, phases: int, **views) -> "BoundEnvStep":
+        """``launch(phases, **views)`` with everything marshalled ONCE: the returned object's ``__call__`` is a single
+        ``amp_env_step`` across the C ABI on prebuilt structs (what the env hooks use step after step; valid for as long as
+        the view tensors keep their addresses -- the env re-binds when a pointer changes -- and until the next
+        ``attach_discriminator``)."""
+        return BoundEnvStep(self, int(phases), self.sim_state(**views), self._buffers(), views)
+
     def check_reference(self, times, ids, out):
         """Argument checks of the fused expert-motion sample; returns (n_samples, K)."""
         cfg = self.cfg
@@ -245,6 +252,27 @@ class EnvStepKernel:
         return self.reset_ids, self.reset_count
 
 
+class BoundEnvStep:
+    """One ``amp_env_step`` launch on prebuilt arguments (:meth:`EnvStepKernel.bind`)."""
+
+    __slots__ = ("_fn", "_args", "_keep", "_dev", "_index", "phases")
+
+    def __init__(self, kernel: EnvStepKernel, phases: int, state, bufs, keep):
+        self._fn = kernel._lib.amp_env_step
+        self._args = (C.byref(kernel._c), C.byref(state), C.byref(bufs), kernel.num_envs, phases)
+        self._keep = (kernel, state, bufs, keep)  # the structs are referenced by pointer; the tensors by address
+        self._dev, self._index, self.phases = kernel.device, kernel.device.index or 0, phases
+
+    def __call__(self) -> None:
+        if torch.cuda.current_device() == self._index:
+            rc = self._fn(*self._args, torch.cuda.current_stream().cuda_stream)
+        else:
+            with torch.cuda.device(self._dev):
+                rc = self._fn(*self._args, torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            nat.check(rc, "amp_env_step")
+
+
 def reset_compact(mask: torch.Tensor):
     """Stand-alone ``mask.nonzero().squeeze(-1)``: returns (ids [N] int64 buffer, count [1] int64) on the device."""
     lib = nat.load()
@@ -259,6 +287,41 @@ def reset_compact(mask: torch.Tensor):
         nat.check(lib.amp_reset_compact(nat.dptr(mask), n, nat.dptr(ids), nat.dptr(count), nat.dptr(ws), nat.stream_ptr()),
                   "amp_reset_compact")
     return ids, count
+
+
+class RowScatter:
+    """``amp_scatter_rows`` on prebuilt arguments: ``dst[ids[i]] = src[i]`` for ``i < count`` with ids and count on the
+    device -- the ``tensor[env_ids] = rows`` of the reset path without a count read-back.  ``ops`` is a list of dicts
+    ``dict(dst=[N, ...] float32, src=[max_n, width] float32 or None, fill=0.0, repeat=1, add=[repeat, width] or None)``;
+    a ``dst`` row is ``repeat`` back-to-back copies of the ``width`` source floats (``+ add``)."""
+
+    def __init__(self, ops, ids: torch.Tensor, count: torch.Tensor):
+        self._lib = nat.load()
+        dev = nat.require_gpu(ids.device)
+        arr = (nat.AmpScatterRows * len(ops))()
+        for a, o in zip(arr, ops):
+            dst, src, add, repeat = o["dst"], o.get("src"), o.get("add"), int(o.get("repeat", 1))
+            if dst.dtype != torch.float32 or dst.stride(-1) != 1 or (dst.dim() > 1 and not dst[0].is_contiguous()):
+                raise nat.AmpEngineError("RowScatter: dst must be float32 with contiguous rows")
+            per = int(dst[0].numel())
+            if per % repeat:
+                raise nat.AmpEngineError("RowScatter: dst row length is not a multiple of repeat")
+            a.dst, a.dst_stride, a.width, a.repeat = dst.data_ptr(), int(dst.stride(0)), per // repeat, repeat
+            if src is not None:
+                if src.dtype != torch.float32 or src.dim() != 2 or src.shape[1] != a.width or src.stride(1) != 1:
+                    raise nat.AmpEngineError(f"RowScatter: src must be float32 [max_n, {a.width}]")
+                a.src, a.src_stride = src.data_ptr(), int(src.stride(0))
+            a.fill = float(o.get("fill", 0.0))
+            if add is not None:
+                if add.dtype != torch.float32 or not add.is_contiguous() or add.numel() != per:
+                    raise nat.AmpEngineError("RowScatter: add must be a contiguous float32 [repeat, width] tensor")
+                a.add = add.data_ptr()
+        self._args = (arr, len(ops), nat.dptr(ids, torch.int64, "ids"), nat.dptr(count, torch.int64, "count"), int(ids.numel()))
+        self._keep, self._dev = (ops, ids, count), dev
+
+    def __call__(self) -> None:
+        with torch.cuda.device(self._dev):
+            nat.check(self._lib.amp_scatter_rows(*self._args, nat.stream_ptr()), "amp_scatter_rows")
 
 
 def command_step(command: torch.Tensor, time_left: torch.Tensor, *, mode: int, step_dt: float, vel_range, time_range,

@@ -5,8 +5,9 @@ humanoid_amp_env.py:22-248): ``step`` / ``reset``, ``extras["amp_obs"]`` (a VIEW
 ``amp_observation_space`` / ``amp_observation_size``, ``collect_reference_motions(num_samples, current_times,
 motion_ids)``.  Each hook is one engine call:
 
-    _get_dones        -> amp_env_step(DONES)     (+ per-tile reset counts for the compaction)
-    _get_rewards      -> amp_env_step(REWARD)
+    _get_dones        -> amp_env_step(DONES | REWARD)  (+ per-tile reset counts for the compaction): DirectRLEnv.step calls
+    _get_rewards         _get_rewards right after _get_dones on the same state, so ONE launch serves both hooks
+                         (_get_rewards on its own still launches REWARD)
     reset ids         -> amp_reset_compact_tiles (replaces reset_buf.nonzero())
     _reset_idx        -> amp_reset_reference_state + amp_collect_reference(scatter into the AMP buffer)
     _get_observations -> amp_env_step(OBS)
@@ -18,6 +19,7 @@ humanoid env was not updated for this fork's tuple-returning ``sample_times`` an
 
 from __future__ import annotations
 
+import ctypes as C
 from types import SimpleNamespace
 
 import numpy as np
@@ -45,17 +47,32 @@ class _AmpEnv(DirectRLEnv):
     IS_G1 = True
 
     def __init__(self, cfg, render_mode: str | None = None, robot=None, log_rewards: bool = True,
-                 device_reset: bool = False, reset_seed: int = 0, env_offset: int = 0, **kwargs):
+                 device_reset: bool = False, reset_seed: int | None = None, env_offset: int | None = None, **kwargs):
         """``device_reset=True`` keeps the whole reset on the device (ids + count from the compaction kernel feed
         ``amp_reset_apply``; clip / time come from the engine's counter-based RNG keyed by ``reset_seed``): no host
         sync and no numpy RNG inside ``step()`` (``tests/test_gpu_reset_device.py`` steps under
         ``torch.cuda.set_sync_debug_mode("error")``).  Needs a state provider with ``write_reset_compact`` (the
         synthetic articulation has one); the reference's exact host-RNG sequence is then not reproduced (distribution
-        is).  ``env_offset``: global id of this shard's env 0 -- every counter-based draw is keyed by the GLOBAL env id,
-        so a sharded run draws what the unsharded run draws."""
+        is).
+
+        ``reset_seed``: key of every counter-based draw (velocity commands, device-side reset clip / time).  ``None``
+        follows the run's seed the way the reference's ``torch.rand`` does: ``cfg.seed`` if the config has one, else
+        ``torch.initial_seed()`` (what ``torch.manual_seed`` set); ``env.reset(seed=...)`` re-keys it.
+        ``env_offset``: global id of this shard's env 0 -- every draw is keyed by the GLOBAL env id, so a sharded run
+        draws what the unsharded run draws and two ranks never draw the same stream.  ``None``: this rank's block of
+        ``distributed.shard_bounds`` when ``torch.distributed`` is initialised (every rank holding ``num_envs`` envs),
+        else 0."""
         self._log_rewards = bool(log_rewards)
-        self.device_reset, self._reset_seed, self._reset_out = bool(device_reset), int(reset_seed), None
+        self.device_reset, self._reset_out = bool(device_reset), None
+        if reset_seed is None:
+            reset_seed = getattr(cfg, "seed", None)
+        self._reset_seed = int(torch.initial_seed() if reset_seed is None else reset_seed)
+        if env_offset is None:
+            import torch.distributed as dist
+
+            env_offset = dist.get_rank() * int(cfg.scene.num_envs) if dist.is_available() and dist.is_initialized() else 0
         self.env_offset = int(env_offset)
+        self._bound, self._reward_fresh, self._reset_args, self._tick_args = {}, False, None, None
         super().__init__(cfg, render_mode, robot=robot, **kwargs)
         nat.require_gpu(self.device)
         data = self.robot.data
@@ -127,26 +144,50 @@ class _AmpEnv(DirectRLEnv):
                     root_lin_vel=d.body_lin_vel_w[:, r], root_ang_vel=d.body_ang_vel_w[:, r])
 
     # ---- DirectRLEnv hooks ----------------------------------------------------------------------------------
+    def _launch(self, phases: int) -> None:
+        """``amp_env_step(phases)`` on this step's simulator views.  The argument structs are built once per phase set
+        and reused for as long as every tensor keeps its address (``self.actions`` / ``last_actions`` are persistent
+        buffers for that reason): a hook then costs one call across the C ABI, no marshalling."""
+        d = self.robot.data
+        key = (d.joint_pos.data_ptr(), d.joint_vel.data_ptr(), d.joint_acc.data_ptr(), d.body_pos_w.data_ptr(),
+               d.body_quat_w.data_ptr(), d.body_lin_vel_w.data_ptr(), d.body_ang_vel_w.data_ptr(),
+               d.soft_joint_pos_limits.data_ptr(), self.actions.data_ptr(), self.last_actions.data_ptr(),
+               self.command_target_speed.data_ptr(), self.episode_length_buf.data_ptr(), id(self._kernel._disc_layout))
+        hit = self._bound.get(phases)
+        if hit is None or hit[0] != key:
+            views = dict(episode_length=self.episode_length_buf, **self._sim_views())
+            if phases & nat.AMP_PHASE_REWARD and self.IS_G1:
+                views.update(joint_acc=d.joint_acc, actions=self.actions, soft_limits=d.soft_joint_pos_limits,
+                             command=self.command_target_speed)
+            if phases & nat.AMP_PHASE_OBS:
+                views.update(body_pos=d.body_pos_w, key_body_indexes=self.key_body_indexes)
+                if self.IS_G1:
+                    views.update(command=self.command_target_speed, last_actions=self.last_actions)
+            hit = self._bound[phases] = (key, self._kernel.bind(phases, **views))
+        hit[1]()
+
     def _pre_physics_step(self, actions: torch.Tensor):
-        self.actions = actions.clone()
+        self.actions.copy_(actions)  # the reference's `self.actions = actions.clone()` into a persistent buffer
 
     def _apply_action(self):
         self.robot.set_joint_position_target(self.action_offset + self.action_scale * self.actions)
 
     def _get_dones(self):
-        self._kernel.launch(nat.AMP_PHASE_DONES, root_pos=self.robot.data.body_pos_w[:, self.ref_body_index],
-                            episode_length=self.episode_length_buf)
+        # dones AND task reward: DirectRLEnv.step calls _get_rewards next, on the same state (g1_amp_env.py:246-330)
+        self._launch(nat.AMP_PHASE_DONES | nat.AMP_PHASE_REWARD)
+        self._reward_fresh = True
         return self._kernel.died, self._kernel.time_out
+
+    def _reset_buf(self):
+        return self._kernel.reset_mask  # died | time_out, written by the DONES phase
 
     def _compact_reset_ids(self) -> torch.Tensor:
         ids, count = self._kernel.compact_resets()
         return ids[: int(count)]  # one scalar read-back, like len(nonzero()) in the reference
 
     def _get_observations(self) -> dict:
-        d = self.robot.data
-        self._kernel.launch(nat.AMP_PHASE_OBS, body_pos=d.body_pos_w, key_body_indexes=self.key_body_indexes,
-                            command=self.command_target_speed if self.IS_G1 else None,
-                            last_actions=self.last_actions if self.IS_G1 else None, **self._sim_views())
+        self._reward_fresh = False
+        self._launch(nat.AMP_PHASE_OBS)
         self.extras = {**{k: v for k, v in self.extras.items() if k == "log"},
                        "amp_obs": self.amp_observation_buffer.view(-1, self.amp_observation_size)}
         return {"policy": self._kernel.policy_obs}
@@ -172,23 +213,47 @@ class _AmpEnv(DirectRLEnv):
         pass
 
     def _reset_on_device(self):
+        """Everything ``DirectRLEnv.step`` does between ``_get_rewards`` and ``_get_observations`` as ONE engine launch
+        (``amp_reset_compact_apply``: reset-id compaction, clip / time draw, reference root / DoF state, K expert frames
+        into ``amp_observation_buffer``, episode-length / last-action / just-reset clears, command resample) + the state
+        provider's ``write_reset_compact``.  Ids and count never leave the device."""
         if not self.cfg.reset_strategy.startswith("random"):
             raise ValueError("device_reset supports the random / random-start strategies")
-        ids, count = self._kernel.compact_resets()
-        self._reset_out = self._motion_loader.reset_apply(
-            ids, count, self.cfg.num_amp_observations, seed=self._reset_seed, step=self.common_step_counter,
-            start="start" in self.cfg.reset_strategy, env_origins=self.scene.env_origins, z_lift=self.Z_LIFT,
-            amp_observation_buffer=self.amp_observation_buffer, out=self._reset_out,
-            env_motion_ids=self.motion_ids, env_motion_start_times=self.motion_start_times, env_offset=self.env_offset)
-        o, mask = self._reset_out, self._kernel.reset_mask
-        if hasattr(self.robot, "reset_masked"):
-            self.robot.reset_masked(mask)
-        self.robot.write_reset_compact(ids, count, o["root_state"], o["dof_pos"], o["dof_vel"])
-        self.episode_length_buf.masked_fill_(mask, 0)
-        self._after_reset_masked(mask)
-
-    def _after_reset_masked(self, mask):
-        pass
+        k = self._kernel
+        key = (self.episode_length_buf.data_ptr(), self.last_actions.data_ptr(), self.command_target_speed.data_ptr(),
+               self.command_time_left.data_ptr(), self.amp_observation_buffer.data_ptr())
+        if self._reset_args is None or self._reset_args[0] != key:
+            N, nd = self.num_envs, len(self.robot.data.joint_names)
+            f32 = dict(dtype=torch.float32, device=self.device)
+            o = self._reset_out = dict(root_state=torch.zeros((N, 13), **f32), dof_pos=torch.zeros((N, nd), **f32),
+                                       dof_vel=torch.zeros((N, nd), **f32),
+                                       motion_ids=torch.zeros(N, dtype=torch.int64, device=self.device),
+                                       motion_times=torch.zeros(N, dtype=torch.float64, device=self.device))
+            c, a = k.compact_args(), nat.AmpResetArgs()
+            a.env_ids, a.count, a.max_n = c.ids, c.count, N
+            a.start, a.K = int("start" in self.cfg.reset_strategy), int(self.cfg.num_amp_observations)
+            a.env_origins, a.z_lift = self.scene.env_origins.data_ptr(), float(self.Z_LIFT)
+            a.root_state, a.dof_pos, a.dof_vel = (o[n].data_ptr() for n in ("root_state", "dof_pos", "dof_vel"))
+            a.amp_obs_buffer = self.amp_observation_buffer.data_ptr()
+            a.motion_ids, a.motion_times = o["motion_ids"].data_ptr(), o["motion_times"].data_ptr()
+            a.env_motion_ids, a.env_motion_start_times = self.motion_ids.data_ptr(), self.motion_start_times.data_ptr()
+            a.env_offset = self.env_offset
+            a.episode_length = self.episode_length_buf.data_ptr()
+            if self.IS_G1:
+                a.last_actions, a.n_actions = self.last_actions.data_ptr(), int(self.last_actions.shape[1])
+                if getattr(self.cfg, "num_actor_observations", 1) > 1:
+                    a.just_reset = self._just_reset_mask.data_ptr()
+            cmd = self._command_args() if self.IS_G1 else None
+            self._reset_args = (key, c, a, cmd, nat.load().amp_reset_compact_apply, self._motion_loader._need_handle())
+        _, c, a, cmd, fn, handle = self._reset_args
+        a.seed, a.step = self._reset_seed & (2**64 - 1), self.common_step_counter & (2**64 - 1)
+        if cmd is not None:
+            cmd.seed, cmd.step = a.seed, a.step
+        with torch.cuda.device(self.device):
+            nat.check(fn(handle, C.byref(c), C.byref(a), C.byref(cmd) if cmd is not None else None, nat.stream_ptr()),
+                      "amp_reset_compact_apply")
+        o = self._reset_out
+        self.robot.write_reset_compact(k.reset_ids, k.reset_count, o["root_state"], o["dof_pos"], o["dof_vel"])
 
     def _reset_strategy_default(self, env_ids):
         d = self.robot.data
@@ -232,19 +297,36 @@ class G1AmpEnv(_AmpEnv):
         return SyntheticArticulation(self.num_envs, G1_JOINT_NAMES, G1_BODY_NAMES, self.device, root_body="pelvis",
                                      dt=self.physics_dt)
 
+    def _command_args(self) -> nat.AmpCommandArgs:
+        """Prebuilt ``AmpCommandArgs`` of the reset-side resample (seed / step are filled in per step)."""
+        a = nat.AmpCommandArgs()
+        a.command, a.time_left = self.command_target_speed.data_ptr(), self.command_time_left.data_ptr()
+        lo, hi = (float(x) for x in self.cfg.track_vel_range)
+        t_lo, t_hi = (float(x) for x in self.cfg.command_resampling_time_range)
+        a.step_dt, a.vel_lo, a.vel_span, a.t_lo, a.t_span = float(self.step_dt), lo, hi - lo, t_lo, t_hi - t_lo
+        a.env_offset = self.env_offset
+        return a
+
     def _command_step(self, mode: int, **which):
         command_step(self.command_target_speed, self.command_time_left, mode=mode, step_dt=self.step_dt,
                      vel_range=self.cfg.track_vel_range, time_range=self.cfg.command_resampling_time_range,
                      seed=self._reset_seed, step=self.common_step_counter, env_offset=self.env_offset, **which)
 
     def _pre_physics_step(self, actions: torch.Tensor):
-        self.actions = actions.clone()
-        # timers + resample of the expired envs (g1_amp_env.py:146-167): one launch, no nonzero() sync
-        self._command_step(nat.AMP_COMMAND_TICK)
+        self.actions.copy_(actions)
+        # timers + resample of the expired envs (g1_amp_env.py:146-167): one launch, no nonzero() sync; prebuilt arguments
+        t = self._tick_args
+        if t is None or t[0] != (self.command_target_speed.data_ptr(), self.command_time_left.data_ptr()):
+            t = self._tick_args = ((self.command_target_speed.data_ptr(), self.command_time_left.data_ptr()), self._command_args(),
+                                   nat.load().amp_command_step)
+        a = t[1]
+        a.seed, a.step = self._reset_seed & (2**64 - 1), self.common_step_counter & (2**64 - 1)
+        with torch.cuda.device(self.device):
+            nat.check(t[2](C.byref(a), self.num_envs, nat.AMP_COMMAND_TICK, nat.stream_ptr()), "amp_command_step")
 
     def _apply_action(self):
         super()._apply_action()
-        self.last_actions = self.actions.clone()
+        self.last_actions.copy_(self.actions)  # `self.last_actions = self.actions.clone()` (g1_amp_env.py:173)
 
     def _resample_commands(self, env_ids, on_reset: bool):
         # reset-side resample (g1_amp_env.py:421-439) for an explicit id list (the host-driven reset path)
@@ -252,9 +334,9 @@ class G1AmpEnv(_AmpEnv):
             self._command_step(nat.AMP_COMMAND_RESET, env_ids=env_ids.to(torch.int64).contiguous())
 
     def _get_rewards(self) -> torch.Tensor:
-        d = self.robot.data
-        self._kernel.launch(nat.AMP_PHASE_REWARD, joint_acc=d.joint_acc, actions=self.actions,
-                            soft_limits=d.soft_joint_pos_limits, command=self.command_target_speed, **self._sim_views())
+        if not self._reward_fresh:  # called on its own: the REWARD phase alone (reads the done bits of the last DONES launch)
+            self._launch(nat.AMP_PHASE_REWARD)
+        self._reward_fresh = False
         if self._log_rewards:
             # the reference's 6-8 .mean().item() syncs (:291-305) become one reduction launch; the read-back happens
             # only when somebody looks at extras["log"] (LazyRewardLog), so step() itself never waits for the device
@@ -275,12 +357,6 @@ class G1AmpEnv(_AmpEnv):
         if getattr(self.cfg, "num_actor_observations", 1) > 1:
             self._just_reset_mask[env_ids] = True
 
-    def _after_reset_masked(self, mask):
-        self.last_actions.masked_fill_(mask[:, None], 0.0)
-        if getattr(self.cfg, "num_actor_observations", 1) > 1:
-            self._just_reset_mask |= mask
-        self._command_step(nat.AMP_COMMAND_RESET, reset_mask=mask)
-
 
 class HumanoidAmpEnv(_AmpEnv):
     KEY_BODY_NAMES = HUMANOID_KEY_BODY_NAMES
@@ -295,5 +371,7 @@ class HumanoidAmpEnv(_AmpEnv):
                                      root_body="torso", dt=self.physics_dt, init_height=1.0)
 
     def _get_rewards(self) -> torch.Tensor:
-        self._kernel.launch(nat.AMP_PHASE_REWARD)
+        if not self._reward_fresh:
+            self._launch(nat.AMP_PHASE_REWARD)
+        self._reward_fresh = False
         return self._kernel.reward

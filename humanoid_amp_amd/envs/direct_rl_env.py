@@ -61,6 +61,10 @@ class DirectRLEnv:
     def _reset_on_device(self):
         raise NotImplementedError
 
+    def _reset_buf(self) -> torch.Tensor:
+        """``reset_terminated | reset_time_outs``; tasks on the engine return the mask their DONES launch wrote."""
+        return self.reset_terminated | self.reset_time_outs
+
     def _compact_reset_ids(self) -> torch.Tensor:
         """Ascending int64 ids of ``reset_buf``; tasks on the engine override this with the fused tile counts."""
         from ..engine import reset_compact
@@ -75,6 +79,8 @@ class DirectRLEnv:
 
             np.random.seed(seed)
             torch.manual_seed(seed)
+            if hasattr(self, "_reset_seed"):  # the engine's counter-based draws follow the run seed as torch.rand does
+                self._reset_seed = int(seed)
         self._reset_idx(None)
         return self._get_observations(), self.extras
 
@@ -87,7 +93,7 @@ class DirectRLEnv:
         self.episode_length_buf += 1
         self.common_step_counter += 1
         self.reset_terminated, self.reset_time_outs = self._get_dones()
-        self.reset_buf = self.reset_terminated | self.reset_time_outs
+        self.reset_buf = self._reset_buf()
         self.reward_buf = self._get_rewards()
         if getattr(self, "device_reset", False):
             self._reset_on_device()   # engine path: no count read-back, no host RNG

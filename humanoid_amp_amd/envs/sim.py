@@ -41,6 +41,7 @@ class SyntheticArticulation:
         self.data = d
         self._ALL_INDICES = torch.arange(N, dtype=torch.long, device=self.device)
         self._target = torch.zeros((N, nd), **f32)
+        self._scatter = None
         # fixed body offsets around the root so key bodies move with it
         self._offsets = torch.randn((nb, 3), generator=self._gen, **f32) * 0.3
         self._offsets[self._root] = 0.0
@@ -50,10 +51,6 @@ class SyntheticArticulation:
     def reset(self, env_ids=None):
         ids = self._ALL_INDICES if env_ids is None else env_ids
         self.data.joint_acc[ids] = 0.0
-
-    def reset_masked(self, mask: torch.Tensor):
-        """``reset(env_ids)`` for a device-side bool mask (no id list, no sync)."""
-        self.data.joint_acc.masked_fill_(mask[:, None], 0.0)
 
     def set_joint_position_target(self, target: torch.Tensor):
         self._target = target
@@ -74,25 +71,21 @@ class SyntheticArticulation:
 
     def write_reset_compact(self, env_ids: torch.Tensor, count: torch.Tensor, root_state: torch.Tensor, joint_pos: torch.Tensor,
                             joint_vel: torch.Tensor):
-        """Device-only counterpart of the three write_*_to_sim calls: rows i < count of the compact arrays go to env
-        ``env_ids[i]``; nothing is read back to the host (rows >= count are routed to a scratch row)."""
-        d, N = self.data, self.num_envs
-        valid = torch.arange(env_ids.numel(), device=self.device) < count
-        tgt = torch.where(valid, env_ids, torch.full_like(env_ids, N))  # N = scratch row
-        def scatter(dst, src):
-            pad = torch.cat([dst, dst[:1]], dim=0)
-            pad.index_copy_(0, tgt, src)
-            dst.copy_(pad[:N])
-        nb = d.body_pos_w.shape[1]
-        scatter(d.joint_pos, joint_pos)
-        scatter(d.joint_vel, joint_vel)
-        scatter(d.body_pos_w, root_state[:, None, 0:3] + self._offsets[None])
-        scatter(d.body_quat_w, root_state[:, None, 3:7].expand(-1, nb, -1))
-        scatter(d.body_lin_vel_w, root_state[:, None, 7:10].expand(-1, nb, -1))
-        scatter(d.body_ang_vel_w, root_state[:, None, 10:13].expand(-1, nb, -1))
-        mask = torch.zeros(N + 1, dtype=torch.bool, device=self.device)
-        mask.index_fill_(0, tgt, True)  # (mask[tgt] = True stages its scalar through a blocking H2D copy)
-        d.joint_acc.masked_fill_(mask[:N, None], 0.0)
+        """Device-only counterpart of the three write_*_to_sim calls (+ ``reset``'s joint_acc clear): rows i < count of
+        the compact arrays go to env ``env_ids[i]``.  One ``amp_scatter_rows`` launch over the seven state arrays, bounded
+        by the device-side count: nothing is read back and rows >= count are never touched."""
+        key = (env_ids.data_ptr(), count.data_ptr(), root_state.data_ptr(), joint_pos.data_ptr(), joint_vel.data_ptr())
+        if self._scatter is None or self._scatter[0] != key:
+            from ..engine import RowScatter
+
+            d, nb = self.data, self.data.body_pos_w.shape[1]
+            ops = [dict(dst=d.joint_pos, src=joint_pos), dict(dst=d.joint_vel, src=joint_vel), dict(dst=d.joint_acc, fill=0.0),
+                   dict(dst=d.body_pos_w, src=root_state[:, 0:3], repeat=nb, add=self._offsets),
+                   dict(dst=d.body_quat_w, src=root_state[:, 3:7], repeat=nb),
+                   dict(dst=d.body_lin_vel_w, src=root_state[:, 7:10], repeat=nb),
+                   dict(dst=d.body_ang_vel_w, src=root_state[:, 10:13], repeat=nb)]
+            self._scatter = (key, RowScatter(ops, env_ids, count))
+        self._scatter[1]()
 
     # ---- toy physics ------------------------------------------------------------------------------------
     def step(self):

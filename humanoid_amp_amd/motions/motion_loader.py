@@ -345,6 +345,52 @@ class MotionLoader:
             nat.check(self._lib.amp_reset_apply(h, C.byref(a), nat.stream_ptr()), "amp_reset_apply")
         return out
 
+    def reset_compact_apply(self, reset_mask: torch.Tensor, tile_counts: torch.Tensor, tile_envs: int, env_ids: torch.Tensor,
+                            count: torch.Tensor, num_amp_observations: int, *, seed: int, step: int, start: bool,
+                            env_origins: torch.Tensor | None, z_lift: float, amp_observation_buffer: torch.Tensor | None,
+                            out: dict | None = None, env_motion_ids: torch.Tensor | None = None,
+                            env_motion_start_times: torch.Tensor | None = None, env_offset: int = 0,
+                            episode_length: torch.Tensor | None = None, last_actions: torch.Tensor | None = None,
+                            just_reset: torch.Tensor | None = None, command: "nat.AmpCommandArgs | None" = None) -> dict:
+        """Reset-id compaction (``reset_mask`` + the per-tile counts of the DONES launch -> ``env_ids`` / ``count``, both
+        written here) and :meth:`reset_apply` on them as ONE launch (``amp_reset_compact_apply``), plus the optional
+        per-env clears (``episode_length[env] = 0``, ``last_actions[env] = 0``, ``just_reset[env] = True``) and the
+        reset-side command resample (``command``: a filled ``AmpCommandArgs``).  Bit-identical to the separate calls."""
+        h = self._need_handle()
+        if self._layout is None:
+            raise nat.AmpEngineError("call set_obs_layout first")
+        n = int(reset_mask.numel())
+        if env_ids.numel() < n:
+            raise nat.AmpEngineError("env_ids must have room for every env")
+        if out is None:
+            f32 = dict(dtype=torch.float32, device=self._tdev)
+            out = dict(root_state=torch.zeros((n, 13), **f32), dof_pos=torch.zeros((n, self.num_dofs), **f32),
+                       dof_vel=torch.zeros((n, self.num_dofs), **f32), motion_ids=torch.zeros(n, dtype=torch.int64, device=self._tdev),
+                       motion_times=torch.zeros(n, dtype=torch.float64, device=self._tdev))
+        c = nat.AmpCompactArgs()
+        c.mask, c.tile_counts = nat.dptr(reset_mask, None, "reset_mask").value, nat.dptr(tile_counts, torch.int32, "tile_counts").value
+        c.tile_envs, c.num_envs = int(tile_envs), n
+        c.ids, c.count = nat.dptr(env_ids, torch.int64, "env_ids").value, nat.dptr(count, torch.int64, "count").value
+        a = nat.AmpResetArgs()
+        a.env_ids, a.count, a.max_n = c.ids, c.count, int(env_ids.numel())
+        a.seed, a.step, a.start, a.K = int(seed) & (2**64 - 1), int(step) & (2**64 - 1), int(bool(start)), int(num_amp_observations)
+        a.env_origins = nat.dptr(env_origins, torch.float32, "env_origins").value
+        a.z_lift = float(z_lift)
+        a.root_state, a.dof_pos, a.dof_vel = (out[k].data_ptr() for k in ("root_state", "dof_pos", "dof_vel"))
+        a.amp_obs_buffer = nat.dptr(amp_observation_buffer, torch.float32, "amp_observation_buffer").value
+        a.motion_ids, a.motion_times = out["motion_ids"].data_ptr(), out["motion_times"].data_ptr()
+        a.env_motion_ids = nat.dptr(env_motion_ids, torch.int64, "env_motion_ids").value
+        a.env_motion_start_times = nat.dptr(env_motion_start_times, torch.float32, "env_motion_start_times").value
+        a.env_offset = int(env_offset)
+        a.episode_length = nat.dptr(episode_length, torch.int64, "episode_length").value
+        if last_actions is not None:
+            a.last_actions, a.n_actions = nat.dptr(last_actions, torch.float32, "last_actions").value, int(last_actions.shape[1])
+        a.just_reset = nat.dptr(just_reset, None, "just_reset").value
+        with torch.cuda.device(self._tdev):
+            nat.check(self._lib.amp_reset_compact_apply(h, C.byref(c), C.byref(a), C.byref(command) if command is not None else None,
+                                                        nat.stream_ptr()), "amp_reset_compact_apply")
+        return out
+
     def reset_reference_state(self, times, motion_ids, env_ids=None, env_origins: torch.Tensor | None = None,
                               z_lift: float = 0.0):
         """(root_state [n,13], dof_pos [n,Dof], dof_vel [n,Dof]) of the reference body for reset envs

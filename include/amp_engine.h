@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define AMP_ABI_VERSION 7
+#define AMP_ABI_VERSION 8
 
 typedef void* amp_stream_t; /* hipStream_t */
 typedef void* amp_event_t;  /* hipEvent_t  */
@@ -157,6 +157,13 @@ typedef struct {
   int64_t* env_motion_ids;      /* dev [num_envs] or NULL */
   float* env_motion_start_times; /* dev [num_envs] fp32 or NULL */
   int64_t env_offset;           /* global id of env 0 of this shard: draws are keyed by env_offset + env_ids[i] */
+  /* optional per-env clears of the reset envs (DirectRLEnv._reset_idx: episode_length_buf[env_ids] = 0;
+   * g1_amp_env.py:352-358: last_actions[env_ids] = 0, _just_reset_mask[env_ids] = True) */
+  int64_t* episode_length;      /* dev [num_envs] or NULL */
+  float* last_actions;          /* dev [num_envs, n_actions] or NULL */
+  uint8_t* just_reset;          /* dev [num_envs] or NULL */
+  int32_t n_actions;
+  int32_t reserved2;
 } AmpResetArgs;
 int amp_reset_apply(const AmpMotion* h, const AmpResetArgs* args, amp_stream_t stream);
 
@@ -303,6 +310,44 @@ int amp_reset_compact(const uint8_t* mask_dev, int64_t num_envs, int64_t* ids_de
 int amp_reset_compact_tiles(const uint8_t* mask_dev, const int32_t* tile_counts_dev, int32_t tile_envs, int64_t num_envs,
                             int64_t* ids_dev, int64_t* count_dev, amp_stream_t stream);
 
+/* Arguments of the compaction when it rides on another launch (amp_reset_compact_apply, the fused step tail). */
+typedef struct {
+  const uint8_t* mask;         /* dev [num_envs] reset mask (AmpEnvBuffers.reset_mask) */
+  const int32_t* tile_counts;  /* dev: AmpEnvBuffers.reset_tile_counts of the same step */
+  int32_t tile_envs;           /* amp_env_step_tile_envs(cfg, num_envs) */
+  int32_t reserved;
+  int64_t num_envs;
+  int64_t* ids;                /* dev [num_envs] out, ascending */
+  int64_t* count;              /* dev [1] out */
+} AmpCompactArgs;
+
+/* Device-count-bounded row scatter: the `tensor[env_ids] = rows` of the reset path (the write_*_to_sim calls and the
+ * per-env clears of G1AmpEnv._reset_idx, g1_amp_env.py:348-358) for a state provider that holds plain device arrays, when
+ * the number of ids lives on the device (amp_reset_compact*'s count): no read-back.  For every op, i < min(max_n, *count),
+ * r < repeat, c < width:   dst[ids[i] * dst_stride + r * width + c] = (src ? src[i * src_stride + c] : fill) + (add ? add[r * width + c] : 0).
+ * Up to 8 ops share one launch. */
+typedef struct {
+  const float* src;      /* dev [max_n, src_stride] compact rows, or NULL: write `fill` */
+  int64_t src_stride;    /* elements between consecutive src rows */
+  float fill;
+  int32_t width;         /* floats copied per (row, repeat) */
+  int32_t repeat;        /* the same `width` source floats written `repeat` times, back to back (e.g. once per body) */
+  int32_t reserved;
+  const float* add;      /* dev [repeat, width] added to every destination row, or NULL */
+  float* dst;            /* dev [*, dst_stride] */
+  int64_t dst_stride;    /* elements between consecutive dst rows (>= width * repeat) */
+} AmpScatterRows;
+int amp_scatter_rows(const AmpScatterRows* ops, int32_t n_ops, const int64_t* ids_dev, const int64_t* count_dev, int64_t max_n,
+                     amp_stream_t stream);
+
+/* amp_reset_compact_tiles + amp_reset_apply (+ the reset-side amp_command_step(AMP_COMMAND_RESET) when command != NULL) as
+ * ONE launch: what DirectRLEnv.step does between _get_rewards and _get_observations (reset_buf.nonzero() -> _reset_idx,
+ * g1_amp_env.py:332-441) with no host round trip and a single kernel.  args->env_ids / args->count must be compact->ids /
+ * compact->count (they are written by this call), args->max_n >= compact->num_envs.  Results are bit-identical to the
+ * separate calls. */
+int amp_reset_compact_apply(const AmpMotion* h, const AmpCompactArgs* compact, const AmpResetArgs* args,
+                            const AmpCommandArgs* command, amp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Discriminator style reward  (replaces the inference half of skrl's AMP agent: amp_state_preprocessor
  * -> discriminator MLP -> style reward -> reward mix; shape agents/skrl_g1_walk_amp_cfg.yaml:31-39,
@@ -373,15 +418,6 @@ int amp_disc_style_reward_prescaled(const AmpDisc* h, const void* scaled_dev, in
  * the GEMMs) rides on the workgroups of the finalize launch instead of paying its own ~6 us launch -- what matters on the
  * 8 192-env shards of the multi-GPU configurations, where the step is a chain of latency-bound launches.  Results are
  * bit-identical to the two separate calls; ids / count become valid when this call's work completes. */
-typedef struct {
-  const uint8_t* mask;         /* dev [num_envs] reset mask (AmpEnvBuffers.reset_mask) */
-  const int32_t* tile_counts;  /* dev: AmpEnvBuffers.reset_tile_counts of the same step */
-  int32_t tile_envs;           /* amp_env_step_tile_envs(cfg, num_envs) */
-  int32_t reserved;
-  int64_t num_envs;
-  int64_t* ids;                /* dev [num_envs] out, ascending */
-  int64_t* count;              /* dev [1] out */
-} AmpCompactArgs;
 int amp_disc_style_reward_prescaled_compact(const AmpDisc* h, const void* scaled_dev, int64_t rows, float reward_scale,
                                             const float* task_reward_dev, float task_weight, float style_weight,
                                             float* logits_dev, float* style_dev, float* combined_dev, void* workspace_dev,

@@ -56,6 +56,61 @@ def test_reset_apply_equals_host_driven_reset():
     assert torch.equal(buf, ref_buf)  # reset rows overwritten, every other row untouched
 
 
+@pytest.mark.parametrize("clips,K,N,tile,density", [("g1_dance", 10, 3000, 8, 0.2), ("g1_walk", 2, 65536, 32, 0.01),
+                                                    ("humanoid3", 2, 8192, 16, 1.0), ("g1_walk", 2, 4099, 64, 0.5)])
+def test_reset_compact_apply_equals_the_separate_launches(clips, K, N, tile, density):
+    """amp_reset_compact_apply (compaction + clip / time draw + reference state + K expert frames + clears + command
+    resample in ONE launch) against amp_reset_compact + amp_reset_apply + amp_command_step + masked fills: torch.equal on
+    everything, at the steady-state density (1 %), at 100 % (every workgroup walks 256 envs x K samples) and ragged N."""
+    from humanoid_amp_amd import _native as nat
+    from humanoid_amp_amd.engine import command_step, reset_compact
+    from humanoid_amp_amd.motions import MotionLoader
+    from humanoid_amp_amd.robots import G1_JOINT_NAMES, G1_KEY_BODY_NAMES, HUMANOID_KEY_BODY_NAMES
+
+    ml = MotionLoader(",".join(gu.clip_files(clips)), "cuda:0")
+    g1 = clips.startswith("g1")
+    perm = ml.get_dof_index(G1_JOINT_NAMES) if g1 else list(range(ml.num_dofs))
+    D = ml.set_obs_layout(perm, 0 if g1 else 1, ml.get_body_index(G1_KEY_BODY_NAMES if g1 else HUMANOID_KEY_BODY_NAMES))
+    gen = torch.Generator().manual_seed(N)
+    mask = (torch.rand(N, generator=gen) < density).cuda()
+    pad = (-N) % tile
+    counts = torch.cat([mask, torch.zeros(pad, dtype=torch.bool, device="cuda")]).view(-1, tile).sum(1).to(torch.int32)
+    origins = torch.randn(N, 3, generator=gen).cuda()
+    nd = ml.num_dofs
+    state0 = dict(buf=torch.randn(N, K, D, generator=gen).cuda(), ep=torch.randint(1, 300, (N,), generator=gen).cuda(),
+                  la=torch.randn(N, nd, generator=gen).cuda(), jr=torch.zeros(N, dtype=torch.bool, device="cuda"),
+                  cmd=torch.randn(N, 2, generator=gen).cuda(), left=torch.rand(N, generator=gen).cuda(),
+                  m_ids=torch.full((N,), -1, dtype=torch.int64, device="cuda"), m_t=torch.full((N,), -1.0, device="cuda"))
+    vel, tr, seed, step, off = (-1.0, 1.5), (4.0, 7.0), 12345, 678, 40000
+    # separate launches
+    a = {k: v.clone() for k, v in state0.items()}
+    ids_a, count_a = reset_compact(mask)
+    out_a = ml.reset_apply(ids_a, count_a, K, seed=seed, step=step, start=False, env_origins=origins, z_lift=0.05,
+                           amp_observation_buffer=a["buf"], env_motion_ids=a["m_ids"], env_motion_start_times=a["m_t"], env_offset=off)
+    command_step(a["cmd"], a["left"], mode=nat.AMP_COMMAND_RESET, step_dt=1 / 30, vel_range=vel, time_range=tr, seed=seed, step=step,
+                 env_offset=off, reset_mask=mask)
+    a["ep"].masked_fill_(mask, 0)
+    a["la"].masked_fill_(mask[:, None], 0.0)
+    a["jr"] |= mask
+    # one launch
+    b = {k: v.clone() for k, v in state0.items()}
+    ids_b, count_b = torch.full((N,), -7, dtype=torch.int64, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda")
+    ca = nat.AmpCommandArgs()
+    ca.command, ca.time_left = b["cmd"].data_ptr(), b["left"].data_ptr()
+    ca.step_dt, ca.vel_lo, ca.vel_span, ca.t_lo, ca.t_span = 1 / 30, vel[0], vel[1] - vel[0], tr[0], tr[1] - tr[0]
+    ca.seed, ca.step, ca.env_offset = seed, step, off
+    out_b = ml.reset_compact_apply(mask, counts, tile, ids_b, count_b, K, seed=seed, step=step, start=False, env_origins=origins,
+                                   z_lift=0.05, amp_observation_buffer=b["buf"], env_motion_ids=b["m_ids"],
+                                   env_motion_start_times=b["m_t"], env_offset=off, episode_length=b["ep"], last_actions=b["la"],
+                                   just_reset=b["jr"], command=ca)
+    n = int(count_a)
+    assert int(count_b) == n == int(mask.sum()) and torch.equal(ids_a[:n], ids_b[:n])
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    for k in out_a:
+        assert torch.equal(out_a[k][:n], out_b[k][:n]), k
+
+
 @pytest.mark.parametrize("strategy", ["random", "random-start"])
 def test_env_device_reset_loop(strategy):
     from humanoid_amp_amd.envs import G1AmpDanceEnvCfg, G1AmpEnv
