@@ -44,7 +44,7 @@ class AmpResetArgs(C.Structure):
         ("motion_ids", C.c_void_p), ("motion_times", C.c_void_p),
         ("env_motion_ids", C.c_void_p), ("env_motion_start_times", C.c_void_p), ("env_offset", C.c_int64),
         ("episode_length", C.c_void_p), ("last_actions", C.c_void_p), ("just_reset", C.c_void_p), ("n_actions", C.c_int32),
-        ("reserved2", C.c_int32),
+        ("reserved2", C.c_int32), ("step_dev", C.c_void_p),
     ]
 
 
@@ -72,6 +72,7 @@ class AmpCommandArgs(C.Structure):
         ("command", C.c_void_p), ("time_left", C.c_void_p), ("step_dt", C.c_float), ("vel_lo", C.c_float), ("vel_span", C.c_float),
         ("t_lo", C.c_float), ("t_span", C.c_float), ("reserved", C.c_int32), ("seed", C.c_uint64), ("step", C.c_uint64),
         ("env_offset", C.c_int64), ("reset_mask", C.c_void_p), ("env_ids", C.c_void_p), ("count", C.c_void_p), ("n_ids", C.c_int64),
+        ("step_dev", C.c_void_p),
     ]
 
 

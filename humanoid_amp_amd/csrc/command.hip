@@ -34,7 +34,7 @@ __global__ __launch_bounds__(kBlock) void command_kernel(AmpCommandArgs a, int64
     const float left = a.time_left[env] - a.step_dt;  // command_time_left -= step_dt
     if (left <= 0.0f && ranged) {
       float cx, cy, tl;
-      draw_command(a.seed, a.step, (uint64_t)(a.env_offset + env), 0u, a.vel_lo, a.vel_span, a.t_lo, a.t_span, cx, cy, tl);
+      draw_command(a.seed, command_step_of(a), (uint64_t)(a.env_offset + env), 0u, a.vel_lo, a.vel_span, a.t_lo, a.t_span, cx, cy, tl);
       a.command[2 * env] = cx;
       a.command[2 * env + 1] = cy;
       a.time_left[env] = tl;

@@ -21,10 +21,12 @@ __device__ __forceinline__ void draw_command(uint64_t seed, uint64_t step, uint6
 
 // the reset-side resample of one env (g1_amp_env.py:421-439): the ranged draw, or the fixed command (lo, 0) with an
 // infinite timer when the range is empty (:436-439)
+__device__ __forceinline__ uint64_t command_step_of(const AmpCommandArgs& a) { return a.step + (a.step_dev ? *a.step_dev : 0ull); }
+
 __device__ __forceinline__ void command_reset_env(const AmpCommandArgs& a, int64_t env) {
   if (a.vel_span > 0.0f) {
     float cx, cy, tl;
-    draw_command(a.seed, a.step, (uint64_t)(a.env_offset + env), 1u, a.vel_lo, a.vel_span, a.t_lo, a.t_span, cx, cy, tl);
+    draw_command(a.seed, command_step_of(a), (uint64_t)(a.env_offset + env), 1u, a.vel_lo, a.vel_span, a.t_lo, a.t_span, cx, cy, tl);
     a.command[2 * env] = cx;
     a.command[2 * env + 1] = cy;
     a.time_left[env] = tl;

@@ -245,7 +245,9 @@ __global__ __launch_bounds__(kBlock) void sample_times_kernel(ClipMeta m, uint64
                                                               const int64_t* __restrict__ n_dev,
                                                               int64_t* __restrict__ o_ids, double* __restrict__ o_t,
                                                               int64_t* __restrict__ env_ids_out,
-                                                              float* __restrict__ env_t_out, int64_t ctr_offset, ResetClears cl) {
+                                                              float* __restrict__ env_t_out, int64_t ctr_offset, ResetClears cl,
+                                                              const uint64_t* __restrict__ step_dev) {
+  if (step_dev) step += *step_dev;
   if (n_dev) n = *n_dev < n ? *n_dev : n;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(kBlock) void reset_compact_apply_kernel(MotionView 
     const int li = wbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
     int64_t clip;
     double t;
-    draw_clip_time(v.clips, a.seed, a.step, a.start, (uint64_t)env + (uint64_t)a.env_offset, clip, t);
+    draw_clip_time(v.clips, a.seed, a.step + (a.step_dev ? *a.step_dev : 0ull), a.start, (uint64_t)env + (uint64_t)a.env_offset, clip, t);
     a.motion_ids[slot] = clip;
     a.motion_times[slot] = t;
     if (a.env_motion_ids) a.env_motion_ids[env] = clip;
@@ -530,7 +532,7 @@ int amp_motion_sample_times(const AmpMotion* h, uint64_t seed, uint64_t step, in
   AMP_REQUIRE(motion_ids && times, "amp_motion_sample_times: null buffer");
   { amp::TraceScope trace__("sample_times_kernel", (hipStream_t)stream);
     sample_times_kernel<<<grid_for(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(h->v.clips, seed, step, start, index, n, n_dev,
-                                                                              motion_ids, times, nullptr, nullptr, 0, ResetClears{});
+                                                                              motion_ids, times, nullptr, nullptr, 0, ResetClears{}, nullptr);
   }
   return launch_status("sample_times_kernel");
 }
@@ -548,7 +550,8 @@ int amp_reset_apply(const AmpMotion* h, const AmpResetArgs* a, amp_stream_t stre
     sample_times_kernel<<<grid_for(n, kBlock), kBlock, 0, st>>>(h->v.clips, a->seed, a->step, a->start, a->env_ids, n, a->count,
                                                              a->motion_ids, a->motion_times, a->env_motion_ids,
                                                              a->env_motion_start_times, a->env_offset,
-                                                             ResetClears{a->episode_length, a->last_actions, a->just_reset, a->n_actions});
+                                                             ResetClears{a->episode_length, a->last_actions, a->just_reset, a->n_actions},
+                                                             a->step_dev);
   }
   int rc = launch_status("sample_times_kernel");
   if (rc != AMP_OK) return rc;

@@ -362,6 +362,11 @@ class LazyRewardLog(dict):
     def __init__(self, names, means_dev: torch.Tensor, drop=()):
         super().__init__()
         self._names, self._means, self._drop = tuple(names), means_dev, frozenset(drop)
+        self._src = means_dev
+
+    def renew(self) -> "LazyRewardLog":
+        """A fresh, unread log over the same device tensor (a replayed hipGraph rewrites it in place every step)."""
+        return LazyRewardLog(self._names, self._src, self._drop)
 
     def _fill(self):
         m, self._means = self._means, None
@@ -379,12 +384,29 @@ class LazyRewardLog(dict):
     def __len__(self): self._fill(); return dict.__len__(self)
     def __contains__(self, k): self._fill(); return dict.__contains__(self, k)
     def __repr__(self): self._fill(); return dict.__repr__(self)
-    def __eq__(self, o): self._fill(); return dict.__eq__(self, o)
+    def __eq__(self, o):
+        self._fill()
+        if isinstance(o, LazyRewardLog):
+            o._fill()
+        return dict.__eq__(self, o)
     def keys(self): self._fill(); return dict.keys(self)
     def values(self): self._fill(); return dict.values(self)
     def items(self): self._fill(); return dict.items(self)
     def get(self, k, d=None): self._fill(); return dict.get(self, k, d)
     def copy(self): self._fill(); return dict(self)
+    # mutators materialise first too, so that the log behaves like the plain dict the reference hands to skrl
+    def __setitem__(self, k, v): self._fill(); dict.__setitem__(self, k, v)
+    def __delitem__(self, k): self._fill(); dict.__delitem__(self, k)
+    def pop(self, *a): self._fill(); return dict.pop(self, *a)
+    def popitem(self): self._fill(); return dict.popitem(self)
+    def setdefault(self, k, d=None): self._fill(); return dict.setdefault(self, k, d)
+    def update(self, *a, **kw): self._fill(); dict.update(self, *a, **kw)
+    def clear(self): self._fill(); dict.clear(self)
+    def __reversed__(self): self._fill(); return dict.__reversed__(self)
+    def __or__(self, o): self._fill(); return dict(self) | o
+    def __ror__(self, o): self._fill(); return o | dict(self)
+    def __ior__(self, o): self._fill(); dict.update(self, o); return self
+    def __ne__(self, o): return not self.__eq__(o)
     __hash__ = None
 
 

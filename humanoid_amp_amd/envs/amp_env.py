@@ -166,6 +166,29 @@ class _AmpEnv(DirectRLEnv):
             hit = self._bound[phases] = (key, self._kernel.bind(phases, **views))
         hit[1]()
 
+    def _track_log(self, log):
+        agent = getattr(self, "_skrl_agent", None)
+        if agent is not None:  # the reference records to TensorBoard every step when an agent is attached (:307-315)
+            try:
+                for k, v in log.items():
+                    agent.track_data(f"Reward / {k}", v)
+            except Exception:
+                pass
+
+    def _step_args(self):
+        """(step, step_dev) of the counter-based draws: the host counter, or -- once ``capture_step`` made the step a
+        hipGraph -- its device-side mirror (the graph increments it; a baked host value would repeat every replay)."""
+        if self._step_dev is not None:
+            return 0, self._step_dev.data_ptr()
+        return self.common_step_counter & (2**64 - 1), None
+
+    def _after_replay(self):
+        log = self.extras.get("log")
+        self.extras = {"amp_obs": self.amp_observation_buffer.view(-1, self.amp_observation_size)}
+        if isinstance(log, LazyRewardLog):  # a fresh lazy view of the graph's static means tensor
+            log = self.extras["log"] = log.renew()
+            self._track_log(log)
+
     def _pre_physics_step(self, actions: torch.Tensor):
         self.actions.copy_(actions)  # the reference's `self.actions = actions.clone()` into a persistent buffer
 
@@ -246,9 +269,10 @@ class _AmpEnv(DirectRLEnv):
             cmd = self._command_args() if self.IS_G1 else None
             self._reset_args = (key, c, a, cmd, nat.load().amp_reset_compact_apply, self._motion_loader._need_handle())
         _, c, a, cmd, fn, handle = self._reset_args
-        a.seed, a.step = self._reset_seed & (2**64 - 1), self.common_step_counter & (2**64 - 1)
+        a.seed = self._reset_seed & (2**64 - 1)
+        a.step, a.step_dev = self._step_args()
         if cmd is not None:
-            cmd.seed, cmd.step = a.seed, a.step
+            cmd.seed, cmd.step, cmd.step_dev = a.seed, a.step, a.step_dev
         with torch.cuda.device(self.device):
             nat.check(fn(handle, C.byref(c), C.byref(a), C.byref(cmd) if cmd is not None else None, nat.stream_ptr()),
                       "amp_reset_compact_apply")
@@ -320,7 +344,8 @@ class G1AmpEnv(_AmpEnv):
             t = self._tick_args = ((self.command_target_speed.data_ptr(), self.command_time_left.data_ptr()), self._command_args(),
                                    nat.load().amp_command_step)
         a = t[1]
-        a.seed, a.step = self._reset_seed & (2**64 - 1), self.common_step_counter & (2**64 - 1)
+        a.seed = self._reset_seed & (2**64 - 1)
+        a.step, a.step_dev = self._step_args()
         with torch.cuda.device(self.device):
             nat.check(t[2](C.byref(a), self.num_envs, nat.AMP_COMMAND_TICK, nat.stream_ptr()), "amp_command_step")
 
@@ -343,13 +368,7 @@ class G1AmpEnv(_AmpEnv):
             drop = () if self.cfg.rew_track_vel > 0.0 else ("rew_track_vel", "error_track_vel")
             log = LazyRewardLog(REWARD_TERMS, reward_log_means(self._kernel.reward_terms), drop)
             self.extras["log"] = log
-            agent = getattr(self, "_skrl_agent", None)
-            if agent is not None:  # the reference records to TensorBoard every step when an agent is attached
-                try:
-                    for k, v in log.items():
-                        agent.track_data(f"Reward / {k}", v)
-                except Exception:
-                    pass
+            self._track_log(log)
         return self._kernel.reward
 
     def _after_reset(self, env_ids):

@@ -33,6 +33,7 @@ class DirectRLEnv:
         self.reset_buf = torch.zeros_like(self.reset_terminated)
         self.extras = {}
         self.common_step_counter = 0
+        self._step_dev, self._graph = None, None  # device-side mirror of common_step_counter / captured step (capture_step)
         self._given_robot = robot
         self.scene = type("Scene", (), {})()
         self.scene.env_origins = self._grid_origins(self.num_envs, float(cfg.scene.env_spacing)).to(self.device)
@@ -85,13 +86,58 @@ class DirectRLEnv:
         return self._get_observations(), self.extras
 
     def step(self, action: torch.Tensor):
-        action = action.to(self.device)
+        if self._graph is not None:
+            return self._replay_step(action)
+        return self._step_eager(action.to(self.device))
+
+    def capture_step(self, warmup: int = 3):
+        """Capture ``step()`` into a hipGraph; later ``step(actions)`` calls copy the actions into a static buffer and
+        replay it.  Every launch of a device-reset step is asynchronous, allocation-free and free of host round trips, so
+        the whole step -- hooks, state-provider writes and (synthetic) physics included -- is one graph; what changes from
+        step to step lives on the device (the counter-based draws read a device-side step counter that the graph itself
+        increments).  Needs ``device_reset=True``.  The returned observation / reward / done tensors are static buffers,
+        overwritten by the next step (as ``extras["amp_obs"]`` always is)."""
+        if not getattr(self, "device_reset", False):
+            raise ValueError("capture_step needs device_reset=True (the host-driven reset reads the reset count back)")
+        n_act = int(self.cfg.action_space)
+        self._graph_actions = torch.zeros((self.num_envs, n_act), dtype=torch.float32, device=self.device)
+        self._step_dev = torch.full((1,), self.common_step_counter, dtype=torch.int64, device=self.device)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                self._step_eager(self._graph_actions)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        gen = getattr(getattr(self, "robot", None), "_gen", None)
+        if gen is not None and hasattr(g, "register_generator_state"):
+            g.register_generator_state(gen)  # the synthetic articulation's torch.Generator draws inside the graph
+        with torch.cuda.graph(g):
+            out = self._step_eager(self._graph_actions)
+        self.common_step_counter -= 1  # recording ran the Python bookkeeping of one step but no kernel
+        self._graph = (g, out)
+        return self
+
+    def _replay_step(self, action: torch.Tensor):
+        g, out = self._graph
+        self._graph_actions.copy_(action)
+        g.replay()
+        self.common_step_counter += 1
+        self._after_replay()
+        return out[0], out[1], out[2], out[3], self.extras
+
+    def _after_replay(self):
+        """Refresh per-step Python objects (``extras``) after a graph replay; tasks override."""
+
+    def _step_eager(self, action: torch.Tensor):
         self._pre_physics_step(action)
         for _ in range(self.cfg.decimation):
             self._apply_action()
             self.robot.step() if hasattr(self.robot, "step") else None
         self.episode_length_buf += 1
         self.common_step_counter += 1
+        if self._step_dev is not None:
+            self._step_dev += 1
         self.reset_terminated, self.reset_time_outs = self._get_dones()
         self.reset_buf = self._reset_buf()
         self.reward_buf = self._get_rewards()

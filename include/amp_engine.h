@@ -164,6 +164,9 @@ typedef struct {
   uint8_t* just_reset;          /* dev [num_envs] or NULL */
   int32_t n_actions;
   int32_t reserved2;
+  /* optional device-side step counter: the draws use step + *step_dev.  Lets a captured hipGraph of the env step advance
+   * the counter-based streams from one replay to the next (the caller increments *step_dev inside the graph). */
+  const uint64_t* step_dev;
 } AmpResetArgs;
 int amp_reset_apply(const AmpMotion* h, const AmpResetArgs* args, amp_stream_t stream);
 
@@ -288,6 +291,7 @@ typedef struct {
   const int64_t* env_ids;    /* RESET: dev [n_ids] local env ids, or NULL */
   const int64_t* count;      /* RESET: dev [1] optional cap on n_ids (the compaction's count), or NULL */
   int64_t n_ids;
+  const uint64_t* step_dev;  /* optional device-side step counter: the draws use step + *step_dev (see AmpResetArgs) */
 } AmpCommandArgs;
 int amp_command_step(const AmpCommandArgs* args, int64_t num_envs, int32_t mode, amp_stream_t stream);
 

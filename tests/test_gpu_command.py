@@ -102,6 +102,50 @@ def test_reward_log_means_and_lazy_log():
     assert "rew_track_vel" not in log and log.materialized and len(log) == 6
     assert abs(log["total_reward"] - float(want[0])) <= 1e-6 and isinstance(log["total_reward"], float)
     assert dict(log.items()).keys() == {k for k in REWARD_TERMS if "track" not in k}
+    # mutators act on the materialised values, like the plain dict the reference hands to skrl (never on the empty shell)
+    fresh = lambda: LazyRewardLog(REWARD_TERMS, means, drop=("rew_track_vel", "error_track_vel"))  # noqa: E731
+    l2 = fresh()
+    assert abs(l2.pop("total_reward") - float(want[0])) <= 1e-6 and len(l2) == 5
+    l3 = fresh()
+    l3.update(total_reward=7.0, extra=1.0)
+    assert l3["total_reward"] == 7.0 and l3["extra"] == 1.0 and len(l3) == 7
+    l4 = fresh()
+    assert l4.setdefault("pub_action_l2", -1.0) != -1.0 and (fresh() | {"x": 1})["x"] == 1
+    assert fresh() == fresh() and not (fresh() != fresh()) and fresh() == dict(fresh().items())
+    assert list(reversed(fresh())) == list(reversed(list(fresh())))
+    k, v = fresh().popitem()
+    assert k == "pub_joint_vel_l2" and isinstance(v, float)
+    # a ragged env count takes the scalar tail / the unaligned-row path
+    for n in (4099, 37):
+        t2 = torch.randn(3, n, generator=torch.Generator().manual_seed(n))
+        got = reward_log_means(t2.cuda())
+        assert float((got.cpu().double() - t2.double().mean(dim=1)).abs().max()) <= 1e-6
+
+
+def test_command_draws_follow_the_run_seed_and_the_shard():
+    """the velocity-command stream is keyed by the run's seed (torch.manual_seed / cfg.seed / env.reset(seed=)),
+    as the reference's torch.rand draws are, and two ranks never draw the same stream for their local env i."""
+    from humanoid_amp_amd.envs import G1AmpEnv, G1AmpEnvCfg_CUSTOM, G1AmpWalkEnvCfg
+
+    def run(manual_seed=None, reset_seed=None, env_offset=None, ctor_seed=None, cfg_seed=None):
+        cfg = G1AmpEnvCfg_CUSTOM(motion_file=G1AmpWalkEnvCfg().motion_file, num_amp_observations=2, reset_strategy="random")
+        cfg.scene.num_envs = 256
+        if cfg_seed is not None:
+            cfg.seed = cfg_seed
+        if manual_seed is not None:
+            torch.manual_seed(manual_seed)
+        env = G1AmpEnv(cfg, device_reset=True, reset_seed=ctor_seed, env_offset=env_offset)
+        env.reset(seed=reset_seed)
+        for _ in range(3):
+            env.step(torch.zeros(256, 29, device="cuda"))
+        return env.command_target_speed.clone()
+
+    assert torch.equal(run(manual_seed=1), run(manual_seed=1))
+    assert not torch.equal(run(manual_seed=1), run(manual_seed=2))          # torch.manual_seed before construction
+    assert not torch.equal(run(manual_seed=1, reset_seed=10), run(manual_seed=1, reset_seed=11))   # env.reset(seed=)
+    assert torch.equal(run(manual_seed=1, reset_seed=10), run(manual_seed=2, reset_seed=10))
+    assert not torch.equal(run(cfg_seed=4), run(cfg_seed=5)) and torch.equal(run(cfg_seed=4), run(manual_seed=9, cfg_seed=4))
+    assert not torch.equal(run(ctor_seed=3, env_offset=0), run(ctor_seed=3, env_offset=256))       # rank 0 vs rank 1 shards
 
 
 def test_g1_env_step_has_no_host_sync():

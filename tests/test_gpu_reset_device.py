@@ -147,3 +147,61 @@ def test_env_device_reset_loop(strategy):
         amp = oenv.shift_history(shadow, ob)
         assert float((extras["amp_obs"].cpu() - amp).abs().max()) <= TOL
     assert total_resets > 300
+
+
+def _deterministic_physics(robot):
+    """The synthetic articulation's toy integrator without its random kick (same ops in eager and captured mode)."""
+    def step():
+        d, dt = robot.data, robot.dt
+        d.joint_acc.copy_(400.0 * (robot._target - d.joint_pos) - 40.0 * d.joint_vel)
+        d.joint_vel.add_(d.joint_acc, alpha=dt)
+        d.joint_pos.add_(d.joint_vel, alpha=dt)
+        d.body_lin_vel_w[..., 2] -= 9.81 * dt * 0.5
+        d.body_pos_w.add_(d.body_lin_vel_w, alpha=dt)
+        d.body_pos_w[..., 2].clamp_(min=0.0)
+    robot.step = step
+
+
+@pytest.mark.parametrize("task", ["g1_walk", "humanoid"])
+def test_captured_step_equals_eager(task):
+    """env.capture_step(): the whole DirectRLEnv step as ONE hipGraph (hooks, device-side reset, state-provider writes,
+    physics) replayed per step equals the eager step bit for bit over 40 steps -- including the counter-based draws, which
+    read the device-side step counter the graph increments -- with resets from deaths and time-outs on the way."""
+    from humanoid_amp_amd.envs import G1AmpEnv, G1AmpWalkEnvCfg, HumanoidAmpEnv, HumanoidAmpWalkEnvCfg
+
+    def make():
+        cfg = G1AmpWalkEnvCfg() if task == "g1_walk" else HumanoidAmpWalkEnvCfg()
+        cfg.scene.num_envs = 700
+        cfg.episode_length_s = 0.5
+        env = (G1AmpEnv if task == "g1_walk" else HumanoidAmpEnv)(cfg, device_reset=True, reset_seed=5)
+        _deterministic_physics(env.robot)
+        env.reset(seed=3)  # the full reset draws clips / times from the host numpy RNG, as the reference does
+        env.episode_length_buf.copy_(torch.randint(0, env.max_episode_length, (700,), generator=torch.Generator().manual_seed(1)).cuda())
+        return env
+
+    eager, graph = make(), make()
+    gen = torch.Generator().manual_seed(2)
+    acts = [(torch.randn(700, eager.cfg.action_space, generator=gen) * 0.3).cuda() for _ in range(40)]
+    for a in acts[:4]:
+        eager.step(a)
+        graph.step(a)
+    graph.capture_step(warmup=2)
+    zero = torch.zeros_like(acts[0])
+    for _ in range(2):  # capture_step ran two warm-up steps on zero actions (the recording pass itself executes nothing)
+        eager.step(zero)
+    assert graph.common_step_counter == eager.common_step_counter
+    n_reset = 0
+    for a in acts[4:]:
+        oe, re_, te, oe_t, xe = eager.step(a)
+        og, rg, tg, og_t, xg = graph.step(a)
+        assert torch.equal(oe["policy"], og["policy"]) and torch.equal(re_, rg) and torch.equal(te, tg) and torch.equal(oe_t, og_t)
+        assert torch.equal(xe["amp_obs"], xg["amp_obs"])
+        assert torch.equal(eager.episode_length_buf, graph.episode_length_buf)
+        if task == "g1_walk":
+            assert torch.equal(eager.command_target_speed, graph.command_target_speed)
+            assert torch.equal(eager.command_time_left, graph.command_time_left)
+            assert xe["log"] == xg["log"]
+        for k in ("joint_pos", "body_pos_w", "body_quat_w"):
+            assert torch.equal(getattr(eager.robot.data, k), getattr(graph.robot.data, k)), k
+        n_reset += int((te | oe_t).sum())
+    assert n_reset > 100

@@ -18,7 +18,7 @@ from humanoid_amp_amd import _native as nat
 
 
 def dropin_env_step(num_envs: int, steps: int = 50, warmup: int = 10, physics: bool = True, task: str = "walk",
-                    device: str = "cuda:0"):
+                    device: str = "cuda:0", graph: bool = False):
     from humanoid_amp_amd.envs import G1AmpEnv, G1AmpDanceEnvCfg, G1AmpWalkEnvCfg
 
     cfg = {"walk": G1AmpWalkEnvCfg, "dance": G1AmpDanceEnvCfg}[task]()
@@ -34,23 +34,33 @@ def dropin_env_step(num_envs: int, steps: int = 50, warmup: int = 10, physics: b
     acts = [torch.randn(num_envs, cfg.action_space, device=device) * 0.3 for _ in range(4)]
     for i in range(warmup):
         env.step(acts[i & 3])
+    if graph:
+        env.capture_step()
+        for i in range(3):
+            env.step(acts[i & 3])
     torch.cuda.synchronize()
     torch.cuda.set_sync_debug_mode("error")  # a host sync inside step() would raise
     try:
         t0 = time.perf_counter()
+        marks = [t0]
         for i in range(steps):
             env.step(acts[i & 3])
+            marks.append(time.perf_counter())
     finally:
         torch.cuda.set_sync_debug_mode("default")
+    submit = (time.perf_counter() - t0) / steps   # host time to enqueue a step
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / steps
+    env._graph = None  # the tracer brackets eager launches
     with nat.KernelTrace(capacity=64 * 20) as tr:
         for i in range(10):
             env.step(acts[i & 3])
     per = {k: round(t / 10 * 1e3, 2) for k, (c, t) in tr.summary().items()}   # us per step (all launches of that kernel)
     calls = {k: c / 10 for k, (c, t) in tr.summary().items()}
     resets = float(env._kernel.reset_count.item())
-    return {"envs": num_envs, "task": task, "physics": physics, "wall_us_per_step": round(wall * 1e6, 1),
+    return {"envs": num_envs, "task": task, "physics": physics, "graph": graph, "wall_us_per_step": round(wall * 1e6, 1), "host_submit_us_per_step": round(submit * 1e6, 1),
+            "host_submit_us_median_max": [round(sorted(b - a for a, b in zip(marks, marks[1:]))[len(marks) // 2] * 1e6, 1),
+                                          round(max(b - a for a, b in zip(marks, marks[1:])) * 1e6, 1)],
             "env_steps_per_s": round(num_envs / wall, 1), "engine_kernel_us_per_step": round(sum(per.values()), 1),
             "engine_launches_per_step": sum(calls.values()), "kernels_us": per, "resets_last_step": resets}
 
@@ -73,7 +83,10 @@ def hotpath_env_launch(num_envs: int, workload: str = "g1_walk", device: str = "
 if __name__ == "__main__":
     sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [4096, 8192, 65536]
     for n in sizes:
-        for physics in (True, False):
-            print(json.dumps(dropin_env_step(n, physics=physics)), flush=True)
+        for physics, graph in ((True, False), (False, False), (True, True), (False, True)):
+            try:
+                print(json.dumps(dropin_env_step(n, physics=physics, graph=graph)), flush=True)
+            except Exception as e:  # e.g. a torch build that cannot capture a custom generator
+                print(json.dumps({"envs": n, "physics": physics, "graph": graph, "error": repr(e)[:300]}), flush=True)
         print(json.dumps({"envs": n, "hotpath_kernels_us": hotpath_env_launch(n)}), flush=True)
         torch.cuda.empty_cache()
