@@ -67,6 +67,9 @@ __device__ __forceinline__ void panel_wait_fills(int younger_pieces) {  // vmcnt
 template <int KS, int TM>
 __global__ __launch_bounds__(panel_threads<TM>(), 1) void disc_gemm_f16_panel_kernel(GemmF16Args g) {
   static_assert(KS >= 2 && KS <= 12, "the activation fragments of the whole reduction live in registers");
+  // TM = 2 (4 waves of 64 x 64 per chunk) was removed in round 3: slower (60 vs 52 us), 443 registers with the spills parked
+  // in AGPRs, and an earlier build of it that spilled to scratch faulted at 65 536 rows (profiles/r02_gemm_f16_l1_panel_experiment.txt)
+  static_assert(TM == 1, "only the 8-wave variant (32 x 64 per wave and chunk) is kept");
   constexpr int NKB = (KS + 1) / 2, TN = 2, NST = kPanelStages, kThreads = panel_threads<TM>();
   constexpr int PPW = 16 / (kThreads / 64);  // fill pieces per wave and unit
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
