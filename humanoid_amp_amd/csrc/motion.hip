@@ -62,75 +62,170 @@ __global__ __launch_bounds__(kBlock) void build_hot_kernel(MotionView v, int64_t
   hot[e] = val;
 }
 
+// samp[f] = [dof_pos | dof_vel | body_pos | body_lin | body_ang | body_rot], segments padded to 4 floats (zeros)
+__global__ __launch_bounds__(kBlock) void build_sample_table_kernel(MotionView v, int64_t n_frames, float* __restrict__ samp) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int SP = v.SP, nd = v.n_dof, B = v.n_bodies, dw = samp_dof_w(nd), bw = samp_body_w(B);
+  if (e >= n_frames * SP) return;
+  const int64_t f = e / SP;
+  int j = (int)(e - f * SP);
+  float val = 0.0f;
+  if (j < dw) { if (j < nd) val = v.dof_pos[f * nd + j]; }
+  else if ((j -= dw) < dw) { if (j < nd) val = v.dof_vel[f * nd + j]; }
+  else if ((j -= dw) < bw) { if (j < 3 * B) val = v.body_pos[f * 3 * B + j]; }
+  else if ((j -= bw) < bw) { if (j < 3 * B) val = v.body_lin[f * 3 * B + j]; }
+  else if ((j -= bw) < bw) { if (j < 3 * B) val = v.body_ang[f * 3 * B + j]; }
+  else { j -= bw; val = v.body_rot[f * 4 * B + j]; }
+  samp[e] = val;
+}
+
 // ------------------------------------------------------------------------------------------------
-// MotionLoader.sample: 6 outputs (motions/motion_loader.py:373-390)
+// MotionLoader.sample: 6 outputs (motions/motion_loader.py:331-390)
+//
+// A workgroup owns T consecutive samples (64 / 32 / 16 / 8: the largest whose six output tiles fit 56 KB of LDS).
+//   phase A  one sample per lane: fp64 frame / blend index -> LDS slot (i0, i1, blend)
+//   phase B  a lane owns ONE quad of columns of the padded sample table (which output it feeds, where its four columns land
+//            in that output's LDS tile, which of them are padding: per-lane constants) and walks the tile's samples: two 16-B
+//            gathers + four LERPs per item, or -- for the quads of the rotation segment -- one SLERP; no per-element row /
+//            column arithmetic (the first version walked every output flat with 4-B gathers, an LDS slot read and a
+//            (sample, column) carry per element: 2.0 TB/s of output at 131 072 samples of G1_walk)
+//   phase C  each output's tile is one contiguous run of T * row floats in HBM: streamed out of LDS with 16-B stores
+// Same arithmetic per element as before (lerp_ref / slerp_ref on the same operands): bit-identical.
 // ------------------------------------------------------------------------------------------------
 struct SampleSlot {
   int32_t i0, i1;
   float blend;
 };
 
-__device__ __forceinline__ void lerp_table_tile(const float* __restrict__ table, float* __restrict__ out, int row,
-                                                int64_t tile_base, int n_tile, const SampleSlot* slots) {
-  if (!out) return;
-  // flat walk over n_tile*row contiguous output floats; (s, j) advanced incrementally (no division in the loop)
-  const int step_s = kBlock / row, step_j = kBlock % row;
-  int s = threadIdx.x / row, j = threadIdx.x % row;
-  float* o = out + tile_base * row;
-  for (int e = threadIdx.x; e < n_tile * row; e += kBlock) {
-    const SampleSlot sl = slots[s];
-    const float a = table[(int64_t)sl.i0 * row + j];
-    const float b = table[(int64_t)sl.i1 * row + j];
-    o[e] = lerp_ref(a, b, sl.blend);
-    s += step_s;
-    j += step_j;
-    if (j >= row) {
-      j -= row;
-      s += 1;
-    }
-  }
+__host__ __device__ inline int sample_out_floats(int n_dof, int n_bodies) { return 2 * n_dof + 13 * n_bodies; }
+static inline int sample_tile(int n_dof, int n_bodies) {
+  int T = 64;
+  while (T > 8 && (size_t)T * sample_out_floats(n_dof, n_bodies) * sizeof(float) > 56 * 1024) T >>= 1;
+  return T;
+}
+static inline size_t sample_lds(int T, int n_dof, int n_bodies) {
+  return sizeof(float) * ((size_t)T * sample_out_floats(n_dof, n_bodies) + 4) + sizeof(SampleSlot) * T;
 }
 
+struct SampleOuts {
+  float* o[6];  // dof_pos, dof_vel, body_pos, body_lin, body_ang, body_rot (the sample table's segment order)
+};
+
 __global__ __launch_bounds__(kBlock) void sample_kernel(MotionView v, const double* __restrict__ times,
-                                                        const int64_t* __restrict__ ids, int64_t n,
-                                                        float* __restrict__ o_dp, float* __restrict__ o_dv,
-                                                        float* __restrict__ o_bp, float* __restrict__ o_br,
-                                                        float* __restrict__ o_bl, float* __restrict__ o_ba) {
-  __shared__ SampleSlot slots[kBlock];
-  const int64_t tile_base = (int64_t)blockIdx.x * kBlock;
-  const int n_tile = (int)((n - tile_base) < kBlock ? (n - tile_base) : kBlock);
-  if (threadIdx.x < n_tile) {
-    const int64_t i = tile_base + threadIdx.x;
+                                                        const int64_t* __restrict__ ids, int64_t n, int T, SampleOuts out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int nd = v.n_dof, B = v.n_bodies, dw = samp_dof_w(nd), bw = samp_body_w(B);
+  const int tid = threadIdx.x;
+  // LDS: the six output tiles back to back ([T][row] each, 16-B aligned starts: T * row is a multiple of 4), a trash quad, slots
+  const int row[6] = {nd, nd, 3 * B, 3 * B, 3 * B, 4 * B};
+  const int segw[5] = {dw, dw, bw, bw, bw};
+  int img[6];
+  {
+    int o = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) { img[a] = o; o += T * row[a]; }
+  }
+  const int total = T * sample_out_floats(nd, B);
+  float* const s_trash = smem + total;
+  SampleSlot* const slots = reinterpret_cast<SampleSlot*>(smem + total + 4);
+  const int64_t tile_base = (int64_t)blockIdx.x * T;
+  const int n_tile = (int)((n - tile_base) < T ? (n - tile_base) : T);
+  // ---- phase A ---------------------------------------------------------------------------------------------------
+  if (tid < n_tile) {
+    const int64_t i = tile_base + tid;
     int64_t a, b;
     double w;
     frame_blend_ref(v.clips, times[i], ids ? ids[i] : 0, a, b, w);
-    slots[threadIdx.x] = SampleSlot{(int32_t)a, (int32_t)b, (float)w};
+    slots[tid] = SampleSlot{(int32_t)a, (int32_t)b, (float)w};
   }
   __syncthreads();
-  const int nd = v.n_dof, B = v.n_bodies;
-  lerp_table_tile(v.dof_pos, o_dp, nd, tile_base, n_tile, slots);
-  lerp_table_tile(v.dof_vel, o_dv, nd, tile_base, n_tile, slots);
-  lerp_table_tile(v.body_pos, o_bp, B * 3, tile_base, n_tile, slots);
-  lerp_table_tile(v.body_lin, o_bl, B * 3, tile_base, n_tile, slots);
-  lerp_table_tile(v.body_ang, o_ba, B * 3, tile_base, n_tile, slots);
-  if (o_br) {
-    // one quaternion per lane: two 16-B row gathers, one 16-B coalesced store
-    const f4* __restrict__ rot = reinterpret_cast<const f4*>(v.body_rot);
-    f4* __restrict__ o = reinterpret_cast<f4*>(o_br) + tile_base * B;
-    const int step_s = kBlock / B, step_b = kBlock % B;
-    int s = threadIdx.x / B, b = threadIdx.x % B;
-    for (int e = threadIdx.x; e < n_tile * B; e += kBlock) {
-      const SampleSlot sl = slots[s];
-      const f4 a = rot[(int64_t)sl.i0 * B + b];
-      const f4 c = rot[(int64_t)sl.i1 * B + b];
-      const Quat q = slerp_ref(Quat{a.x, a.y, a.z, a.w}, Quat{c.x, c.y, c.z, c.w}, sl.blend);
-      o[e] = f4{q.w, q.x, q.y, q.z};
-      s += step_s;
-      b += step_b;
-      if (b >= B) {
-        b -= B;
-        s += 1;
+  const int SQ = v.SP >> 2;                       // quads per table row
+  const int QL = (2 * dw + 3 * bw) >> 2;          // quads of the five LERP segments; the B rotation quads follow
+  const f4* __restrict__ samp4 = reinterpret_cast<const f4*>(v.samp);
+  // ---- phase B, LERP segments: passes of up to 256 quads, G = 256 / quads sample groups side by side ---------------
+  for (int q0 = 0; q0 < QL; q0 += kBlock) {
+    const int Qp = QL - q0 < kBlock ? QL - q0 : kBlock;
+    const int G = kBlock / Qp, g = (int)(((float)tid + 0.5f) * (1.0f / (float)Qp));
+    if (g < G) {
+      const int q = q0 + tid - g * Qp;
+      // which segment the quad belongs to and its first column inside it
+      int seg = 0, c0 = 4 * q;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+        if (seg == a && c0 >= segw[a]) { c0 -= segw[a]; seg = a + 1; }
+      int rw = row[0], im = img[0];
+      const float* optr = out.o[0];
+#pragma unroll
+      for (int a = 1; a < 5; ++a)
+        if (seg == a) { rw = row[a]; im = img[a]; optr = out.o[a]; }
+      int woff[4], wstep[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bool keep = optr != nullptr && c0 + c < rw;   // padding columns and skipped outputs go to the trash quad
+        woff[c] = keep ? im + g * rw + c0 + c : total + c;
+        wstep[c] = keep ? G * rw : 0;
       }
+      float* w0 = smem + woff[0]; float* w1 = smem + woff[1]; float* w2 = smem + woff[2]; float* w3 = smem + woff[3];
+      // four samples per trip: their eight 16-B gathers are in flight together (the walk is latency-bound: L2 round trips)
+      constexpr int U = 4;
+      for (int s = g; s < n_tile; s += U * G) {
+        SampleSlot k[U];
+        f4 a[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int su = s + u * G < n_tile ? s + u * G : n_tile - 1;  // clamped: a repeated (cached) gather, result dropped
+          k[u] = slots[su];
+          a[u] = samp4[(int64_t)k[u].i0 * SQ + q];
+          b[u] = samp4[(int64_t)k[u].i1 * SQ + q];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (s + u * G < n_tile) {
+            *w0 = lerp_ref(a[u][0], b[u][0], k[u].blend);
+            *w1 = lerp_ref(a[u][1], b[u][1], k[u].blend);
+            *w2 = lerp_ref(a[u][2], b[u][2], k[u].blend);
+            *w3 = lerp_ref(a[u][3], b[u][3], k[u].blend);
+            w0 += wstep[0]; w1 += wstep[1]; w2 += wstep[2]; w3 += wstep[3];
+          }
+      }
+    }
+  }
+  // ---- phase B, rotations: one quaternion (= one quad) per item, wxyz SLERP (motion_loader.py:217-279) --------------
+  if (out.o[5]) {
+    for (int b0 = 0; b0 < B; b0 += kBlock) {
+      const int Qp = B - b0 < kBlock ? B - b0 : kBlock;
+      const int G = kBlock / Qp, g = (int)(((float)tid + 0.5f) * (1.0f / (float)Qp));
+      if (g < G) {
+        const int b = b0 + tid - g * Qp;
+        const int q = QL + b;
+        f4* w = reinterpret_cast<f4*>(smem + img[5]) + g * B + b;   // the rotation tile starts 16-B aligned, rows of B quads
+        const SampleSlot* sl = slots + g;
+        for (int s = g; s < n_tile; s += G, sl += G, w += G * B) {
+          const SampleSlot k = *sl;
+          const f4 a = samp4[(int64_t)k.i0 * SQ + q];
+          const f4 c = samp4[(int64_t)k.i1 * SQ + q];
+          const Quat o = slerp_ref(Quat{a[0], a[1], a[2], a[3]}, Quat{c[0], c[1], c[2], c[3]}, k.blend);
+          *w = f4{o.w, o.x, o.y, o.z};
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase C: every output's tile is one contiguous run ---------------------------------------------------------------
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    float* dst = out.o[a];
+    if (!dst) continue;
+    dst += tile_base * row[a];
+    const float* src = smem + img[a];
+    const int count = n_tile * row[a];
+    if ((((uintptr_t)dst) & 15) == 0) {
+      const f4* src4 = reinterpret_cast<const f4*>(src);
+      f4* dst4 = reinterpret_cast<f4*>(dst);
+      for (int e = tid; e < (count >> 2); e += kBlock) dst4[e] = src4[e];
+      for (int e = (count & ~3) + tid; e < count; e += kBlock) dst[e] = src[e];
+    } else {
+      for (int e = tid; e < count; e += kBlock) dst[e] = src[e];
     }
   }
 }
@@ -426,6 +521,22 @@ int amp_motion_create(const AmpMotionDesc* d, AmpMotion** out) {
   v.n_key = 0;
   v.D = 0;
   v.HP = 0;
+  // private padded copy of the six tables for MotionLoader.sample (16-B gathers of any 4 columns).  The caller's tables may
+  // have been written on any stream: one device-wide sync at create time, then the build on the null stream.
+  v.SP = samp_row_floats(d->n_dof, d->n_bodies);
+  e = hipMalloc(&h->d_samp, sizeof(float) * (size_t)total * v.SP);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) {
+    v.samp = h->d_samp;
+    const int64_t cells = total * v.SP;
+    build_sample_table_kernel<<<grid_for(cells, kBlock), kBlock, 0, nullptr>>>(v, total, h->d_samp);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+  }
+  if (e != hipSuccess) {
+    amp_motion_destroy(h);
+    return fail(AMP_ERR_HIP, "amp_motion_create (sample table): %s", hipGetErrorString(e));
+  }
   *out = h;
   return AMP_OK;
 }
@@ -436,6 +547,7 @@ int amp_motion_destroy(AmpMotion* h) {
   (void)hipFree(h->d_span);
   (void)hipFree(h->d_dur);
   (void)hipFree(h->d_hot);
+  (void)hipFree(h->d_samp);
   (void)hipFree(h->d_perm);
   delete h;
   return AMP_OK;
@@ -500,10 +612,12 @@ int amp_motion_sample(const AmpMotion* h, const double* times, const int64_t* id
   if (n == 0) return AMP_OK;
   AMP_REQUIRE(times, "amp_motion_sample: times is null");
   AMP_REQUIRE(n * (int64_t)h->v.n_bodies * 4 < ((int64_t)1 << 40), "amp_motion_sample: n too large");
-  AMP_REQUIRE(br == nullptr || ((uintptr_t)br % 16 == 0 && (uintptr_t)h->v.body_rot % 16 == 0),
-              "amp_motion_sample: quaternion buffers must be 16-byte aligned");
+  const int T = sample_tile(h->v.n_dof, h->v.n_bodies);
+  const size_t lds = sample_lds(T, h->v.n_dof, h->v.n_bodies);
+  AMP_REQUIRE(lds <= 64 * 1024, "amp_motion_sample: %d bodies x %d DoFs need %zu B of LDS per 8-sample tile (> 64 KiB)", h->v.n_bodies,
+              h->v.n_dof, lds);
   { amp::TraceScope trace__("sample_kernel", (hipStream_t)stream);
-    sample_kernel<<<grid_for(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(h->v, times, ids, n, dp, dv, bp, br, bl, ba);
+    sample_kernel<<<grid_for(n, T), kBlock, lds, (hipStream_t)stream>>>(h->v, times, ids, n, T, SampleOuts{{dp, dv, bp, bl, ba, br}});
   }
   return launch_status("sample_kernel");
 }

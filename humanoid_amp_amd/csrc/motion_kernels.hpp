@@ -26,7 +26,18 @@ struct MotionView {
   const float* hot;  // [F, D] private hot-subset table
   int32_t n_dof, n_bodies, n_key, D;
   int32_t HP;  // floats per hot row: D rounded up to a multiple of 4 (16-B aligned rows for dwordx4 gathers)
+  // private copy of the six tables for MotionLoader.sample: per frame [dof_pos | dof_vel | body_pos | body_lin | body_ang |
+  // body_rot], every segment padded to a multiple of 4 floats, so that any 4 columns of any table are ONE 16-B gather
+  const float* samp;
+  int32_t SP;  // floats per row of `samp`
 };
+
+// segment widths (floats, padded to 4) and the row pitch of the sample table
+__host__ __device__ inline int samp_dof_w(int n_dof) { return (n_dof + 3) & ~3; }
+__host__ __device__ inline int samp_body_w(int n_bodies) { return (3 * n_bodies + 3) & ~3; }
+__host__ __device__ inline int samp_row_floats(int n_dof, int n_bodies) {
+  return 2 * samp_dof_w(n_dof) + 3 * samp_body_w(n_bodies) + 4 * n_bodies;
+}
 
 }  // namespace amp
 
@@ -38,6 +49,7 @@ struct AmpMotion {
   int64_t* d_span;
   double* d_dur;
   float* d_hot;
+  float* d_samp;
   int32_t* d_perm;
   int32_t ref_body;
   int32_t key_bodies[amp::kMaxKey];

@@ -113,6 +113,49 @@ def test_sample_empty_and_ragged(loaders):
             assert float((g.cpu() - w).abs().max()) <= TOL, name
 
 
+@pytest.mark.parametrize("tag", list(gu.CLIPSETS))
+def test_sample_tiles_vs_oracle(tag, loaders):
+    """Round 3's sample kernel (padded table, a lane owns a column quad and walks the tile's samples, outputs staged in LDS):
+    64-sample tiles for G1_walk / the humanoid clips, 16-sample tiles for G1_dance (39 bodies); several whole tiles + a
+    ragged tail against the oracle, LERP tables bit-exact."""
+    from oracle import motion as om
+
+    ml = loaders[tag]
+    mt = om.load_tables(gu.clip_files(tag))
+    rng = np.random.default_rng(11)
+    n = 64 * 21 + 13
+    ids = rng.integers(0, ml.num_trajectories, size=n)
+    t = rng.uniform(-0.1, 1.03, size=n) * mt.durations[ids]
+    want = om.sample(mt, t, ids)
+    got = ml.sample(n, times=t, motion_ids=ids)
+    for name, g, w in zip(TABLE_KEYS, got, want):
+        if name in LERP_TABLES:
+            assert torch.equal(g.cpu(), w), name
+        else:
+            d = (g.cpu() - w).abs()
+            assert float(d[~torch.isnan(d)].max()) <= TOL and torch.equal(torch.isnan(g.cpu()), torch.isnan(w)), name
+
+
+def test_sample_skips_null_outputs(loaders):
+    """amp_motion_sample: any output pointer may be NULL (include/amp_engine.h); the others are unchanged by that."""
+    import ctypes as C
+
+    from humanoid_amp_amd import _native as nat
+
+    ml = loaders["g1_walk"]
+    n = 200
+    rng = np.random.default_rng(3)
+    t = torch.from_numpy(rng.uniform(0, 1, size=n) * ml.durations[0]).cuda()
+    full = ml.sample(n, times=t)
+    bp = torch.full_like(full[2], -7.0)
+    br = torch.full_like(full[3], -7.0)
+    null = C.c_void_p(None)
+    with torch.cuda.device("cuda:0"):
+        nat.check(nat.load().amp_motion_sample(ml._need_handle(), nat.dptr(t), null, n, null, null, nat.dptr(bp), nat.dptr(br), null, null,
+                                               nat.stream_ptr()), "amp_motion_sample")
+    assert torch.equal(bp, full[2]) and torch.equal(br, full[3])
+
+
 @pytest.mark.parametrize("name,tag,keys", [("g1_walk_k2", "g1_walk", gu.G1_KEY_BODIES), ("g1_walk_k10", "g1_walk", gu.G1_KEY_BODIES),
                                            ("g1_dance_k10", "g1_dance", gu.G1_KEY_BODIES),
                                            ("humanoid3_k2", "humanoid3", gu.HUM_KEY_BODIES)])
