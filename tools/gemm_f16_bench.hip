@@ -687,6 +687,15 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
+  if (getenv("XPS") && mode == 1) {  // the same ablations on the 128 x 128 tile of the 8 192-row shards (TM = 2, TN = 1)
+    for (int rep = 0; rep < 2; ++rep) {
+      run_dma<1, 0, 2, 1>(g, M, N, K, false); puts("  ^ 128x128 LDS-DMA kernel, full");
+      run_dma<1, 1, 2, 1>(g, M, N, K, false); puts("  ^ no fills in the loop");
+      run_dma<1, 2, 2, 1>(g, M, N, K, false); puts("  ^ no fills, no fragment reads: barriers + MFMA");
+      run_dma<1, 5, 2, 1>(g, M, N, K, false); puts("  ^ free-running waves, one barrier per k-block");
+    }
+    return 0;
+  }
   if (getenv("XP") && mode == 0) {
     run_dma<0, 0>(g, M, N, K, false);
     printf("  ^ layer-1 LDS-DMA kernel, full\n");
