@@ -39,12 +39,12 @@ constexpr int kDmaThreads = 512, kDmaBM = 256, kDmaBN = 256;  // the default til
 constexpr int kDmaKB = 32;                                  // values per k-block = 2 k-steps
 constexpr int kDmaLdsBytes = 2 * (kDmaBM + kDmaBN) * 128;   // 128 KB: two stages of both operands
 // Tile geometry: 8 waves as 2 (rows) x 4 (columns), each wave (32 TM) x (32 TN); workgroup tile (64 TM) x (128 TN).
-template <int TM, int TN>
+template <int TM, int TN, int NS = 2>
 struct DmaTile {
   static constexpr int BM = 64 * TM, BN = 128 * TN;
   static constexpr int kA = BM * 128, kB = BN * 128;          // bytes of one operand in a stage
   static constexpr int kStage = kA + kB;
-  static constexpr int kLds = 2 * kStage;
+  static constexpr int kLds = NS * kStage;
   static constexpr int kWgPerCu = kLds <= 80 * 1024 ? 2 : 1;
 };
 
@@ -76,9 +76,17 @@ static __global__ __launch_bounds__(kBlock) void split_rows_blocks_kernel(const 
 // W = weights in block layout, row pitch 2 * Kp halves; MODE 0 output H in block layout, row pitch 2 * ldh halves.
 // (Ablated variants of this kernel -- no fills, no fragment reads, no stores, free-running waves -- live in
 // tools/experiments/disc_gemm_f16_dma_xp.hpp for tools/gemm_f16_bench.hip; the product kernel carries none.)
-template <int MODE, int TM = 4, int TN = 2>
-__global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN>::kWgPerCu)) void disc_gemm_f16_dma_kernel(GemmF16Args g) {
-  using T = DmaTile<TM, TN>;
+// KB2 = 1 (small tiles): a matrix segment holds BOTH k-steps of a k-block -- R M per k-block instead of R0 M0 R1 M1 -- over a
+// THREE-stage ring.  A 128 x 128 tile has 6 MFMAs (192 matrix-pipe cycles) per k-step and wave: with two barriers per k-step
+// the barrier-bracketed segments alone cost 20 of the 29 us of an 8 192-row layer-2 launch (tools/gemm_f16_bench.hip XPS=1,
+// profiles/r03_gemm_f16_small_tile_ablation.txt: bare MFMA stream 11.7 us).  Twelve MFMAs per segment halve the barriers; the
+// third stage gives the fills the latency cover the two dropped intervals took away (k-block q + 2 is issued in R(q), awaited
+// before the barrier in front of R(q + 1)'s first read, counted: vmcnt(np) leaves only the younger k-block in flight).
+// Accumulation order per accumulator is unchanged (k ascending, the same three products per k-step): bit-identical results.
+template <int MODE, int TM = 4, int TN = 2, int KB2 = 0>
+__global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? 3 : 2>::kWgPerCu)) void disc_gemm_f16_dma_kernel(GemmF16Args g) {
+  using T = DmaTile<TM, TN, KB2 ? 3 : 2>;
+  static_assert(!KB2 || MODE == 1, "the k-block-per-segment schedule is wired for layer 2 (no zero-padding k-step skip, no split-K)");
   constexpr int BM = T::BM, BN = T::BN, kOpA = T::kA, kStage = T::kStage;
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   int mt, nt, slice = 0;
@@ -203,6 +211,70 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN>::kWgPerCu)) void disc
     __builtin_amdgcn_sched_barrier(0);
   };
 
+  if constexpr (KB2) {
+    h8 y0[2][TM], y1[2][TM], v0[2][TN], v1[2][TN];  // fragments of both k-steps
+    auto wait_younger = [&](const bool one_in_flight) {  // the wave's pieces of the OLDER outstanding k-block have landed
+      if (!one_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (np == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (np == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (np == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    };
+    fill(0, 0);
+    if (nq > 1) fill(1, 1);
+    wait_younger(nq > 1);
+    __builtin_amdgcn_s_barrier();  // k-block 0 is visible to every wave
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    auto kb = [&](const int q, const bool ahead) {  // ahead: k-block q + 2 exists and is issued here
+      const unsigned char* sb = lds + (q % 3) * kStage;
+      // R: fragments of both k-steps; stage (q + 2) % 3 held k-block q - 1, whose last reads were retired in front of a
+      // barrier this wave has passed
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+          y0[ks][a] = *reinterpret_cast<const h8*>(sb + arow + a * 32 * 128 + ca[ks][0]);
+          y1[ks][a] = *reinterpret_cast<const h8*>(sb + arow + a * 32 * 128 + ca[ks][1]);
+        }
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          v0[ks][b] = *reinterpret_cast<const h8*>(sb + brow + b * 32 * 128 + cb[ks][0]);
+          v1[ks][b] = *reinterpret_cast<const h8*>(sb + brow + b * 32 * 128 + cb[ks][1]);
+        }
+      }
+      if (ahead) fill(q + 2, (q + 2) % 3);
+      if (grp == 1) wait_younger(ahead);  // group 1's pieces of k-block q + 1: before the barrier that ends this interval
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // M: 2 x 3 TM TN MFMAs between two barriers
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0[ks][b], y1[ks][a], acc[a][b], 0, 0, 0);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1[ks][b], y0[ks][a], acc[a][b], 0, 0, 0);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0[ks][b], y0[ks][a], acc[a][b], 0, 0, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (grp == 0) wait_younger(ahead);  // group 0's pieces of k-block q + 1: behind its MFMAs
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int q = 0; q + 2 < nq; ++q) kb(q, true);
+    if (nq >= 2) kb(nq - 2, false);
+    kb(nq - 1, false);
+  } else {
   fill(0, 0);
   if (nq > 1) {
     fill(1, 1);
@@ -237,6 +309,7 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN>::kWgPerCu)) void disc
   };
   for (int q = 0; q + 1 < nq; ++q) kblock(q, true);
   kblock(nq - 1, 2 * nq - 1 < ksteps);
+  }
   if (grp == 0) __builtin_amdgcn_s_barrier();
   __syncthreads();  // every wave is done with the stages: the scratch below reuses them
 
