@@ -201,10 +201,26 @@ struct AdamSegs {
   int32_t cols[6];
   float reg2[6];
 };
-__global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamSegs a, float lr, float b1, float b2, float eps, float bc1, float bc2,
-                                                            float* __restrict__ grad_out) {
+// What changes from step to step besides the tensors lives on the DEVICE, so that a captured hipGraph of the training step
+// advances it by itself: state[0] = samples the running scaler has seen (double), state[1] = Adam step (int64 bits),
+// state[2] = the two bias corrections 1 - beta^step of the CURRENT step as floats (written by train_state_kernel, read by Adam).
+struct TrainState {
+  double count;
+  long long step;
+  float bc1, bc2;
+};
+__global__ void train_state_kernel(TrainState* __restrict__ s, double rows_merged, double beta1, double beta2) {
+  s->count += rows_merged;
+  s->step += 1;
+  s->bc1 = (float)(1.0 - pow(beta1, (double)s->step));
+  s->bc2 = (float)(1.0 - pow(beta2, (double)s->step));
+}
+
+__global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamSegs a, float lr, float b1, float b2, float eps,
+                                                            const TrainState* __restrict__ state, float* __restrict__ grad_out) {
   const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (e >= a.start[6]) return;
+  const float bc1 = state->bc1, bc2 = state->bc2;
   int s = 0;
 #pragma unroll
   for (int k = 1; k < 6; ++k) s += e >= a.start[k];
@@ -293,9 +309,13 @@ __global__ __launch_bounds__(kBlock) void scaler_part_kernel(const float* __rest
 // (+ the fp32 vectors the scaling pass reads -- mean32 / den32 [np], same formulas as disc_scaler_kernel -- so that a group's
 //  batch is scaled with the statistics that include it without a round trip through the discriminator handle)
 __global__ __launch_bounds__(kBlock) void scaler_merge_kernel(const double* __restrict__ part, int64_t rows, int cols,
-                                                              double* __restrict__ mean, double* __restrict__ var, double count,
+                                                              double* __restrict__ mean, double* __restrict__ var,
+                                                              const TrainState* __restrict__ state, double count_add,
                                                               int np, float eps, float* __restrict__ mean32,
                                                               float* __restrict__ den32) {
+  // samples seen before this batch: the count at the start of the step (device state, advanced once at the step's end)
+  // + the batches this step has merged already
+  const double count = state->count + count_add;
   const int c = blockIdx.x * kBlock + threadIdx.x;
   if (c >= cols) {
     if (mean32 && c < np) { mean32[c] = 0.0f; den32[c] = 1.0f; }
@@ -354,12 +374,11 @@ struct AmpDiscTrainer {
   AmpDiscTrainCfg cfg;
   DiscParams p;
   int64_t max_rows;   // capacity per group
-  int64_t step;
   // persistent device state
   float *w2t, *w1t;              // W2^T [h1, h2], W1^T [kN, h1] (kN = k1p rounded to 64)
   float *mom[6], *vel[6];        // Adam moments for W1 (logical [h1, in_dim]), b1, W2, b2, w3, b3
   double *mean64, *var64;        // running scaler statistics (owned here when update_scaler)
-  double count;
+  TrainState* state;             // device: scaler count, Adam step, bias corrections (see train_state_kernel)
   float* ws;                     // workspace
   int64_t ws_floats;
   int kN;
@@ -534,6 +553,7 @@ int amp_disc_trainer_destroy(AmpDiscTrainer* t) {
     (void)hipFree(t->mom[i]);
     (void)hipFree(t->vel[i]);
   }
+  (void)hipFree(t->state);
   (void)hipFree(t->mean64);
   (void)hipFree(t->var64);
   (void)hipFree(t->ws);
@@ -557,7 +577,6 @@ int amp_disc_trainer_create(AmpDisc* disc, const AmpDiscTrainCfg* cfg, const dou
   t->p = disc_params(disc);
   t->max_rows = up(cfg->max_rows_per_group, 16);
   t->kN = (int)up(t->p.k1p, 64);
-  t->count = current_count;
   const DiscParams& p = t->p;
   const int64_t sizes[6] = {(int64_t)p.h1 * p.in_dim, p.h1, (int64_t)p.h2 * p.h1, p.h2, p.h2, 1};
   hipStream_t st = (hipStream_t)stream;
@@ -568,6 +587,11 @@ int amp_disc_trainer_create(AmpDisc* disc, const AmpDiscTrainCfg* cfg, const dou
     if (e == hipSuccess) e = hipMalloc(&t->vel[i], sizeof(float) * sizes[i]);
     if (e == hipSuccess) e = hipMemsetAsync(t->mom[i], 0, sizeof(float) * sizes[i], st);
     if (e == hipSuccess) e = hipMemsetAsync(t->vel[i], 0, sizeof(float) * sizes[i], st);
+  }
+  if (e == hipSuccess) e = hipMalloc(&t->state, sizeof(TrainState));
+  if (e == hipSuccess) {
+    const TrainState s0{current_count, 0, 1.0f, 1.0f};
+    e = hipMemcpy(t->state, &s0, sizeof(TrainState), hipMemcpyHostToDevice);
   }
   if (e == hipSuccess) e = hipMalloc(&t->mean64, sizeof(double) * p.in_dim);
   if (e == hipSuccess) e = hipMalloc(&t->var64, sizeof(double) * p.in_dim);
@@ -619,7 +643,12 @@ int amp_disc_trainer_scaler(const AmpDiscTrainer* t, double* mean_out, double* v
   hipStream_t st = (hipStream_t)stream;
   if (mean_out) AMP_HIP(hipMemcpyAsync(mean_out, t->mean64, sizeof(double) * t->p.in_dim, hipMemcpyDeviceToDevice, st));
   if (var_out) AMP_HIP(hipMemcpyAsync(var_out, t->var64, sizeof(double) * t->p.in_dim, hipMemcpyDeviceToDevice, st));
-  if (count) *count = t->count;
+  if (count) {  // the count lives on the device (a replayed graph advances it): one small blocking read-back
+    TrainState s{};
+    AMP_HIP(hipMemcpyAsync(&s, t->state, sizeof(TrainState), hipMemcpyDeviceToHost, st));
+    AMP_HIP(hipStreamSynchronize(st));
+    *count = s.count;
+  }
   return AMP_OK;
 }
 
@@ -719,9 +748,9 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
       // each batch updates the running statistics, then is scaled with them (skrl order); the merge also writes the fp32
       // vectors the scaling pass reads
       scaler_part_kernel<<<dim3((p.in_dim + 63) / 64, kChunks), kBlock, 0, st>>>(groups[gi], B, p.in_dim, row_stride, dpart);
-      scaler_merge_kernel<<<(k1p + kBlock - 1) / kBlock, kBlock, 0, st>>>(dpart, B, p.in_dim, t->mean64, t->var64, t->count, k1p,
-                                                                         c.scaler_epsilon, c.use_scaler ? mean32w : nullptr, den32w);
-      t->count += (double)B;
+      scaler_merge_kernel<<<(k1p + kBlock - 1) / kBlock, kBlock, 0, st>>>(dpart, B, p.in_dim, t->mean64, t->var64, t->state,
+                                                                         (double)gi * (double)B, k1p, c.scaler_epsilon,
+                                                                         c.use_scaler ? mean32w : nullptr, den32w);
       if (c.use_scaler) { mean32 = mean32w; den32 = den32w; clip = c.scaler_clip; }
     }
     scale_rows_kernel<<<blocks(B * k1p), kBlock, 0, st>>>(groups[gi], row_stride, B, p.in_dim, k1p, mean32, den32, clip,
@@ -796,8 +825,8 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
   if (loss_dev) AMP_HIP(hipMemcpyAsync(loss_dev, loss, 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
 
   // ---- 6. Adam -------------------------------------------------------------------------------------------------
-  t->step += 1;
-  const float bc1 = 1.0f - powf(c.beta1, (float)t->step), bc2 = 1.0f - powf(c.beta2, (float)t->step);
+  // advance the device-side state: scaler count += the batches merged above, Adam step += 1, bias corrections of this step
+  train_state_kernel<<<1, 1, 0, st>>>(t->state, c.update_scaler ? 3.0 * (double)B : 0.0, (double)c.beta1, (double)c.beta2);
   const float wd2 = 2.0f * c.loss_scale * c.weight_decay_scale, lr2 = 2.0f * c.loss_scale * c.logit_reg_scale;
   const float lr = c.apply_update ? c.learning_rate : 0.0f;
   {
@@ -814,7 +843,7 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
       a.ld_p[k] = ldp[k]; a.ld_g[k] = ldg[k]; a.cols[k] = cols_[k]; a.reg2[k] = reg[k];
       a.start[k + 1] = a.start[k] + rows_[k] * cols_[k];
     }
-    adam_multi_kernel<<<blocks(a.start[6]), kBlock, 0, st>>>(a, lr, c.beta1, c.beta2, c.adam_epsilon, bc1, bc2, grads_dev);
+    adam_multi_kernel<<<blocks(a.start[6]), kBlock, 0, st>>>(a, lr, c.beta1, c.beta2, c.adam_epsilon, t->state, grads_dev);
   }
   rc = launch_status("adam_multi_kernel");
   if (rc != AMP_OK) return rc;

@@ -88,7 +88,7 @@ class G1AmpDanceEnvCfg(G1AmpEnvCfg_CUSTOM):
 @dataclass
 class G1AmpCustomEnvCfg(G1AmpEnvCfg_CUSTOM):
     episode_length_s: float = 5.0
-    motion_file: str = os.path.join(MOTIONS_DIR, "custom_motion.npz")  # clip not shipped here
+    motion_file: str = os.path.join(MOTIONS_DIR, "custom_motion.npz")  # the reference's own clip, shipped as data
 
 
 @dataclass

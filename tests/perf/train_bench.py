@@ -24,6 +24,15 @@ for _ in range(n):
     tr.step(pc, rc, mc)
 torch.cuda.synchronize()
 gpu_ms = (time.perf_counter() - t0) / n * 1e3
+tr.capture()
+for _ in range(3):
+    tr.step_captured(pc, rc, mc)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(n):
+    tr.step_captured(pc, rc, mc)
+torch.cuda.synchronize()
+graph_ms = (time.perf_counter() - t0) / n * 1e3
 with nat.KernelTrace(4096) as trc:
     tr.step(pc, rc, mc)
 kern = {k: (c, round(t * 1e3, 1)) for k, (c, t) in trc.summary().items()}
@@ -38,5 +47,5 @@ t0 = time.perf_counter()
 for _ in range(3):
     odt.loss_and_grads(w, p, r, m, mean, var)
 cpu_ms = (time.perf_counter() - t0) / 3 * 1e3
-print(json.dumps({"in_dim": in_dim, "rows_per_group": B, "gpu_ms_per_step": round(gpu_ms, 3), "tflops": round(flops / gpu_ms / 1e9, 1),
+print(json.dumps({"in_dim": in_dim, "rows_per_group": B, "gpu_ms_per_step": round(gpu_ms, 3), "hipgraph_ms_per_step": round(graph_ms, 3), "tflops": round(flops / gpu_ms / 1e9, 1),
                   "cpu_autograd_ms_per_step_16thr": round(cpu_ms, 1), "speedup": round(cpu_ms / gpu_ms, 1), "kernels_calls_us": kern}))

@@ -127,3 +127,37 @@ def test_f16x3_gemms_match_the_fp32_pipe_at_full_size(in_dim):
     ga, gb = _split(outs["f16x3"]["grads"].cpu(), w), _split(outs["f32"]["grads"].cpu(), w)
     for i, (a, b) in enumerate(zip(ga, gb)):
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), i
+
+
+def test_captured_training_step_equals_eager():
+    """AmpDiscriminatorTrainer.capture(): the step as ONE hipGraph (scaler count, Adam step and bias corrections live on the
+    device and are advanced by the graph itself) replayed five times == five eager steps of an identical trainer, bit for
+    bit: weights, running statistics, sample count, losses."""
+    from humanoid_amp_amd.engine import AmpDiscriminator, AmpDiscriminatorTrainer
+    from humanoid_amp_amd.workloads import make_disc_weights
+
+    B, dim = 512, 166
+    gen = torch.Generator().manual_seed(4)
+    batches = [[(torch.randn(B, dim, generator=gen) * (1.0 + 0.3 * k)).cuda() for k in range(3)] for _ in range(7)]
+
+    def make():
+        disc = AmpDiscriminator(make_disc_weights(dim, seed=1), "cuda:0")
+        return disc, AmpDiscriminatorTrainer(disc, batch_size=B, learning_rate=1e-3)
+
+    (d_e, t_e), (d_g, t_g) = make(), make()
+    for b in batches[:2]:
+        t_e.step(*b)
+        t_g.step(*b)
+    t_g.capture()
+    for b in batches[2:]:
+        le = t_e.step(*b)
+        lg = t_g.step_captured(*b)
+        for k in AmpDiscriminatorTrainer.LOSS_TERMS:
+            assert torch.equal(le[k], lg[k]), k
+    for (we, be), (wg, bg) in zip(t_e.weights(), t_g.weights()):
+        assert torch.equal(we, wg) and torch.equal(be, bg)
+    me, ve, ce = t_e.scaler_state()
+    mg, vg, cg = t_g.scaler_state()
+    assert torch.equal(me, mg) and torch.equal(ve, vg) and ce == cg == 1.0 + 7 * 3 * B
+    x = batches[0][0]
+    assert torch.equal(d_e.style_reward(x)["style"], d_g.style_reward(x)["style"])  # the inference planes followed

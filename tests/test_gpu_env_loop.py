@@ -147,8 +147,18 @@ def test_make_and_errors():
     bad.scene.num_envs = 8
     with pytest.raises(ValueError, match="Unknown reset strategy"):
         G1AmpEnv(bad).reset()
-    with pytest.raises(ValueError, match="not shipped"):
-        make("Isaac-G1-AMP-Custom-Direct-v0", num_envs=8)  # custom_motion.npz is not shipped: "No files found"
+    # the Custom task runs on the reference's own custom_motion.npz (309 frames, 25 bodies; shipped as data since round 3)
+    cus = make("Isaac-G1-AMP-Custom-Direct-v0", num_envs=48)
+    assert cus.cfg.num_amp_observations == 10 and cus.amp_observation_size == 830
+    assert cus.motion_key_body_indexes == [19, 20, 21, 22] and cus.motion_ref_body_index == 0
+    obs, extras = cus.reset(seed=0)
+    obs, rew, term, tout, extras = cus.step(torch.zeros(48, 29, device="cuda"))
+    assert extras["amp_obs"].shape == (48, 830) and torch.isfinite(extras["amp_obs"]).all() and torch.isfinite(rew).all()
+    # a clip that does not exist: the reference's resolver error type (motion_loader.py:55,84)
+    missing = G1AmpWalkEnvCfg(motion_file="/nonexistent/clip.npz")
+    missing.scene.num_envs = 8
+    with pytest.raises((ValueError, FileNotFoundError)):
+        G1AmpEnv(missing)
     # the Deploy task runs on the bundled motion_config.yaml (the reference's own list points at private recordings)
     dep = make("Isaac-G1-AMP-Deploy-Direct-v0", num_envs=32)
     obs, extras = dep.reset(seed=0)
