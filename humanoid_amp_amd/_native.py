@@ -53,6 +53,10 @@ class AmpCompactArgs(C.Structure):
                 ("num_envs", C.c_int64), ("ids", C.c_void_p), ("count", C.c_void_p)]
 
 
+class AmpRewardLogArgs(C.Structure):
+    _fields_ = [("reward_terms", C.c_void_p), ("n_terms", C.c_int32), ("reserved", C.c_int32), ("means", C.c_void_p)]
+
+
 class AmpScatterRows(C.Structure):
     _fields_ = [("src", C.c_void_p), ("src_stride", C.c_int64), ("fill", C.c_float), ("width", C.c_int32), ("repeat", C.c_int32),
                 ("reserved", C.c_int32), ("add", C.c_void_p), ("dst", C.c_void_p), ("dst_stride", C.c_int64)]
@@ -170,7 +174,8 @@ SIGNATURES = {
     "amp_reset_reference_state": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _vp, _vp, _vp, _vp]),
     "amp_motion_sample_times": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _i32, _vp, _vp, _i64, _vp, _vp, _vp]),
     "amp_reset_apply": (C.c_int, [_vp, C.POINTER(AmpResetArgs), _vp]),
-    "amp_reset_compact_apply": (C.c_int, [_vp, C.POINTER(AmpCompactArgs), C.POINTER(AmpResetArgs), C.POINTER(AmpCommandArgs), _vp]),
+    "amp_reset_compact_apply": (C.c_int, [_vp, C.POINTER(AmpCompactArgs), C.POINTER(AmpResetArgs), C.POINTER(AmpCommandArgs),
+                                          C.POINTER(AmpRewardLogArgs), _vp]),
     "amp_policy_obs_size": (_i64, [C.POINTER(AmpEnvCfg)]),
     "amp_actor_history_frame_size": (_i64, [C.POINTER(AmpEnvCfg)]),
     "amp_env_step": (C.c_int, [C.POINTER(AmpEnvCfg), C.POINTER(AmpSimState), C.POINTER(AmpEnvBuffers), _i64, C.c_uint32, _vp]),

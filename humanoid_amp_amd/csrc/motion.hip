@@ -364,20 +364,55 @@ __global__ __launch_bounds__(kBlock) void sample_times_kernel(ClipMeta m, uint64
 
 // ------------------------------------------------------------------------------------------------
 // The whole device-side reset as ONE launch (amp_reset_compact_apply): reset-id compaction + everything amp_reset_apply
-// does + the reset-side command resample + the per-env clears.  A workgroup owns 256 consecutive envs: compact_rank_body
-// gives every reset lane its slot in the ascending id list (and writes ids / count exactly as the stand-alone compaction
-// does); the lane then draws (clip, t), writes the root state of its slot and queues its env in an LDS list; the
-// workgroup's reset envs (0-3 of 256 in steady state) are then finished cooperatively: DoF rows, last_actions row, and
-// the K expert frames through collect_reference_body (times / clips / destination rows read from the LDS list).
-// Same device functions, same inputs per env as the separate launches: bit-identical results.
+// does + the reset-side command resample + the per-env clears (+ optionally the reward-log means of the step, on extra
+// workgroups).  A workgroup owns 256 consecutive envs: compact_rank_body gives every reset lane its slot in the ascending
+// id list (and writes ids / count exactly as the stand-alone compaction does); the lane draws (clip, t) and queues its env
+// in an LDS list; the workgroup's reset envs (0-3 of 256 in steady state) are then finished by collect_reference_body over
+// that list (times / clips / destination rows read from LDS): phase A's gathers also yield the root state, the k = 0
+// frame's first 2 n_dof columns are the DoF rows.  A chain of four dependent memory round trips (counts -> clip table ->
+// frame gathers -> column gathers) instead of the eight of the separate launches' bodies run back to back.
+// Same device functions on the same inputs per env: bit-identical to the separate launches.
 // ------------------------------------------------------------------------------------------------
+// one term's mean over the envs on a 256-lane workgroup: fp64 accumulation, fixed order (eight 16-B loads in flight per lane)
+__device__ __forceinline__ void reward_mean_block(const float* __restrict__ row, int64_t N, float* __restrict__ mean_out) {
+  __shared__ double red[kBlock];
+  const int tid = threadIdx.x;
+  double s = 0.0;
+  if ((reinterpret_cast<uintptr_t>(row) & 15) == 0) {
+    const f4* row4 = reinterpret_cast<const f4*>(row);
+    const int64_t n4 = N >> 2;
+    for (int64_t i = tid; i < n4; i += 8 * kBlock) {
+      f4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = i + u * kBlock < n4 ? row4[i + u * kBlock] : f4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += ((double)v[u][0] + (double)v[u][1]) + ((double)v[u][2] + (double)v[u][3]);
+    }
+    for (int64_t i = (n4 << 2) + tid; i < N; i += kBlock) s += (double)row[i];
+  } else {
+    for (int64_t i = tid; i < N; i += kBlock) s += (double)row[i];
+  }
+  red[tid] = s;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) *mean_out = (float)(red[0] / (double)N);
+}
+
 __global__ __launch_bounds__(kBlock) void reset_compact_apply_kernel(MotionView v, AmpCompactArgs c, AmpResetArgs a,
                                                                      AmpCommandArgs cmd, int has_cmd, int64_t n_tiles, int sub,
-                                                                     int64_t n_counts) {
+                                                                     int64_t n_counts, unsigned compact_blocks,
+                                                                     AmpRewardLogArgs lg) {
   extern __shared__ __attribute__((aligned(16))) float s_img[];  // expert_lds(D): collect_reference_body's tile
+  if (blockIdx.x >= compact_blocks) {  // the step's reward-log means ride on this launch: one workgroup per term
+    const int term = (int)(blockIdx.x - compact_blocks);
+    reward_mean_block(lg.reward_terms + (int64_t)term * c.num_envs, c.num_envs, lg.means + term);
+    return;
+  }
   __shared__ double s_t[kBlock];
   __shared__ int64_t s_clip[kBlock], s_env[kBlock], s_slot[kBlock];
-  __shared__ SampleSlot s_fb[kBlock];
   __shared__ int s_wcnt[kBlock / kWave];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int64_t env;
@@ -393,8 +428,6 @@ __global__ __launch_bounds__(kBlock) void reset_compact_apply_kernel(MotionView 
     cnt += s_wcnt[w];
   }
   if (cnt == 0) return;  // uniform: nothing to reset among this workgroup's envs
-  const int nd = v.n_dof;
-  const float* __restrict__ hot = v.hot;
   if (slot >= 0) {
     const int li = wbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
     int64_t clip;
@@ -404,54 +437,27 @@ __global__ __launch_bounds__(kBlock) void reset_compact_apply_kernel(MotionView 
     a.motion_times[slot] = t;
     if (a.env_motion_ids) a.env_motion_ids[env] = clip;
     if (a.env_motion_start_times) a.env_motion_start_times[env] = (float)t;
-    int64_t i0, i1;
-    double w;
-    frame_blend_ref(v.clips, t, clip, i0, i1, w);
-    const float bl = (float)w;
-    s_fb[li] = SampleSlot{(int32_t)i0, (int32_t)i1, bl};
     s_t[li] = t;
     s_clip[li] = clip;
     s_env[li] = env;
     s_slot[li] = slot;
-    if (a.root_state) {  // reset_state_kernel's root row (g1_amp_env.py:385-411)
-      const float* r0 = hot + i0 * v.HP + 2 * nd;
-      const float* r1 = hot + i1 * v.HP + 2 * nd;
-      float* o = a.root_state + slot * 13;
-      const float* og = a.env_origins ? a.env_origins + env * 3 : nullptr;
-      const float px = lerp_ref(r0[0], r1[0], bl), py = lerp_ref(r0[1], r1[1], bl), pz = lerp_ref(r0[2], r1[2], bl);
-      o[0] = og ? px + og[0] : px;
-      o[1] = og ? py + og[1] : py;
-      o[2] = (og ? pz + og[2] : pz) + a.z_lift;
-      const Quat q = slerp_ref(Quat{r0[3], r0[4], r0[5], r0[6]}, Quat{r1[3], r1[4], r1[5], r1[6]}, bl);
-      o[3] = q.w; o[4] = q.x; o[5] = q.y; o[6] = q.z;
-      for (int k = 7; k < 13; ++k) o[k] = lerp_ref(r0[k], r1[k], bl);
-    }
     if (a.episode_length) a.episode_length[env] = 0;
     if (a.just_reset) a.just_reset[env] = 1;
     if (has_cmd) command_reset_env(cmd, env);
   }
   __syncthreads();
-  // DoF rows of the workgroup's reset envs: hot columns [0, nd) and [nd, 2 nd), already in robot order
-  for (int which = 0; which < 2; ++which) {
-    float* out = which ? a.dof_vel : a.dof_pos;
-    if (!out) continue;
-    const int off = which * nd;
-    for (int e = tid; e < cnt * nd; e += kBlock) {
-      const int li = e / nd, j = e - li * nd;
-      const SampleSlot sl = s_fb[li];
-      out[s_slot[li] * nd + j] = lerp_ref(hot[(int64_t)sl.i0 * v.HP + off + j], hot[(int64_t)sl.i1 * v.HP + off + j], sl.blend);
-    }
-  }
   if (a.last_actions)
     for (int e = tid; e < cnt * a.n_actions; e += kBlock) {
       const int li = e / a.n_actions;
       a.last_actions[s_env[li] * a.n_actions + (e - li * a.n_actions)] = 0.0f;
     }
-  if (a.amp_obs_buffer)  // amp_observation_buffer[env] = K expert frames (g1_amp_env.py:414-419)
-    for (int chunk = 0; chunk * kExpertTile < cnt * a.K; ++chunk) {
-      collect_reference_body(v, s_t, s_clip, cnt, a.K, a.amp_obs_buffer, s_env, nullptr, chunk, s_img);
-      __syncthreads();
-    }
+  // K expert frames per reset env into amp_observation_buffer[env] (g1_amp_env.py:414-419); their phase A also writes the
+  // root state, their k = 0 frames the DoF rows
+  const ResetRows rr{a.root_state, a.dof_pos, a.dof_vel, s_slot, a.env_origins, a.z_lift};
+  for (int chunk = 0; chunk * kExpertTile < cnt * a.K; ++chunk) {
+    collect_reference_body<true>(v, s_t, s_clip, cnt, a.K, a.amp_obs_buffer, s_env, nullptr, chunk, s_img, &rr);
+    __syncthreads();
+  }
 }
 
 static inline unsigned grid_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
@@ -685,7 +691,7 @@ int amp_reset_apply(const AmpMotion* h, const AmpResetArgs* a, amp_stream_t stre
 }
 
 int amp_reset_compact_apply(const AmpMotion* h, const AmpCompactArgs* c, const AmpResetArgs* a, const AmpCommandArgs* cmd,
-                            amp_stream_t stream) {
+                            const AmpRewardLogArgs* lg, amp_stream_t stream) {
   AMP_REQUIRE(h && c && a, "amp_reset_compact_apply: null argument");
   AMP_REQUIRE(h->has_layout, "amp_reset_compact_apply: call amp_motion_set_obs_layout first");
   AMP_REQUIRE(c->num_envs >= 0 && a->K >= 1, "amp_reset_compact_apply: need num_envs >= 0 and K >= 1");
@@ -701,7 +707,9 @@ int amp_reset_compact_apply(const AmpMotion* h, const AmpCompactArgs* c, const A
               "amp_reset_compact_apply: tile_envs must be 8, 16, 32 or 64");
   AMP_REQUIRE(a->env_ids == c->ids && a->count == c->count && a->max_n >= N,
               "amp_reset_compact_apply: the reset arguments must consume the compaction's ids / count (max_n >= num_envs)");
-  AMP_REQUIRE(a->motion_ids && a->motion_times, "amp_reset_compact_apply: null buffer");
+  AMP_REQUIRE(a->motion_ids && a->motion_times && a->amp_obs_buffer, "amp_reset_compact_apply: null buffer (motion_ids / motion_times / amp_obs_buffer)");
+  AMP_REQUIRE(!lg || (lg->reward_terms && lg->means && lg->n_terms >= 1 && lg->n_terms <= 64),
+              "amp_reset_compact_apply: the reward-log arguments need reward_terms, means and 1..64 terms");
   AMP_REQUIRE(!a->last_actions || a->n_actions >= 1, "amp_reset_compact_apply: last_actions needs n_actions >= 1");
   AMP_REQUIRE(!cmd || (cmd->command && cmd->time_left), "amp_reset_compact_apply: null command buffer");
   AMP_REQUIRE(!cmd || !(cmd->vel_span > 0.0f) || cmd->t_span >= 0.0f, "amp_reset_compact_apply: negative resampling-time span");
@@ -712,7 +720,8 @@ int amp_reset_compact_apply(const AmpMotion* h, const AmpCompactArgs* c, const A
   const size_t lds = expert_lds(h->v.D);
   AMP_REQUIRE(lds <= 48 * 1024, "amp_reset_compact_apply: expert tile needs %zu B of LDS", lds);
   { amp::TraceScope trace__("reset_compact_apply_kernel", st);
-    reset_compact_apply_kernel<<<grid, kBlock, lds, st>>>(h->v, *c, *a, cmd ? *cmd : AmpCommandArgs{}, cmd ? 1 : 0, n_tiles, sub, n_counts);
+    reset_compact_apply_kernel<<<grid + (lg ? (unsigned)lg->n_terms : 0u), kBlock, lds, st>>>(h->v, *c, *a, cmd ? *cmd : AmpCommandArgs{}, cmd ? 1 : 0,
+                                                                                           n_tiles, sub, n_counts, grid, lg ? *lg : AmpRewardLogArgs{});
   }
   return launch_status("reset_compact_apply_kernel");
 }

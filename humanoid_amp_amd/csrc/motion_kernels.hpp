@@ -89,6 +89,18 @@ struct ExpertSlot {
 
 constexpr int kExpertTile = 64;  // samples per workgroup: many short workgroups hide the L2 gather latency
 
+// Optional by-products of the newest (k = 0) frame of every row, for the one-launch device reset (motion.hip): the
+// reference root state (g1_amp_env.py:385-411) falls out of phase A's gathers, the robot-order DoF rows are the first
+// 2 n_dof columns of the k = 0 expert frame (the same lerp_ref of the same hot columns: bit-identical to reset_state_kernel).
+struct ResetRows {
+  float* root_state;        // [*, 13] compact rows (slot of row r = slots[r]), may be NULL
+  float* dof_pos;           // [*, n_dof], may be NULL
+  float* dof_vel;
+  const int64_t* slots;     // [n] compact slot of row r
+  const float* origins;     // [num_envs, 3] indexed by dst_rows[r], or NULL
+  float z_lift;
+};
+
 // Phase A: one sample per lane (fp64 frame/blend, SLERP of the reference quaternion, tangent/normal).
 // Phase B: a lane LERPs FOUR consecutive columns of one sample from two 16-B gathers (hot rows are padded to a
 //          16-B pitch) and drops them into an LDS image of the tile's output, which is contiguous in HBM
@@ -97,10 +109,12 @@ constexpr int kExpertTile = 64;  // samples per workgroup: many short workgroups
 //          discriminator update, not the next kernels of the step).
 // `block` = index of the 64-sample tile, `s_img` = the workgroup's dynamic LDS (16-B aligned, expert_lds(D) bytes):
 // a device function so that it can also run as part of a horizontally fused launch (env_step.hip).
+template <bool kReset = false>
 __device__ __forceinline__ void collect_reference_body(const MotionView& v, const double* __restrict__ times,
                                                        const int64_t* __restrict__ ids, int64_t n, int K,
                                                        float* __restrict__ out, const int64_t* __restrict__ dst_rows,
-                                                       const int64_t* __restrict__ n_dev, int64_t block, float* s_img) {
+                                                       const int64_t* __restrict__ n_dev, int64_t block, float* s_img,
+                                                       const ResetRows* rr = nullptr) {
   // s_img: [64][D] output image, then the slots
   const int D = v.D, HP = v.HP, nd2 = 2 * v.n_dof;
   ExpertSlot* slots = reinterpret_cast<ExpertSlot*>(s_img + ((kExpertTile * D + 3) & ~3));
@@ -136,6 +150,15 @@ __device__ __forceinline__ void collect_reference_body(const MotionView& v, cons
     const int64_t row = dst_rows ? dst_rows[r] : r;
     sl.obase = (row * K + k) * (int64_t)D;
     slots[threadIdx.x] = sl;
+    if (kReset && k == 0 && rr->root_state) {  // reset_state_kernel's root row
+      float* o = rr->root_state + rr->slots[r] * 13;
+      const float* og = rr->origins ? rr->origins + row * 3 : nullptr;
+      o[0] = og ? sl.rp[0] + og[0] : sl.rp[0];
+      o[1] = og ? sl.rp[1] + og[1] : sl.rp[1];
+      o[2] = (og ? sl.rp[2] + og[2] : sl.rp[2]) + rr->z_lift;
+      o[3] = q.w; o[4] = q.x; o[5] = q.y; o[6] = q.z;
+      for (int c = 7; c < 13; ++c) o[c] = lerp_ref(r0[c], r1[c], sl.blend);
+    }
   }
   __syncthreads();
   // ---- phase B: (sample, quad) items; both gathers of an item are 16-B loads --------------------------
@@ -181,6 +204,18 @@ __device__ __forceinline__ void collect_reference_body(const MotionView& v, cons
     for (int e = threadIdx.x; e < n_tile * D; e += kBlock) {
       const int s = e / D, j = e - s * D;
       out[slots[s].obase + j] = s_img[e];
+    }
+  }
+  if (kReset && (rr->dof_pos || rr->dof_vel)) {
+    // robot-order DoF rows of the reset state = columns [0, nd) / [nd, 2 nd) of the k = 0 frames of this tile
+    const int nd = v.n_dof;
+    for (int e = threadIdx.x; e < n_tile * nd2; e += kBlock) {
+      const int s = e / nd2, j = e - s * nd2;
+      const int64_t sidx = tile_base + s;
+      const int64_t r = sidx / K;
+      if (sidx - r * K != 0) continue;
+      float* dst = j < nd ? rr->dof_pos : rr->dof_vel;
+      if (dst) dst[rr->slots[r] * nd + (j < nd ? j : j - nd)] = s_img[s * D + j];
     }
   }
 }

@@ -73,6 +73,7 @@ class _AmpEnv(DirectRLEnv):
             env_offset = dist.get_rank() * int(cfg.scene.num_envs) if dist.is_available() and dist.is_initialized() else 0
         self.env_offset = int(env_offset)
         self._bound, self._reward_fresh, self._reset_args, self._tick_args = {}, False, None, None
+        self._pending_means, self._log_args = None, nat.AmpRewardLogArgs()
         super().__init__(cfg, render_mode, robot=robot, **kwargs)
         nat.require_gpu(self.device)
         data = self.robot.data
@@ -273,9 +274,14 @@ class _AmpEnv(DirectRLEnv):
         a.step, a.step_dev = self._step_args()
         if cmd is not None:
             cmd.seed, cmd.step, cmd.step_dev = a.seed, a.step, a.step_dev
+        lg, means = None, self._pending_means
+        if means is not None:
+            lg = self._log_args
+            lg.reward_terms, lg.n_terms, lg.means = k.reward_terms.data_ptr(), int(k.reward_terms.shape[0]), means.data_ptr()
+            self._pending_means = None
         with torch.cuda.device(self.device):
-            nat.check(fn(handle, C.byref(c), C.byref(a), C.byref(cmd) if cmd is not None else None, nat.stream_ptr()),
-                      "amp_reset_compact_apply")
+            nat.check(fn(handle, C.byref(c), C.byref(a), C.byref(cmd) if cmd is not None else None,
+                         C.byref(lg) if lg is not None else None, nat.stream_ptr()), "amp_reset_compact_apply")
         o = self._reset_out
         self.robot.write_reset_compact(k.reset_ids, k.reset_count, o["root_state"], o["dof_pos"], o["dof_vel"])
 
@@ -366,7 +372,12 @@ class G1AmpEnv(_AmpEnv):
             # the reference's 6-8 .mean().item() syncs (:291-305) become one reduction launch; the read-back happens
             # only when somebody looks at extras["log"] (LazyRewardLog), so step() itself never waits for the device
             drop = () if self.cfg.rew_track_vel > 0.0 else ("rew_track_vel", "error_track_vel")
-            log = LazyRewardLog(REWARD_TERMS, reward_log_means(self._kernel.reward_terms), drop)
+            if self.device_reset and self._in_step:
+                # inside step() the means ride on the reset launch that follows (amp_reset_compact_apply, one launch fewer)
+                means = self._pending_means = torch.empty(len(REWARD_TERMS), dtype=torch.float32, device=self.device)
+            else:
+                means = reward_log_means(self._kernel.reward_terms)
+            log = LazyRewardLog(REWARD_TERMS, means, drop)
             self.extras["log"] = log
             self._track_log(log)
         return self._kernel.reward

@@ -33,6 +33,7 @@ class DirectRLEnv:
         self.reset_buf = torch.zeros_like(self.reset_terminated)
         self.extras = {}
         self.common_step_counter = 0
+        self._in_step = False
         self._step_dev, self._graph = None, None  # device-side mirror of common_step_counter / captured step (capture_step)
         self._given_robot = robot
         self.scene = type("Scene", (), {})()
@@ -130,6 +131,7 @@ class DirectRLEnv:
         """Refresh per-step Python objects (``extras``) after a graph replay; tasks override."""
 
     def _step_eager(self, action: torch.Tensor):
+        self._in_step = True   # hooks may defer work to a later hook of the same step (the reward-log means ride on the reset launch)
         self._pre_physics_step(action)
         for _ in range(self.cfg.decimation):
             self._apply_action()
@@ -148,6 +150,7 @@ class DirectRLEnv:
             if len(reset_env_ids) > 0:
                 self._reset_idx(reset_env_ids)
         self.obs_buf = self._get_observations()
+        self._in_step = False
         return self.obs_buf, self.reward_buf, self.reset_terminated, self.reset_time_outs, self.extras
 
     def close(self):

@@ -351,7 +351,8 @@ class MotionLoader:
                             out: dict | None = None, env_motion_ids: torch.Tensor | None = None,
                             env_motion_start_times: torch.Tensor | None = None, env_offset: int = 0,
                             episode_length: torch.Tensor | None = None, last_actions: torch.Tensor | None = None,
-                            just_reset: torch.Tensor | None = None, command: "nat.AmpCommandArgs | None" = None) -> dict:
+                            just_reset: torch.Tensor | None = None, command: "nat.AmpCommandArgs | None" = None,
+                            reward_terms: torch.Tensor | None = None, reward_means: torch.Tensor | None = None) -> dict:
         """Reset-id compaction (``reset_mask`` + the per-tile counts of the DONES launch -> ``env_ids`` / ``count``, both
         written here) and :meth:`reset_apply` on them as ONE launch (``amp_reset_compact_apply``), plus the optional
         per-env clears (``episode_length[env] = 0``, ``last_actions[env] = 0``, ``just_reset[env] = True``) and the
@@ -386,9 +387,15 @@ class MotionLoader:
         if last_actions is not None:
             a.last_actions, a.n_actions = nat.dptr(last_actions, torch.float32, "last_actions").value, int(last_actions.shape[1])
         a.just_reset = nat.dptr(just_reset, None, "just_reset").value
+        lg = None
+        if reward_terms is not None:  # the step's reward-log means on the same launch -> reward_means [n_terms]
+            lg = nat.AmpRewardLogArgs()
+            lg.reward_terms, lg.n_terms = nat.dptr(reward_terms, torch.float32, "reward_terms").value, int(reward_terms.shape[0])
+            lg.means = nat.dptr(reward_means, torch.float32, "reward_means").value
         with torch.cuda.device(self._tdev):
             nat.check(self._lib.amp_reset_compact_apply(h, C.byref(c), C.byref(a), C.byref(command) if command is not None else None,
-                                                        nat.stream_ptr()), "amp_reset_compact_apply")
+                                                        C.byref(lg) if lg is not None else None, nat.stream_ptr()),
+                      "amp_reset_compact_apply")
         return out
 
     def reset_reference_state(self, times, motion_ids, env_ids=None, env_origins: torch.Tensor | None = None,

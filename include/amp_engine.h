@@ -347,10 +347,18 @@ int amp_scatter_rows(const AmpScatterRows* ops, int32_t n_ops, const int64_t* id
 /* amp_reset_compact_tiles + amp_reset_apply (+ the reset-side amp_command_step(AMP_COMMAND_RESET) when command != NULL) as
  * ONE launch: what DirectRLEnv.step does between _get_rewards and _get_observations (reset_buf.nonzero() -> _reset_idx,
  * g1_amp_env.py:332-441) with no host round trip and a single kernel.  args->env_ids / args->count must be compact->ids /
- * compact->count (they are written by this call), args->max_n >= compact->num_envs.  Results are bit-identical to the
- * separate calls. */
+ * compact->count (they are written by this call), args->max_n >= compact->num_envs; args->amp_obs_buffer is required.
+ * Results are bit-identical to the separate calls. */
+/* log != NULL: the step's reward-log means (amp_reward_log_means of log->reward_terms [n_terms, num_envs] -> log->means
+ * [n_terms]) ride on the same launch, one extra workgroup per term: one launch fewer per env step. */
+typedef struct {
+  const float* reward_terms;   /* dev [n_terms, num_envs] (AmpEnvBuffers.reward_terms) */
+  int32_t n_terms;
+  int32_t reserved;
+  float* means;                /* dev [n_terms] out */
+} AmpRewardLogArgs;
 int amp_reset_compact_apply(const AmpMotion* h, const AmpCompactArgs* compact, const AmpResetArgs* args,
-                            const AmpCommandArgs* command, amp_stream_t stream);
+                            const AmpCommandArgs* command, const AmpRewardLogArgs* log, amp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Discriminator style reward  (replaces the inference half of skrl's AMP agent: amp_state_preprocessor

@@ -95,6 +95,8 @@ def test_reset_compact_apply_equals_the_separate_launches(clips, K, N, tile, den
     # one launch
     b = {k: v.clone() for k, v in state0.items()}
     ids_b, count_b = torch.full((N,), -7, dtype=torch.int64, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda")
+    terms = torch.randn(8, N, generator=gen).cuda() * torch.arange(1, 9, device="cuda")[:, None]
+    means_b = torch.zeros(8, device="cuda")
     ca = nat.AmpCommandArgs()
     ca.command, ca.time_left = b["cmd"].data_ptr(), b["left"].data_ptr()
     ca.step_dt, ca.vel_lo, ca.vel_span, ca.t_lo, ca.t_span = 1 / 30, vel[0], vel[1] - vel[0], tr[0], tr[1] - tr[0]
@@ -102,7 +104,10 @@ def test_reset_compact_apply_equals_the_separate_launches(clips, K, N, tile, den
     out_b = ml.reset_compact_apply(mask, counts, tile, ids_b, count_b, K, seed=seed, step=step, start=False, env_origins=origins,
                                    z_lift=0.05, amp_observation_buffer=b["buf"], env_motion_ids=b["m_ids"],
                                    env_motion_start_times=b["m_t"], env_offset=off, episode_length=b["ep"], last_actions=b["la"],
-                                   just_reset=b["jr"], command=ca)
+                                   just_reset=b["jr"], command=ca, reward_terms=terms, reward_means=means_b)
+    from humanoid_amp_amd.engine import reward_log_means
+    assert float((means_b.double() - terms.double().mean(dim=1)).abs().max()) <= 1e-6
+    assert float((means_b - reward_log_means(terms)).abs().max()) <= 1e-7
     n = int(count_a)
     assert int(count_b) == n == int(mask.sum()) and torch.equal(ids_a[:n], ids_b[:n])
     for k in a:

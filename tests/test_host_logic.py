@@ -21,7 +21,7 @@ def test_resolver_mini_language(tmp_path):
     assert res(a) == [a]
     assert res(f"{a}, {b}") == [a, b]
     assert res(os.path.join(gu.MOTIONS, "humanoid_*.npz")) == sorted(gu.clip_files("humanoid3"))
-    assert len(res(gu.MOTIONS)) == 5  # directory -> every npz, sorted
+    assert len(res(gu.MOTIONS)) == 6  # directory -> every npz, sorted (five BASELINE clips + custom_motion.npz)
     cfg = tmp_path / "m.yaml"
     cfg.write_text(yaml.safe_dump({"motion_files": [a, "missing.npz"]}))
     assert res(str(cfg)) == [a]
@@ -183,7 +183,7 @@ def test_shipped_clips_pass_the_surveys_self_checks():
 
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "humanoid_amp_amd", "motions")
     want = {"G1_walk.npz": (399, 29, 11), "G1_dance.npz": (601, 29, 39), "humanoid_dance.npz": (902, 28, 15),
-            "humanoid_run.npz": (82, 28, 15), "humanoid_walk.npz": (154, 28, 15)}
+            "humanoid_run.npz": (82, 28, 15), "humanoid_walk.npz": (154, 28, 15), "custom_motion.npz": (309, 29, 25)}
     seen = {}
     for path in sorted(glob.glob(os.path.join(root, "*.npz"))):
         d = np.load(path, allow_pickle=False)
