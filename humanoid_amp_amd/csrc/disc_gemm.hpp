@@ -237,4 +237,121 @@ __global__ __launch_bounds__(kBlock, MINW_) void disc_gemm_kernel(GemmArgs g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// "TT" product for the training step's weight gradients:  C[m][n] (+)= sum_k A[k][m] * W[k][n]  -- both operands with the
+// REDUCTION index as their row (the batch: dW = dY^T X with dY [rows, m], X [rows, n] exactly as the forward / backward
+// kernels leave them).  The NT kernel above needs both operands k-contiguous, which cost the step eight explicit
+// transposes (dH2^T, H1^T, dH1^T, Xs^T, a1^T, dg^T, a2^T, e1^T: 10 launches, ~94 us and ~400 MB of traffic per step).
+// Here a k-tile is BK_ rows of BM_ / BN_ contiguous floats (fully coalesced loads, stored to LDS as they come); the MFMA's
+// A / B operand of lane (li, lh) at step s is the single float [2 s + lh][row0 + li]: 32 consecutive floats per lane half,
+// conflict-free 4-B LDS reads, one per MFMA.  Rows k >= g.K read as zero (ragged batch).  g.Kp is W's row pitch here.
+// Split-K and the epilogue as MODE 2 (no mask).
+template <int BM_, int BN_, int BK_, int MINW_>
+__global__ __launch_bounds__(kBlock, MINW_) void disc_gemm_tt_kernel(GemmArgs g) {
+  constexpr int TM = BM_ / 64, TN = BN_ / 64, LDA = BM_ + 4, LDB = BN_ + 4;
+  constexpr int STAGE_F = BK_ * (LDA + LDB);
+  constexpr int EP_F = 4 * 32 * (TN * 32 + 4);
+  constexpr int SMEM_F = STAGE_F > EP_F ? STAGE_F : EP_F;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_F];
+  int mt, nt, slice = 0;
+  if (!tile_of_block(g, mt, nt, &slice)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int64_t m0 = (int64_t)mt * BM_;
+  const int n0 = nt * BN_;
+  const int nk_all = (g.K + BK_ - 1) / BK_;
+  const int per_slice = g.k_slices > 1 ? (nk_all + g.k_slices - 1) / g.k_slices : nk_all;
+  const int k0 = slice * per_slice;
+  const int nk = k0 + per_slice < nk_all ? k0 + per_slice : nk_all;
+  if (g.k_slices > 1) g.C += (int64_t)slice * g.slice_stride;
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  constexpr int QA = BM_ / 4, QB = BN_ / 4, RA = kBlock / QA, RB = kBlock / QB;  // 16-B pieces per row, rows per pass
+  constexpr int NA = BK_ / RA, NB = BK_ / RB;
+  static_assert(BK_ % RA == 0 && BK_ % RB == 0, "the k-tile is a whole number of load passes");
+  f4 ra[NA], rb[NB];
+  float* const As = smem;
+  float* const Bs = smem + BK_ * LDA;
+  auto load = [&](const int kt) {
+    const f4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int64_t k = (int64_t)kt * BK_ + tid / QA + RA * i;
+      ra[i] = k < g.K ? *reinterpret_cast<const f4*>(g.A + k * g.lda + m0 + 4 * (tid % QA)) : zero;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int64_t k = (int64_t)kt * BK_ + tid / QB + RB * i;
+      rb[i] = k < g.K ? *reinterpret_cast<const f4*>(g.W + k * (int64_t)g.Kp + n0 + 4 * (tid % QB)) : zero;
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) *reinterpret_cast<f4*>(&As[(tid / QA + RA * i) * LDA + 4 * (tid % QA)]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<f4*>(&Bs[(tid / QB + RB * i) * LDB + 4 * (tid % QB)]) = rb[i];
+  };
+  const int arow = wm * (TM * 32) + li, brow = wn * (TN * 32) + li;
+  if (k0 < nk) {
+    load(k0);
+    store();
+  }
+  __syncthreads();
+  for (int kt = k0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load(kt + 1);  // in flight under this tile's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s2 = 0; s2 < BK_ / 2; ++s2) {
+      float x[TM], y[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) x[a] = As[(2 * s2 + lh) * LDA + arow + a * 32];
+#pragma unroll
+      for (int b = 0; b < TN; ++b) y[b] = Bs[(2 * s2 + lh) * LDB + brow + b * 32];
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[a], y[b], acc[a][b], 0, 0, 0);
+    }
+    lds_barrier();
+    if (kt + 1 < nk) {
+      store();
+      lds_barrier();
+    }
+  }
+  __syncthreads();
+  // epilogue as MODE 2 (no mask): C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  constexpr int W = TN * 32, EPL = W + 4, QPR = W / 4;
+  float* ep = smem + wave * (32 * EPL);
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+      for (int b = 0; b < TN; ++b) ep[row * EPL + b * 32 + li] = acc[a][b][r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < (32 * QPR) / 64; ++i) {
+      const int idx = lane + 64 * i, row = idx / QPR, q = idx % QPR;
+      f4 v = *reinterpret_cast<const f4*>(&ep[row * EPL + 4 * q]);
+      const int64_t grow = m0 + wm * (TM * 32) + a * 32 + row;
+      if (grow < g.M) {
+        const int col = n0 + wn * W + 4 * q;
+        if (g.accumulate) v += *reinterpret_cast<const f4*>(&g.C[grow * g.ldc + col]);
+        *reinterpret_cast<f4*>(&g.C[grow * g.ldc + col]) = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace amp

@@ -162,6 +162,61 @@ __global__ __launch_bounds__(kBlock) void dh2_kernel(const float* __restrict__ d
   dH2[e] = H2[e] > 0.0f ? dlogit[i] * w3[n] : 0.0f;
 }
 
+// dh2_kernel + colsum(H2 * dlogit) + colsum(dH2) + colsum(dlogit) in ONE pass over H2 (they were seven launches reading H2 /
+// dH2 three times).  Grid, row striding and the combination of the four row-lane partials are colsum_part_kernel's, so every
+// sum is bit-identical to the separate launches:
+//   dH2[i][c] = H2[i][c] > 0 ? dlogit[i] * w3[c] : 0
+//   part[0][ch][c] = sum_i H2[i][c] * dlogit[i]   (-> gw3)      part[1][ch][c] = sum_i dH2[i][c]   (-> gb2)
+//   part[2][ch][0] = sum_i dlogit[i]              (-> gb3; column block 0 only)
+__global__ __launch_bounds__(kBlock) void dh2_colsum_kernel(const float* __restrict__ dlogit, const float* __restrict__ w3,
+                                                            const float* __restrict__ H2, int64_t rows, int cols,
+                                                            float* __restrict__ dH2, float* __restrict__ part) {
+  __shared__ float red[3][4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), p = threadIdx.x >> 6;
+  const int64_t per = (rows + kChunks - 1) / kChunks;
+  const int64_t lo = (int64_t)blockIdx.y * per, hi = lo + per < rows ? lo + per : rows;
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+  const float w = c < cols ? w3[c] : 0.0f;
+  if (c < cols)
+    for (int64_t i = lo + p; i < hi; i += 4) {
+      const float h = H2[i * cols + c], dl = dlogit[i];
+      float v = h;
+      v *= dl;                                    // colsum_part_kernel's "A * rowscale"
+      s0 += v;
+      const float d = h > 0.0f ? dl * w : 0.0f;   // dh2_kernel
+      dH2[i * cols + c] = d;
+      s1 += d;
+      if (c == 0) s2 += dl;
+    }
+  red[0][p][threadIdx.x & 63] = s0;
+  red[1][p][threadIdx.x & 63] = s1;
+  red[2][p][threadIdx.x & 63] = s2;
+  __syncthreads();
+  if (p == 0 && c < cols) {
+    const int l = threadIdx.x;
+    const int64_t plane = (int64_t)kChunks * cols;
+    part[0 * plane + (int64_t)blockIdx.y * cols + c] = (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]);
+    part[1 * plane + (int64_t)blockIdx.y * cols + c] = (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
+    if (c == 0) part[2 * plane + blockIdx.y] = (red[2][0][l] + red[2][1][l]) + (red[2][2][l] + red[2][3][l]);
+  }
+}
+__global__ __launch_bounds__(kBlock) void dh2_colsum_final_kernel(const float* __restrict__ part, int cols, float* __restrict__ gw3,
+                                                                  float* __restrict__ gb2, float* __restrict__ gb3) {
+  const int c = blockIdx.x * kBlock + threadIdx.x;
+  const int64_t plane = (int64_t)kChunks * cols;
+  if (c < cols) {
+    float a = 0.0f, b = 0.0f;
+    for (int ch = 0; ch < kChunks; ++ch) { a += part[(int64_t)ch * cols + c]; b += part[plane + (int64_t)ch * cols + c]; }
+    gw3[c] = a;
+    gb2[c] = b;
+  }
+  if (c == 0) {
+    float s = 0.0f;
+    for (int ch = 0; ch < kChunks; ++ch) s += part[2 * plane + ch];
+    gb3[0] = s;
+  }
+}
+
 // a2[i][n] = w3[n] * (H2m[i][n] > 0)
 __global__ __launch_bounds__(kBlock) void a2_kernel(const float* __restrict__ w3, const float* __restrict__ H2, int64_t rows, int cols,
                                                     float* __restrict__ a2) {
@@ -337,6 +392,94 @@ __global__ __launch_bounds__(kBlock) void scaler_merge_kernel(const double* __re
     mean32[c] = (float)mean_new;
     den32[c] = sqrtf((float)var_new) + eps;
   }
+}
+
+// The three batches (policy, replay, motion) of a step in ONE launch per stage (they were 3 x (partials, merge, scale)):
+//   scaler_part3_kernel   blockIdx.z = batch: scaler_part_kernel's sums into part + z * stride
+//   scaler_merge3_kernel  a column merges the three batches IN ORDER (each batch updates the running statistics and is then
+//                         scaled with them, skrl's order) and keeps the fp32 vectors of every intermediate state
+//   scale_rows3_kernel    blockIdx.y = batch: scaled with that batch's vectors
+// Same arithmetic per column, in the same order, as the nine launches.
+struct Batch3 {
+  const float* x[3];
+};
+__global__ __launch_bounds__(kBlock) void scaler_part3_kernel(Batch3 b, int64_t rows, int cols, int64_t ld, double* __restrict__ part,
+                                                              int64_t part_stride) {
+  __shared__ double red[2][4][64];
+  const float* __restrict__ x = b.x[blockIdx.z];
+  part += (int64_t)blockIdx.z * part_stride;
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), p = threadIdx.x >> 6;
+  const int64_t per = (rows + kChunks - 1) / kChunks;
+  const int64_t lo = (int64_t)blockIdx.y * per, hi = lo + per < rows ? lo + per : rows;
+  double s = 0.0, q = 0.0;
+  if (c < cols)
+    for (int64_t i = lo + p; i < hi; i += 4) {
+      const double v = (double)x[i * ld + c];
+      s += v;
+      q += v * v;
+    }
+  red[0][p][threadIdx.x & 63] = s;
+  red[1][p][threadIdx.x & 63] = q;
+  __syncthreads();
+  if (p == 0 && c < cols) {
+    const int l = threadIdx.x;
+    part[((int64_t)blockIdx.y * cols + c) * 2 + 0] = (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]);
+    part[((int64_t)blockIdx.y * cols + c) * 2 + 1] = (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
+  }
+}
+__global__ __launch_bounds__(kBlock) void scaler_merge3_kernel(const double* __restrict__ part, int64_t part_stride, int64_t rows,
+                                                               int cols, double* __restrict__ mean, double* __restrict__ var,
+                                                               const TrainState* __restrict__ state, int np, float eps,
+                                                               float* __restrict__ mean32, float* __restrict__ den32, int vec_stride) {
+  const int c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= cols) {
+    if (mean32 && c < np)
+      for (int g = 0; g < 3; ++g) { mean32[g * vec_stride + c] = 0.0f; den32[g * vec_stride + c] = 1.0f; }
+    return;
+  }
+  double m = mean[c], v = var[c];
+  const double n = (double)rows;
+  for (int g = 0; g < 3; ++g) {
+    const double count = state->count + (double)g * n;
+    const double* pg = part + (int64_t)g * part_stride;
+    double s = 0.0, q = 0.0;
+    for (int ch = 0; ch < kChunks; ++ch) {
+      s += pg[((int64_t)ch * cols + c) * 2 + 0];
+      q += pg[((int64_t)ch * cols + c) * 2 + 1];
+    }
+    const double bm = s / n;
+    const double bv = (q - n * bm * bm) / (n - 1.0);
+    const double total = count + n, delta = bm - m;
+    const double m2 = v * count + bv * n + delta * delta * count * n / total;
+    m = m + delta * n / total;
+    v = m2 / total;
+    if (mean32) {
+      mean32[g * vec_stride + c] = (float)m;
+      den32[g * vec_stride + c] = sqrtf((float)v) + eps;
+    }
+  }
+  mean[c] = m;
+  var[c] = v;
+}
+// xs rows have a pitch of `pitch` floats (zero beyond k): batch z scaled with (mean + z * vec_stride, den + z * vec_stride)
+__global__ __launch_bounds__(kBlock) void scale_rows3_kernel(Batch3 b, int64_t row_stride, int64_t rows, int k, int pitch,
+                                                             const float* __restrict__ mean, const float* __restrict__ den,
+                                                             int vec_stride, float clip, float* __restrict__ xs) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= rows * pitch) return;
+  const int z = blockIdx.y;
+  const float* __restrict__ x = b.x[z];
+  const int64_t m = e / pitch;
+  const int c = (int)(e - m * pitch);
+  float v = 0.0f;
+  if (c < k) {
+    v = x[m * row_stride + c];
+    if (mean) {
+      v = (v - mean[z * vec_stride + c]) / den[z * vec_stride + c];
+      v = fminf(fmaxf(v, -clip), clip);
+    }
+  }
+  xs[(int64_t)z * rows * pitch + e] = v;
 }
 
 __global__ void scaler_to_f32_kernel(const double* __restrict__ mean64, const double* __restrict__ var64, int n, int np, float eps,
@@ -523,6 +666,38 @@ int gemm_nt(hipStream_t st, const float* A, int64_t lda, int64_t M, const float*
   return launch_status("sum_slices_kernel");
 }
 
+// C[M, N] (ld = ldc) (+)= A^T W with A [K, M] (row pitch lda) and W [K, N] (row pitch ldw): the weight-gradient products
+// dW = dY^T X straight on the row-major batch tensors (disc_gemm_tt_kernel: no transposed copies).  M and N are multiples
+// of 64, the row pitches multiples of 4; split-K as gemm_nt.
+int gemm_tt(hipStream_t st, const float* A, int64_t lda, int M, const float* W, int64_t ldw, int N, int64_t K, float* C, int64_t ldc,
+            int accumulate, float* split) {
+  if (M % 64 != 0 || N % 64 != 0 || lda % 4 != 0 || ldw % 4 != 0 || K > INT32_MAX) return kShapeNotSupported;
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.M = M; g.K = (int32_t)K; g.W = W; g.Kp = (int32_t)ldw; g.N = N; g.C = C; g.ldc = ldc;
+  g.accumulate = accumulate;
+  // 64 x 64 tiles (wave tile 32 x 32).  128 x 128 / 128 x 64 tiles (one LDS read per MFMA instead of two) were measured SLOWER at
+  // 3 x 4096 rows (0.909 vs 0.873 ms per step: with 16 k-slices there are too few of them for 256 CUs) and are not instantiated.
+  g.n_tiles = N / 64; g.m_tiles = M / 64;
+  const int tiles = g.m_tiles * g.n_tiles, nk = (int)((K + 15) / 16);
+  int slices = 1;
+  if (split) {
+    while (slices < 16 && tiles * slices < 1024 && nk / (slices * 2) >= 16) slices *= 2;
+  }
+  if (slices > 1) {
+    g.k_slices = slices; g.slice_stride = (int64_t)M * ldc; g.C = split; g.accumulate = 0;
+  }
+  const unsigned grid = (unsigned)(((int64_t)tiles * slices + 7) / 8 * 8);
+  {
+    amp::TraceScope trace__("disc_gemm_tt_kernel", st);
+    disc_gemm_tt_kernel<64, 64, 16, 4><<<grid, kBlock, 0, st>>>(g);
+  }
+  int rc = launch_status("disc_gemm_tt_kernel");
+  if (rc != AMP_OK || slices == 1) return rc;
+  const int64_t n = (int64_t)M * ldc;
+  sum_slices_kernel<<<(unsigned)((n + kBlock - 1) / kBlock), kBlock, 0, st>>>(split, slices, n, n, C, accumulate);
+  return launch_status("sum_slices_kernel");
+}
+
 int gemm_fwd(hipStream_t st, const float* A, int64_t lda, int64_t M, const float* W, int Kp, int N, const float* bias, float* C) {
   GemmArgs g{};
   g.A = A; g.lda = lda; g.M = M; g.K = Kp; g.W = W; g.Kp = Kp; g.bias = bias; g.N = N; g.C = C; g.ldc = N;
@@ -606,8 +781,8 @@ int amp_disc_trainer_create(AmpDisc* disc, const AmpDiscTrainCfg* cfg, const dou
                     B * p.h2 + B * p.h1 + B * t->kN + B * p.h1 + B * p.h2 +                        // a2 a1 g e1 da2
                     (int64_t)p.h1 * Bp + (int64_t)t->kN * Bp + (int64_t)p.h2 * Bp + (int64_t)p.h1 * Bp +  // a1T dgT a2T e1T
                     (int64_t)p.h1 * t->kN + p.h1 + (int64_t)p.h2 * p.h1 + p.h2 + p.h2 + 1 + 64;    // grads + loss
-  t->ws_floats = f + (int64_t)16 * p.h2 * p.h1 + (int64_t)kChunks * 1024 + 1024 + (int64_t)kChunks * p.in_dim * 4 + 16 + 16 * 40 +
-                 2 * up(p.k1p, 16);
+  t->ws_floats = f + (int64_t)16 * p.h2 * p.h1 + (int64_t)kChunks * 1024 + 1024 + 3 * (up((int64_t)kChunks * p.in_dim * 2, 8) * 2) + 16 +
+                 16 * 40 + 6 * up(p.k1p, 16) + M * (t->kN - p.k1p) + 2 * (int64_t)kChunks * 1024;
   if (e == hipSuccess) e = hipMalloc(&t->ws, sizeof(float) * t->ws_floats);
   if (e == hipSuccess && !cfg->gemm_fp32) {
     // fp16-split GEMM path: planes of the largest operand ([3B (padded), max(h1, h2)] or its transpose), twice
@@ -665,7 +840,7 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
   // ---- workspace carve-up (every region 16-float aligned) ------------------------------------------------------
   float* w = t->ws;
   auto take = [&](int64_t n) { float* r = w; w += up(n, 16); return r; };
-  float* Xs = take(M * k1p);
+  float* Xs = take(M * kN);      // row pitch kN (zero beyond in_dim): the TT product dH1^T Xs reads whole 64-column tiles
   float* H1 = take(M * H1n);
   float* H2 = take(M * H2n);
   float* logit = take(M);
@@ -693,10 +868,12 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
   float* gb3 = take(1);
   float* loss = take(16);  // [0] prediction, [1] gradient penalty, [2] logit reg, [3] weight decay
   float* split = take((int64_t)16 * H2n * H1n);                  // split-K partial products (largest: gW2)
-  float* part = take((int64_t)kChunks * 1024 + 1024);          // column-sum / scalar partials
-  double* dpart = reinterpret_cast<double*>(take((int64_t)kChunks * p.in_dim * 4 + 16));
-  float* mean32w = take(k1p);  // the running statistics as the scaling pass reads them (refreshed per group)
-  float* den32w = take(k1p);
+  float* part = take((int64_t)3 * kChunks * 1024 + 1024);      // column-sum / scalar partials (three planes: dh2_colsum_kernel)
+  const int64_t dpart_stride = up((int64_t)kChunks * p.in_dim * 2, 8);                 // doubles per batch
+  double* dpart = reinterpret_cast<double*>(take(3 * dpart_stride * 2 + 16));
+  const int vec_stride = (int)up(k1p, 16);
+  float* mean32w = take(3 * vec_stride);  // the running statistics after each batch, as the scaling pass reads them
+  float* den32w = take(3 * vec_stride);
   AMP_REQUIRE(w - t->ws <= t->ws_floats, "amp_disc_train_step: internal workspace overflow");
   AMP_REQUIRE(H1n <= 1024 && H2n <= 1024, "amp_disc_train_step: hidden sizes above 1024 are not supported");
   auto colsum = [&](const float* A, int64_t rows_, int cols_, int64_t lda_, const float* rowscale, const float* mask, int64_t ldm,
@@ -734,7 +911,6 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
   const float* mean32 = nullptr;
   const float* den32 = nullptr;
   float clip = 0.0f;
-  const float* groups[3] = {policy, replay, motion};
   if (c.use_scaler && !c.update_scaler) {
     // frozen statistics: the fp32 vectors already live in the discriminator handle
     rc = amp_disc_set_scaler(t->disc, t->mean64, t->var64, c.scaler_epsilon, c.scaler_clip, stream);
@@ -743,29 +919,30 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
     amp_disc_input_layout(t->disc, &lay);
     mean32 = lay.mean_dev; den32 = lay.den_dev; clip = lay.clip;
   }
-  for (int gi = 0; gi < 3; ++gi) {
+  {
+    const Batch3 b3{{policy, replay, motion}};
+    int vstride = 0;  // frozen / no statistics: one vector pair for the three batches
     if (c.update_scaler) {
-      // each batch updates the running statistics, then is scaled with them (skrl order); the merge also writes the fp32
-      // vectors the scaling pass reads
-      scaler_part_kernel<<<dim3((p.in_dim + 63) / 64, kChunks), kBlock, 0, st>>>(groups[gi], B, p.in_dim, row_stride, dpart);
-      scaler_merge_kernel<<<(k1p + kBlock - 1) / kBlock, kBlock, 0, st>>>(dpart, B, p.in_dim, t->mean64, t->var64, t->state,
-                                                                         (double)gi * (double)B, k1p, c.scaler_epsilon,
-                                                                         c.use_scaler ? mean32w : nullptr, den32w);
-      if (c.use_scaler) { mean32 = mean32w; den32 = den32w; clip = c.scaler_clip; }
+      // each batch updates the running statistics, then is scaled with them (skrl order): partial sums of the three batches,
+      // one in-order merge that also writes the fp32 vectors of every intermediate state, one scaling pass
+      scaler_part3_kernel<<<dim3((p.in_dim + 63) / 64, kChunks, 3), kBlock, 0, st>>>(b3, B, p.in_dim, row_stride, dpart, dpart_stride);
+      scaler_merge3_kernel<<<(k1p + kBlock - 1) / kBlock, kBlock, 0, st>>>(dpart, dpart_stride, B, p.in_dim, t->mean64, t->var64, t->state,
+                                                                          k1p, c.scaler_epsilon, c.use_scaler ? mean32w : nullptr,
+                                                                          den32w, vec_stride);
+      if (c.use_scaler) { mean32 = mean32w; den32 = den32w; clip = c.scaler_clip; vstride = vec_stride; }
     }
-    scale_rows_kernel<<<blocks(B * k1p), kBlock, 0, st>>>(groups[gi], row_stride, B, p.in_dim, k1p, mean32, den32, clip,
-                                                         Xs + gi * B * k1p);
+    scale_rows3_kernel<<<dim3(blocks(B * kN), 3), kBlock, 0, st>>>(b3, row_stride, B, p.in_dim, kN, mean32, den32, vstride, clip, Xs);
   }
   if (c.use_scaler && c.update_scaler) {
     // the discriminator handle serves inference with the statistics after the third batch
     rc = amp_disc_set_scaler(t->disc, t->mean64, t->var64, c.scaler_epsilon, c.scaler_clip, stream);
     if (rc != AMP_OK) return rc;
   }
-  rc = launch_status("scale_rows_kernel");
+  rc = launch_status("scale_rows3_kernel");
   if (rc != AMP_OK) return rc;
 
   // ---- 2. forward, keeping H1 / H2 -----------------------------------------------------------------------------
-  rc = gemm_fwd(st, Xs, k1p, M, p.w1p, k1p, H1n, p.b1, H1);
+  rc = gemm_fwd(st, Xs, kN, M, p.w1p, k1p, H1n, p.b1, H1);
   if (rc != AMP_OK) return rc;
   rc = gemm_fwd(st, H1, H1n, M, p.w2, H1n, H2n, p.b2, H2);
   if (rc != AMP_OK) return rc;
@@ -773,22 +950,31 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
   bce_kernel<<<1, 1024, 0, st>>>(logit, 2 * B, B, c.loss_scale, dlogit, loss);
 
   // ---- 3. backward of the prediction loss ----------------------------------------------------------------------
-  colsum(H2, M, H2n, H2n, dlogit, nullptr, 0, gw3, 0);   // gw3 = H2^T dlogit
-  colsum(dlogit, M, 1, 1, nullptr, nullptr, 0, gb3, 0);
-  dh2_kernel<<<blocks(M * H2n), kBlock, 0, st>>>(dlogit, p.w3, H2, M, H2n, dH2);
-  colsum(dH2, M, H2n, H2n, nullptr, nullptr, 0, gb2, 0);
+  // dH2 = dlogit (x) w3 * (H2 > 0), gw3 = H2^T dlogit, gb2 = colsum(dH2), gb3 = sum(dlogit): one pass over H2
+  dh2_colsum_kernel<<<dim3((H2n + 63) / 64, kChunks), kBlock, 0, st>>>(dlogit, p.w3, H2, M, H2n, dH2, part);
+  dh2_colsum_final_kernel<<<(H2n + kBlock - 1) / kBlock, kBlock, 0, st>>>(part, H2n, gw3, gb2, gb3);
   transpose(st, p.w2, H2n, H1n, H1n, t->w2t, H2n, H1n);               // W2^T [h1, h2]
   transpose(st, p.w1p, H1n, k1p, k1p, t->w1t, H1n, kN);               // W1^T [kN, h1] (zero rows >= k1p)
   rc = nt(dH2, H2n, M, t->w2t, H2n, H1n, dH1, H1n, H1, H1n, 0);   // dH1 = (dH2 W2) * (H1 > 0)
   if (rc != AMP_OK) return rc;
   colsum(dH1, M, H1n, H1n, nullptr, nullptr, 0, gb1, 0);
-  transpose(st, dH2, M, H2n, H2n, dH2T, Mp, H2n);
-  transpose(st, H1, M, H1n, H1n, H1T, Mp, H1n);
-  rc = nt(dH2T, Mp, H2n, H1T, (int)Mp, H1n, gW2, H1n, nullptr, 0, 0, split);   // gW2 = dH2^T H1
+  // the weight gradients reduce over the batch: the TT kernel takes both operands as the kernels above left them (rows = batch)
+  // (the fp16-split option keeps its transposed-copy route: its kernel is k-contiguous by construction)
+  auto tt = [&](const float* A, int64_t lda, int Mo, const float* W, int64_t ldw, int No, int64_t Kr, float* C, int64_t ldc,
+                int acc) -> int { return f16 ? kShapeNotSupported : gemm_tt(st, A, lda, Mo, W, ldw, No, Kr, C, ldc, acc, split); };
+  rc = tt(dH2, H2n, H2n, H1, H1n, H1n, M, gW2, H1n, 0);       // gW2 = dH2^T H1
+  if (rc == kShapeNotSupported) {
+    transpose(st, dH2, M, H2n, H2n, dH2T, Mp, H2n);
+    transpose(st, H1, M, H1n, H1n, H1T, Mp, H1n);
+    rc = nt(dH2T, Mp, H2n, H1T, (int)Mp, H1n, gW2, H1n, nullptr, 0, 0, split);
+  }
   if (rc != AMP_OK) return rc;
-  transpose(st, dH1, M, H1n, H1n, dH1T, Mp, H1n);
-  transpose(st, Xs, M, k1p, k1p, XsT, Mp, kN);
-  rc = nt(dH1T, Mp, H1n, XsT, (int)Mp, kN, gW1, kN, nullptr, 0, 0, split);     // gW1 = dH1^T Xs
+  rc = tt(dH1, H1n, H1n, Xs, kN, kN, M, gW1, kN, 0);          // gW1 = dH1^T Xs
+  if (rc == kShapeNotSupported) {
+    transpose(st, dH1, M, H1n, H1n, dH1T, Mp, H1n);
+    transpose(st, Xs, M, k1p, kN, XsT, Mp, kN);
+    rc = nt(dH1T, Mp, H1n, XsT, (int)Mp, kN, gW1, kN, nullptr, 0, 0, split);
+  }
   if (rc != AMP_OK) return rc;
 
   // ---- 4. gradient penalty on the motion rows ------------------------------------------------------------------
@@ -802,15 +988,21 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
     if (rc != AMP_OK) return rc;
     // loss[1] = gp_scale * mean_rows |g|^2 ;  g <- dL/dg = (2 gp_scale loss_scale / B) g
     sumsq(g, B, p.in_dim, kN, 2.0f * c.grad_penalty_scale * c.loss_scale / (float)B, 1, c.grad_penalty_scale / (float)B, 1, 0);
-    transpose(st, a1, B, H1n, H1n, a1T, Bp, H1n);
-    transpose(st, g, B, kN, kN, dgT, Bp, kN);
-    rc = nt(a1T, Bp, H1n, dgT, (int)Bp, kN, gW1, kN, nullptr, 0, 1, split);    // gW1 += a1^T dg
+    rc = tt(a1, H1n, H1n, g, kN, kN, B, gW1, kN, 1);        // gW1 += a1^T dg
+    if (rc == kShapeNotSupported) {
+      transpose(st, a1, B, H1n, H1n, a1T, Bp, H1n);
+      transpose(st, g, B, kN, kN, dgT, Bp, kN);
+      rc = nt(a1T, Bp, H1n, dgT, (int)Bp, kN, gW1, kN, nullptr, 0, 1, split);
+    }
     if (rc != AMP_OK) return rc;
     rc = nt(g, kN, B, p.w1p, k1p, H1n, e1, H1n, H1m, H1n, 0);           // e1 = (dg W1^T) * m1   (K = k1p <= kN)
     if (rc != AMP_OK) return rc;
-    transpose(st, a2, B, H2n, H2n, a2T, Bp, H2n);
-    transpose(st, e1, B, H1n, H1n, e1T, Bp, H1n);
-    rc = nt(a2T, Bp, H2n, e1T, (int)Bp, H1n, gW2, H1n, nullptr, 0, 1, split);  // gW2 += a2^T e1
+    rc = tt(a2, H2n, H2n, e1, H1n, H1n, B, gW2, H1n, 1);    // gW2 += a2^T e1
+    if (rc == kShapeNotSupported) {
+      transpose(st, a2, B, H2n, H2n, a2T, Bp, H2n);
+      transpose(st, e1, B, H1n, H1n, e1T, Bp, H1n);
+      rc = nt(a2T, Bp, H2n, e1T, (int)Bp, H1n, gW2, H1n, nullptr, 0, 1, split);
+    }
     if (rc != AMP_OK) return rc;
     rc = nt(e1, H1n, B, p.w2, H1n, H2n, da2, H2n, nullptr, 0, 0);       // da2 = e1 W2^T
     if (rc != AMP_OK) return rc;

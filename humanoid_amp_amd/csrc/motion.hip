@@ -126,7 +126,6 @@ __global__ __launch_bounds__(kBlock) void sample_kernel(MotionView v, const doub
     for (int a = 0; a < 6; ++a) { img[a] = o; o += T * row[a]; }
   }
   const int total = T * sample_out_floats(nd, B);
-  float* const s_trash = smem + total;
   SampleSlot* const slots = reinterpret_cast<SampleSlot*>(smem + total + 4);
   const int64_t tile_base = (int64_t)blockIdx.x * T;
   const int n_tile = (int)((n - tile_base) < T ? (n - tile_base) : T);
