@@ -85,7 +85,7 @@ class AmpDiscTrainCfg(C.Structure):
         ("max_rows_per_group", C.c_int64), ("learning_rate", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
         ("adam_epsilon", C.c_float), ("loss_scale", C.c_float), ("logit_reg_scale", C.c_float), ("grad_penalty_scale", C.c_float),
         ("weight_decay_scale", C.c_float), ("scaler_epsilon", C.c_float), ("scaler_clip", C.c_float), ("use_scaler", C.c_int32),
-        ("update_scaler", C.c_int32), ("apply_update", C.c_int32), ("gemm_fp32", C.c_int32),
+        ("update_scaler", C.c_int32), ("apply_update", C.c_int32), ("gemm_f16x3", C.c_int32),
     ]
 
 

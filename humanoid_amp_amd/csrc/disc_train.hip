@@ -784,7 +784,7 @@ int amp_disc_trainer_create(AmpDisc* disc, const AmpDiscTrainCfg* cfg, const dou
   t->ws_floats = f + (int64_t)16 * p.h2 * p.h1 + (int64_t)kChunks * 1024 + 1024 + 3 * (up((int64_t)kChunks * p.in_dim * 2, 8) * 2) + 16 +
                  16 * 40 + 6 * up(p.k1p, 16) + M * (t->kN - p.k1p) + 2 * (int64_t)kChunks * 1024;
   if (e == hipSuccess) e = hipMalloc(&t->ws, sizeof(float) * t->ws_floats);
-  if (e == hipSuccess && !cfg->gemm_fp32) {
+  if (e == hipSuccess && cfg->gemm_f16x3) {
     // fp16-split GEMM path: planes of the largest operand ([3B (padded), max(h1, h2)] or its transpose), twice
     const int64_t rows = up(Mp, 32), cols = up(std::max<int64_t>(std::max(p.h1, p.h2), up(t->kN, 32)), 32);
     t->plane_halves = 2 * rows * cols;
@@ -887,7 +887,7 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
     scalar_final_kernel<<<1, 256, 0, st>>>(part, nb, scale, loss, slot, accumulate);
   };
   int rc;
-  // The BACKWARD products whose shape fits run at fp32 accuracy on the fp16 matrix pipe (gemm_f16x3) unless cfg.gemm_fp32;
+  // The BACKWARD products whose shape fits run at fp32 accuracy on the fp16 matrix pipe (gemm_f16x3) when cfg.gemm_f16x3 is set;
   // the others (output width kN = 192: the W1-gradient products and g) and the two FORWARD GEMMs stay on the fp32 pipe.
   // The forward decides the ReLU masks: a pre-activation within rounding of zero flips its mask with any change of the
   // summation (measured: one of 786 432 H2 entries between the two engines at 3 x 512 rows), and one flipped unit moves its

@@ -636,7 +636,7 @@ class AmpDiscriminatorTrainer:
         c.grad_penalty_scale, c.weight_decay_scale = discriminator_gradient_penalty_scale, discriminator_weight_decay_scale
         c.scaler_epsilon, c.scaler_clip = disc.epsilon, disc.clip_threshold
         c.use_scaler, c.update_scaler, c.apply_update = int(use_scaler), int(update_scaler), int(apply_update)
-        c.gemm_fp32 = int(gemm_precision == "f32")
+        c.gemm_f16x3 = int(gemm_precision == "f16x3")
         self.loss_scale = float(discriminator_loss_scale)
         m = None if running_mean is None else running_mean.detach().to(device=self.device, dtype=torch.float64).contiguous()
         v = None if running_variance is None else running_variance.detach().to(device=self.device, dtype=torch.float64).contiguous()

@@ -245,6 +245,15 @@ class HotPath:
           args.append(per_parity)
         self._hot_args = args
         self._hot_lib = nat.load()
+        # the raw pointers baked into the arguments: a later disc._workspace() growth or attach_discriminator() reallocation
+        # must not leave amp_hot_step writing through stale addresses (the tensors themselves are kept alive above)
+        self._hot_keep.append((ws, [k.disc_input for k in self._kernels]))
+        self._hot_ptrs = self._hot_pointer_key()
+
+    def _hot_pointer_key(self):
+        ws = (self.disc._ws or {}).get(0)
+        return (None if ws is None else ws.data_ptr(),) + tuple(None if k.disc_input is None else k.disc_input.data_ptr()
+                                                                 for k in self._kernels)
 
     def _eager_step(self, which: int | None = None):
         i = (self._n if which is None else which) % len(self.states)
@@ -253,7 +262,7 @@ class HotPath:
         if self.one_call and self.fused_scaler and self.fused_tail and self.fused_expert and not self.overlap:
             import ctypes as C
 
-            if self._hot_args is None:
+            if self._hot_args is None or self._hot_ptrs != self._hot_pointer_key():
                 self._build_hot_args()
             if self.two_streams:
                 par = self._n & 1

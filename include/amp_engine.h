@@ -497,9 +497,9 @@ typedef struct {
   int32_t use_scaler;           /* 0: feed raw observations */
   int32_t update_scaler;        /* 1: train=True statistics update with every batch (fp64) */
   int32_t apply_update;         /* 0: compute loss / gradients only (Adam moments still advance with lr = 0) */
-  int32_t gemm_fp32;            /* 1: every GEMM on the fp32 matrix pipe (what the Python wrapper asks for by default: faster at
-                                 * 3 x 4 096 rows); 0: the large backward products at fp32 accuracy on the fp16 matrix pipe (two
-                                 * fp16 planes per operand, three MFMAs per product, like the inference path) */
+  int32_t gemm_f16x3;           /* 0 (default, also what a zero-initialised struct gets): every GEMM on the fp32 matrix pipe -- the
+                                 * faster choice at 3 x 4 096 rows; 1: opt in to the large backward products at fp32 accuracy on the
+                                 * fp16 matrix pipe (two fp16 planes per operand, three MFMAs per product, like the inference path) */
 } AmpDiscTrainCfg;
 
 /* The trainer updates `disc`'s weights (and, with use_scaler, its scaler) in place; `disc` must outlive it.

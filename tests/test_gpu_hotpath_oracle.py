@@ -50,3 +50,26 @@ def test_hot_step_matches_the_oracle(workload, num_envs):
         assert err["task"] <= TOL * scale and err["style"] <= TOL and err["combined"] <= TOL * scale, (step, err)
         total_resets += err["n_reset"]
     assert total_resets > 0
+
+
+def test_hot_args_follow_a_reallocated_workspace():
+    """amp_hot_step runs on prebuilt arguments holding raw device pointers.  A later call on the same discriminator
+    that needs a LARGER workspace replaces the tensor: the next hot step must rebuild its arguments instead of writing through
+    the stale address.  Two identical shards; one of them is disturbed between the steps; results stay bit-equal."""
+    from humanoid_amp_amd.workloads import WORKLOADS, HotPath
+
+    spec = WORKLOADS["g1_walk"]
+    a = HotPath(spec, 512, "cuda:0", seed=5, state_sets=2)
+    b = HotPath(spec, 512, "cuda:0", seed=5, state_sets=2)
+    oa, ob = a.step(), b.step()
+    assert torch.equal(oa["style"], ob["style"])
+    ws_before = b.disc._ws[0].data_ptr()
+    big = torch.randn(8192, spec.K * spec.D, device="cuda")
+    b.disc.style_reward(big)                       # 16x the rows: the workspace of slot 0 is reallocated
+    assert b.disc._ws[0].data_ptr() != ws_before
+    junk = torch.full((1 << 22,), float("nan"), device="cuda")  # whatever reuses the freed block must not be read or written
+    oa, ob = a.step(), b.step()
+    torch.cuda.synchronize()
+    assert torch.equal(oa["style"], ob["style"]) and torch.equal(oa["combined"], ob["combined"])
+    assert torch.equal(a.kernel.amp_observation_buffer, b.kernel.amp_observation_buffer)
+    assert bool(torch.isnan(junk).all())
