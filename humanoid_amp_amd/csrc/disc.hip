@@ -347,7 +347,7 @@ static int launch_f16(GemmF16Args g, int64_t rows, int N, const char* name, hipS
 // LDS-DMA launch of one layer on a (64 TM) x (128 TN) tile (block-layout operands)
 template <int MODE, int TM, int TN, int KB2 = 0>
 static int launch_dma(GemmF16Args g, int64_t rows, int N, const char* name, hipStream_t st) {
-  using T = DmaTile<TM, TN, KB2 ? 3 : 2>;
+  using T = DmaTile<TM, TN, KB2 ? KB2 : 2>;
   g.n_tiles = N / T::BN;
   g.m_tiles = (int)((rows + T::BM - 1) / T::BM);
   const unsigned grid = (unsigned)(((int64_t)g.m_tiles * g.n_tiles + 7) / 8 * 8);
@@ -358,7 +358,7 @@ static int launch_dma(GemmF16Args g, int64_t rows, int N, const char* name, hipS
 template <int MODE, int TM, int TN, int KB2 = 0>
 static hipError_t dma_kernel_init() {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gemm_f16_dma_kernel<MODE, TM, TN, KB2>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, DmaTile<TM, TN, KB2 ? 3 : 2>::kLds);
+                             hipFuncAttributeMaxDynamicSharedMemorySize, DmaTile<TM, TN, KB2 ? KB2 : 2>::kLds);
 }
 // kernels whose LDS tile exceeds the 64 KB default need the limit raised once per device (not capturable: done at create)
 static int f16_kernels_init() {
@@ -374,7 +374,7 @@ static int f16_kernels_init() {
   AMP_HIP((dma_kernel_init<1, 4, 1>()));
   AMP_HIP((dma_kernel_init<0, 2, 1>()));
   AMP_HIP((dma_kernel_init<1, 2, 1>()));
-  AMP_HIP((dma_kernel_init<1, 2, 1, 1>()));
+  AMP_HIP((dma_kernel_init<1, 2, 1, 4>()));
   if (dev >= 0 && dev < 64) done[dev] = true;
   return AMP_OK;
 }
@@ -447,11 +447,12 @@ static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* a
       g2.A = H1p;
       g2.W = h->w2b;
       // 128 x 128 tiles: when the launch is ONE round of workgroups (<= one per CU: the 8 192-env shards) the k-block-per-
-      // segment schedule on a three-stage ring (96 KB: one workgroup per CU anyway) is 2.4-3 us faster (8 192 rows 31.5 ->
-      // 29.1 us, 6 144 rows 29.9 -> 26.8, engine tracer); with more tiles than CUs two 64-KB workgroups per CU win (12 000
-      // rows: 45.9 vs 49.3 us).  Same accumulation order: bit-identical either way.
+      // segment schedule on a four-stage ring (128 KB: one workgroup per CU anyway) is ~3 us faster (8 192 rows 31.5 -> 29.1 us
+      // with three stages, 28.2 with four; 6 144 rows 29.9 -> 26.8, engine tracer) -- what helps is the extra fill cover: the same
+      // schedule on TWO stages measured 31.8 us; with more tiles than CUs two 64-KB workgroups per CU win (12 000 rows: 45.9 vs
+      // 49.3 us).  Same accumulation order: bit-identical either way.
       const bool one_round = (m + 127) / 128 * (h->h2 / 128) <= 256;
-      if (plan == kPlanDmaSmall) rc = one_round ? launch_dma<1, 2, 1, 1>(g2, m, h->h2, "disc_gemm_f16_dma_kernel<1>", st)
+      if (plan == kPlanDmaSmall) rc = one_round ? launch_dma<1, 2, 1, 4>(g2, m, h->h2, "disc_gemm_f16_dma_kernel<1>", st)
                                                 : launch_dma<1, 2, 1>(g2, m, h->h2, "disc_gemm_f16_dma_kernel<1>", st);
       else if (plan == kPlanDmaMid) rc = launch_dma<1, 4, 1>(g2, m, h->h2, "disc_gemm_f16_dma_kernel<1>", st);
       else rc = launch_dma<1, 4, 2>(g2, m, h->h2, "disc_gemm_f16_dma_kernel<1>", st);

@@ -76,16 +76,19 @@ static __global__ __launch_bounds__(kBlock) void split_rows_blocks_kernel(const 
 // W = weights in block layout, row pitch 2 * Kp halves; MODE 0 output H in block layout, row pitch 2 * ldh halves.
 // (Ablated variants of this kernel -- no fills, no fragment reads, no stores, free-running waves -- live in
 // tools/experiments/disc_gemm_f16_dma_xp.hpp for tools/gemm_f16_bench.hip; the product kernel carries none.)
-// KB2 = 1 (small tiles): a matrix segment holds BOTH k-steps of a k-block -- R M per k-block instead of R0 M0 R1 M1 -- over a
-// THREE-stage ring.  A 128 x 128 tile has 6 MFMAs (192 matrix-pipe cycles) per k-step and wave: with two barriers per k-step
+// KB2 = 3 / 4 (small tiles): a matrix segment holds BOTH k-steps of a k-block -- R M per k-block instead of R0 M0 R1 M1 -- over a
+// ring of KB2 stages.  A 128 x 128 tile has 6 MFMAs (192 matrix-pipe cycles) per k-step and wave: with two barriers per k-step
 // the barrier-bracketed segments alone cost 20 of the 29 us of an 8 192-row layer-2 launch (tools/gemm_f16_bench.hip XPS=1,
-// profiles/r03_gemm_f16_small_tile_ablation.txt: bare MFMA stream 11.7 us).  Twelve MFMAs per segment halve the barriers; the
-// third stage gives the fills the latency cover the two dropped intervals took away (k-block q + 2 is issued in R(q), awaited
-// before the barrier in front of R(q + 1)'s first read, counted: vmcnt(np) leaves only the younger k-block in flight).
+// profiles/r03_gemm_f16_small_tile_ablation.txt: bare MFMA stream 11.7 us).  Twelve MFMAs per segment halve the barriers, and the
+// extra stages give the fills the latency cover the two dropped intervals took away (k-block q + KB2 - 1 is issued in R(q); k-block
+// q + 1 is awaited before the barrier in front of R(q + 1)'s first read, counted: vmcnt leaves only the younger k-blocks in
+// flight).  Measured at 8 192 rows: two stages 31.8 us (no gain over the k-step schedule's 31.5), three 29.1, four 28.2.
 // Accumulation order per accumulator is unchanged (k ascending, the same three products per k-step): bit-identical results.
+// (KB2 = the number of stages of that ring: 3, or 4 = one more k-block of fill cover.)
 template <int MODE, int TM = 4, int TN = 2, int KB2 = 0>
-__global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? 3 : 2>::kWgPerCu)) void disc_gemm_f16_dma_kernel(GemmF16Args g) {
-  using T = DmaTile<TM, TN, KB2 ? 3 : 2>;
+__global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPerCu)) void disc_gemm_f16_dma_kernel(GemmF16Args g) {
+  using T = DmaTile<TM, TN, KB2 ? KB2 : 2>;
+  static_assert(KB2 == 0 || KB2 == 3 || KB2 == 4, "KB2 = stages of the k-block-per-segment ring");
   static_assert(!KB2 || MODE == 1, "the k-block-per-segment schedule is wired for layer 2 (no zero-padding k-step skip, no split-K)");
   constexpr int BM = T::BM, BN = T::BN, kOpA = T::kA, kStage = T::kStage;
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
@@ -213,22 +216,26 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? 3 : 2>::kWgPerC
 
   if constexpr (KB2) {
     h8 y0[2][TM], y1[2][TM], v0[2][TN], v1[2][TN];  // fragments of both k-steps
-    auto wait_younger = [&](const bool one_in_flight) {  // the wave's pieces of the OLDER outstanding k-block have landed
-      if (!one_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (np == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (np == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else if (np == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    constexpr int NS = KB2;
+    auto wait_younger = [&](const int younger) {  // all of the wave's pieces but those of the `younger` newest k-blocks have landed
+      const int pieces = younger * np;
+      if (pieces <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (pieces == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      else if (pieces == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else if (pieces == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (pieces == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (pieces == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (3 x ... never occurs with NS <= 4 and np a power of two <= 8)
     };
-    fill(0, 0);
-    if (nq > 1) fill(1, 1);
-    wait_younger(nq > 1);
+    for (int q = 0; q < NS - 1 && q < nq; ++q) fill(q, q);
+    wait_younger((nq < NS - 1 ? nq : NS - 1) - 1);
     __builtin_amdgcn_s_barrier();  // k-block 0 is visible to every wave
     if (grp == 1) __builtin_amdgcn_s_barrier();
-    auto kb = [&](const int q, const bool ahead) {  // ahead: k-block q + 2 exists and is issued here
-      const unsigned char* sb = lds + (q % 3) * kStage;
-      // R: fragments of both k-steps; stage (q + 2) % 3 held k-block q - 1, whose last reads were retired in front of a
-      // barrier this wave has passed
+    // `younger`: k-blocks q + 2 .. that are in flight when k-block q + 1 is awaited (NS - 2 in the steady loop)
+    auto kb = [&](const int q, const bool ahead, const int younger) {  // ahead: k-block q + NS - 1 exists and is issued here
+      const unsigned char* sb = lds + (q % NS) * kStage;
+      // R: fragments of both k-steps; stage (q + NS - 1) % NS held k-block q - 1, whose last reads were retired in front of
+      // a barrier this wave has passed
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -242,8 +249,8 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? 3 : 2>::kWgPerC
           v1[ks][b] = *reinterpret_cast<const h8*>(sb + brow + b * 32 * 128 + cb[ks][1]);
         }
       }
-      if (ahead) fill(q + 2, (q + 2) % 3);
-      if (grp == 1) wait_younger(ahead);  // group 1's pieces of k-block q + 1: before the barrier that ends this interval
+      if (ahead) fill(q + NS - 1, (q + NS - 1) % NS);
+      if (grp == 1) wait_younger(younger);  // group 1's pieces of k-block q + 1: before the barrier that ends this interval
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       // M: 2 x 3 TM TN MFMAs between two barriers
       __builtin_amdgcn_sched_barrier(0);
@@ -267,13 +274,13 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? 3 : 2>::kWgPerC
       }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
-      if (grp == 0) wait_younger(ahead);  // group 0's pieces of k-block q + 1: behind its MFMAs
+      if (grp == 0) wait_younger(younger);  // group 0's pieces of k-block q + 1: behind its MFMAs
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
     };
-    for (int q = 0; q + 2 < nq; ++q) kb(q, true);
-    if (nq >= 2) kb(nq - 2, false);
-    kb(nq - 1, false);
+    int q = 0;
+    for (; q + NS - 1 < nq; ++q) kb(q, true, NS - 2);
+    for (; q < nq; ++q) kb(q, false, nq - 2 - q > 0 ? nq - 2 - q : 0);  // the tail: nothing left to issue, fewer k-blocks in flight
   } else {
   fill(0, 0);
   if (nq > 1) {
