@@ -696,6 +696,15 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
+  if (getenv("XPS") && mode == 0) {  // layer 1 on the 128 x 128 tile of the 8 192-row shards
+    for (int rep = 0; rep < 2; ++rep) {
+      run_dma<0, 0, 2, 1>(g, M, N, K, false); puts("  ^ 128x128 layer-1 LDS-DMA kernel, full");
+      run_dma<0, 3, 2, 1>(g, M, N, K, false); puts("  ^ no global stores in the epilogue");
+      run_dma<0, 4, 2, 1>(g, M, N, K, false); puts("  ^ one k-step only: prologue + epilogue + stores");
+      run_dma<0, 1, 2, 1>(g, M, N, K, false); puts("  ^ no fills in the loop");
+    }
+    return 0;
+  }
   if (getenv("XP") && mode == 0) {
     run_dma<0, 0>(g, M, N, K, false);
     printf("  ^ layer-1 LDS-DMA kernel, full\n");
