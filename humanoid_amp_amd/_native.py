@@ -53,6 +53,11 @@ class AmpCompactArgs(C.Structure):
                 ("num_envs", C.c_int64), ("ids", C.c_void_p), ("count", C.c_void_p)]
 
 
+class AmpPrePhysicsArgs(C.Structure):
+    _fields_ = [("actions_in", C.c_void_p), ("actions", C.c_void_p), ("last_actions", C.c_void_p), ("target", C.c_void_p),
+                ("offset", C.c_void_p), ("scale", C.c_void_p), ("num_envs", C.c_int64), ("n_actions", C.c_int32), ("reserved", C.c_int32)]
+
+
 class AmpRewardLogArgs(C.Structure):
     _fields_ = [("reward_terms", C.c_void_p), ("n_terms", C.c_int32), ("reserved", C.c_int32), ("means", C.c_void_p)]
 
@@ -182,6 +187,7 @@ SIGNATURES = {
     "amp_env_step_with_reference": (C.c_int, [C.POINTER(AmpEnvCfg), C.POINTER(AmpSimState), C.POINTER(AmpEnvBuffers), _i64, C.c_uint32,
                                               _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "amp_command_step": (C.c_int, [C.POINTER(AmpCommandArgs), _i64, _i32, _vp]),
+    "amp_pre_physics_step": (C.c_int, [C.POINTER(AmpPrePhysicsArgs), C.POINTER(AmpCommandArgs), _vp]),
     "amp_reward_log_means": (C.c_int, [_vp, _i32, _i64, _vp, _vp]),
     "amp_reset_compact_workspace_bytes": (_i64, [_i64]),
     "amp_reset_compact": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),

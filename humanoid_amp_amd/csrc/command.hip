@@ -47,6 +47,38 @@ __global__ __launch_bounds__(kBlock) void command_kernel(AmpCommandArgs a, int64
   command_reset_env(a, env);
 }
 
+// The per-step bookkeeping in front of the physics step as ONE launch (amp_pre_physics_step): what G1AmpEnv._pre_physics_step
+// (g1_amp_env.py:142-167) and _apply_action (:169-173) do with five ATen launches + the command-timer launch:
+//   actions[e] = actions_in[e]; last_actions[e] = actions_in[e]; target[e] = offset[j] + scale[j] * actions_in[e]   (mul, add:
+//   the reference's `self.action_offset + self.action_scale * self.actions`, bit for bit)   + the timers' tick for env < N.
+// A thread owns one (env, joint) element; the threads with joint 0 also tick their env's command timer.
+__global__ __launch_bounds__(kBlock) void pre_physics_kernel(AmpPrePhysicsArgs a, AmpCommandArgs c, int has_tick) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t total = a.num_envs * a.n_actions;
+  if (e >= total) return;
+  const int64_t env = e / a.n_actions;
+  const int j = (int)(e - env * a.n_actions);
+  const float v = a.actions_in[e];
+  if (a.actions) a.actions[e] = v;
+  if (a.last_actions) a.last_actions[e] = v;
+  if (a.target) {
+    const float s = a.scale ? a.scale[j] * v : v;
+    a.target[e] = a.offset ? a.offset[j] + s : s;
+  }
+  if (j == 0 && has_tick) {
+    const float left = c.time_left[env] - c.step_dt;  // command_time_left -= step_dt (command_kernel's TICK branch)
+    if (left <= 0.0f && c.vel_span > 0.0f) {
+      float cx, cy, tl;
+      draw_command(c.seed, command_step_of(c), (uint64_t)(c.env_offset + env), 0u, c.vel_lo, c.vel_span, c.t_lo, c.t_span, cx, cy, tl);
+      c.command[2 * env] = cx;
+      c.command[2 * env + 1] = cy;
+      c.time_left[env] = tl;
+    } else {
+      c.time_left[env] = left;
+    }
+  }
+}
+
 // One workgroup (1 024 lanes) per term.  Lane t owns elements t*4 .. t*4+3 of every 4 096-element trip and accumulates them
 // in fp64 in trip order; eight trips' 16-B loads are issued before the first add (the first version issued one dependent
 // 4-B load per trip and 256 lanes: 64 us at 65 536 envs, all latency), then a fixed binary tree over the lanes.
@@ -103,6 +135,21 @@ int amp_command_step(const AmpCommandArgs* a, int64_t num_envs, int32_t mode, am
     command_kernel<<<(unsigned)((threads + kBlock - 1) / kBlock), kBlock, 0, st>>>(*a, num_envs, mode);
   }
   return launch_status("command_kernel");
+}
+
+int amp_pre_physics_step(const AmpPrePhysicsArgs* a, const AmpCommandArgs* tick, amp_stream_t stream) {
+  AMP_REQUIRE(a, "amp_pre_physics_step: null argument");
+  AMP_REQUIRE(a->num_envs >= 0 && a->n_actions >= 1, "amp_pre_physics_step: need num_envs >= 0 and n_actions >= 1");
+  if (a->num_envs == 0) return AMP_OK;
+  AMP_REQUIRE(a->actions_in, "amp_pre_physics_step: actions_in is null");
+  AMP_REQUIRE(!tick || (tick->command && tick->time_left), "amp_pre_physics_step: null command buffer");
+  AMP_REQUIRE(!tick || !(tick->vel_span > 0.0f) || tick->t_span >= 0.0f, "amp_pre_physics_step: negative resampling-time span");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = a->num_envs * a->n_actions;
+  { amp::TraceScope trace__("pre_physics_kernel", st);
+    pre_physics_kernel<<<(unsigned)((total + kBlock - 1) / kBlock), kBlock, 0, st>>>(*a, tick ? *tick : AmpCommandArgs{}, tick ? 1 : 0);
+  }
+  return launch_status("pre_physics_kernel");
 }
 
 int amp_reward_log_means(const float* reward_terms, int32_t n_terms, int64_t num_envs, float* means, amp_stream_t stream) {

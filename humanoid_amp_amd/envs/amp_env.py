@@ -121,6 +121,9 @@ class _AmpEnv(DirectRLEnv):
         self.action_space = Box(-np.inf, np.inf, (self.cfg.action_space,))
         f32 = dict(dtype=torch.float32, device=self.device)
         self.actions = torch.zeros((self.num_envs, self.cfg.action_space), **f32)
+        self._target = torch.zeros((self.num_envs, self.cfg.action_space), **f32)
+        self.action_offset, self.action_scale = self.action_offset.contiguous(), self.action_scale.contiguous()
+        self._pre_args = None
         self.last_actions = torch.zeros((self.num_envs, self.cfg.action_space), **f32)
         self.command_target_speed = torch.zeros((self.num_envs, 2), **f32)
         self.command_time_left = torch.zeros(self.num_envs, **f32)
@@ -190,11 +193,29 @@ class _AmpEnv(DirectRLEnv):
             log = self.extras["log"] = log.renew()
             self._track_log(log)
 
+    def _pre_physics(self, actions: torch.Tensor, tick) -> None:
+        """``amp_pre_physics_step``: the reference's ``self.actions = actions.clone()``, the joint targets
+        ``action_offset + action_scale * actions`` of ``_apply_action``, ``self.last_actions = self.actions.clone()`` (G1) and
+        the command timers' tick as ONE launch into persistent buffers (g1_amp_env.py:142-173)."""
+        if actions.dtype != torch.float32 or not actions.is_contiguous() or tuple(actions.shape) != tuple(self.actions.shape):
+            actions = actions.to(dtype=torch.float32).contiguous().view(self.actions.shape)
+        p = self._pre_args
+        if p is None:
+            a = nat.AmpPrePhysicsArgs()
+            a.actions, a.target = self.actions.data_ptr(), self._target.data_ptr()
+            a.last_actions = self.last_actions.data_ptr() if self.IS_G1 else None
+            a.offset, a.scale = self.action_offset.data_ptr(), self.action_scale.data_ptr()
+            a.num_envs, a.n_actions = self.num_envs, int(self.actions.shape[1])
+            p = self._pre_args = (a, nat.load().amp_pre_physics_step)
+        p[0].actions_in = actions.data_ptr()
+        with torch.cuda.device(self.device):
+            nat.check(p[1](C.byref(p[0]), C.byref(tick) if tick is not None else None, nat.stream_ptr()), "amp_pre_physics_step")
+
     def _pre_physics_step(self, actions: torch.Tensor):
-        self.actions.copy_(actions)  # the reference's `self.actions = actions.clone()` into a persistent buffer
+        self._pre_physics(actions, None)
 
     def _apply_action(self):
-        self.robot.set_joint_position_target(self.action_offset + self.action_scale * self.actions)
+        self.robot.set_joint_position_target(self._target)  # computed by _pre_physics_step's launch
 
     def _get_dones(self):
         # dones AND task reward: DirectRLEnv.step calls _get_rewards next, on the same state (g1_amp_env.py:246-330)
@@ -343,21 +364,15 @@ class G1AmpEnv(_AmpEnv):
                      seed=self._reset_seed, step=self.common_step_counter, env_offset=self.env_offset, **which)
 
     def _pre_physics_step(self, actions: torch.Tensor):
-        self.actions.copy_(actions)
-        # timers + resample of the expired envs (g1_amp_env.py:146-167): one launch, no nonzero() sync; prebuilt arguments
+        # actions / targets / last_actions + the timers' tick with the resample of the expired envs (g1_amp_env.py:146-173):
+        # one launch, no nonzero() sync; prebuilt arguments
         t = self._tick_args
         if t is None or t[0] != (self.command_target_speed.data_ptr(), self.command_time_left.data_ptr()):
-            t = self._tick_args = ((self.command_target_speed.data_ptr(), self.command_time_left.data_ptr()), self._command_args(),
-                                   nat.load().amp_command_step)
+            t = self._tick_args = ((self.command_target_speed.data_ptr(), self.command_time_left.data_ptr()), self._command_args())
         a = t[1]
         a.seed = self._reset_seed & (2**64 - 1)
         a.step, a.step_dev = self._step_args()
-        with torch.cuda.device(self.device):
-            nat.check(t[2](C.byref(a), self.num_envs, nat.AMP_COMMAND_TICK, nat.stream_ptr()), "amp_command_step")
-
-    def _apply_action(self):
-        super()._apply_action()
-        self.last_actions.copy_(self.actions)  # `self.last_actions = self.actions.clone()` (g1_amp_env.py:173)
+        self._pre_physics(actions, a)
 
     def _resample_commands(self, env_ids, on_reset: bool):
         # reset-side resample (g1_amp_env.py:421-439) for an explicit id list (the host-driven reset path)

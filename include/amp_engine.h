@@ -295,6 +295,24 @@ typedef struct {
 } AmpCommandArgs;
 int amp_command_step(const AmpCommandArgs* args, int64_t num_envs, int32_t mode, amp_stream_t stream);
 
+/* The bookkeeping in front of the physics step as ONE launch: G1AmpEnv._pre_physics_step (g1_amp_env.py:142-167) and the
+ * arithmetic of _apply_action (:169-173) -- `self.actions = actions.clone()`, the command timers' tick (tick != NULL: exactly
+ * amp_command_step(AMP_COMMAND_TICK)), `target = action_offset + action_scale * actions` (one fp32 multiply, one add, as the
+ * reference evaluates it), `self.last_actions = self.actions.clone()` -- instead of five ATen launches and the timer launch.
+ * Any output pointer may be NULL (skipped); offset / scale NULL mean 0 / 1. */
+typedef struct {
+  const float* actions_in;   /* dev [num_envs, n_actions] the agent's actions */
+  float* actions;            /* dev [num_envs, n_actions] out: self.actions */
+  float* last_actions;       /* dev [num_envs, n_actions] out: self.last_actions */
+  float* target;             /* dev [num_envs, n_actions] out: joint position targets */
+  const float* offset;       /* dev [n_actions] action_offset, or NULL */
+  const float* scale;        /* dev [n_actions] action_scale, or NULL */
+  int64_t num_envs;
+  int32_t n_actions;
+  int32_t reserved;
+} AmpPrePhysicsArgs;
+int amp_pre_physics_step(const AmpPrePhysicsArgs* args, const AmpCommandArgs* tick, amp_stream_t stream);
+
 /* Means over the envs of the rows of reward_terms [n_terms, N] (AmpEnvBuffers.reward_terms) -> means_dev [n_terms]:
  * the `.mean().item()` chain of G1AmpEnv._get_rewards (g1_amp_env.py:291-305) as one launch with no read-back (fp64
  * accumulation in a fixed order). */

@@ -185,3 +185,43 @@ def test_g1_env_step_has_no_host_sync():
     assert all(np.isfinite(v) for v in logs[-1].values())
     # the per-env mirrors of the reset draw (g1_amp_env.py:377-382) follow on the device path too
     assert int(env.motion_ids.max()) == 0 and float(env.motion_start_times.max()) > 0.0
+
+
+def test_pre_physics_step_equals_the_separate_launches():
+    """amp_pre_physics_step (actions copy + joint targets + last_actions + command tick in ONE launch) against the five
+    ATen launches of the reference's _pre_physics_step / _apply_action (g1_amp_env.py:142-173) + amp_command_step(TICK):
+    torch.equal on everything, ragged env count, NULL outputs skipped."""
+    import ctypes as C
+
+    from humanoid_amp_amd import _native as nat
+    from humanoid_amp_amd.engine import command_step
+
+    N, A = 5003, 29
+    gen = torch.Generator().manual_seed(8)
+    acts = (torch.randn(N, A, generator=gen) * 0.7).cuda()
+    off, scale = torch.randn(A, generator=gen).cuda(), (torch.rand(A, generator=gen) + 0.5).cuda()
+    cmd0, left0 = (torch.rand(N, 2, generator=gen) * 2 - 1).cuda(), (torch.rand(N, generator=gen) * 0.1 - 0.02).cuda()
+    # separate launches
+    cmd_a, left_a = cmd0.clone(), left0.clone()
+    command_step(cmd_a, left_a, mode=nat.AMP_COMMAND_TICK, step_dt=DT, vel_range=VEL, time_range=TIME, seed=77, step=5, env_offset=1000)
+    want_target = off + scale * acts
+    # one launch
+    cmd_b, left_b = cmd0.clone(), left0.clone()
+    actions, last, target = torch.zeros_like(acts), torch.zeros_like(acts), torch.zeros_like(acts)
+    a = nat.AmpPrePhysicsArgs()
+    a.actions_in, a.actions, a.last_actions, a.target = acts.data_ptr(), actions.data_ptr(), last.data_ptr(), target.data_ptr()
+    a.offset, a.scale, a.num_envs, a.n_actions = off.data_ptr(), scale.data_ptr(), N, A
+    t = nat.AmpCommandArgs()
+    t.command, t.time_left = cmd_b.data_ptr(), left_b.data_ptr()
+    t.step_dt, t.vel_lo, t.vel_span, t.t_lo, t.t_span = DT, VEL[0], VEL[1] - VEL[0], TIME[0], TIME[1] - TIME[0]
+    t.seed, t.step, t.env_offset = 77, 5, 1000
+    with torch.cuda.device("cuda:0"):
+        nat.check(nat.load().amp_pre_physics_step(C.byref(a), C.byref(t), nat.stream_ptr()), "amp_pre_physics_step")
+    assert torch.equal(actions, acts) and torch.equal(last, acts) and torch.equal(target, want_target)
+    assert torch.equal(cmd_a, cmd_b) and torch.equal(left_a, left_b) and not torch.equal(cmd0, cmd_b)
+    # NULL outputs / no tick / no affine map
+    a2 = nat.AmpPrePhysicsArgs()
+    a2.actions_in, a2.target, a2.num_envs, a2.n_actions = acts.data_ptr(), target.data_ptr(), N, A
+    with torch.cuda.device("cuda:0"):
+        nat.check(nat.load().amp_pre_physics_step(C.byref(a2), None, nat.stream_ptr()), "amp_pre_physics_step")
+    assert torch.equal(target, acts) and torch.equal(cmd_a, cmd_b)
