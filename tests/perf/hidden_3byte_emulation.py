@@ -5,7 +5,7 @@ engine's arithmetic on the CPU: layer 1 exact (fp64), hidden activations rounded
 import numpy as np
 import torch
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import disc as odisc
 
 rng = np.random.default_rng(0)
