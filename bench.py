@@ -468,7 +468,7 @@ def main():
         # keys are "kernel<template args>@workgroups" of one launch (tools/pmc_summary.py --traffic-json)
         if args.disc_precision == "f16x3" and rows >= 24576:
             wg = ((rows + 255) // 256 * 2 + 7) // 8 * 8
-            traffic = (tj.get(f"disc_gemm_f16_dma_kernel<1, 4, 2>@{wg}") or {}).get("hbm_bytes")
+            traffic = (tj.get(f"disc_gemm_f16_dma_kernel<1, 4, 2, 0>@{wg}") or tj.get(f"disc_gemm_f16_dma_kernel<1, 4, 2>@{wg}") or {}).get("hbm_bytes")
         if spec.K == 2 and envs >= 32768 and envs % 32 == 0:
             wg = envs // 32 + (envs * spec.K + 255) // 256  # 32-env tiles + 256-sample expert tiles of the fused launch
             hbm_traffic = (tj.get(f"env_step_dma_reference_kernel<32>@{wg}") or {}).get("hbm_bytes")
