@@ -90,7 +90,7 @@ class AmpDiscTrainCfg(C.Structure):
         ("max_rows_per_group", C.c_int64), ("learning_rate", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
         ("adam_epsilon", C.c_float), ("loss_scale", C.c_float), ("logit_reg_scale", C.c_float), ("grad_penalty_scale", C.c_float),
         ("weight_decay_scale", C.c_float), ("scaler_epsilon", C.c_float), ("scaler_clip", C.c_float), ("use_scaler", C.c_int32),
-        ("update_scaler", C.c_int32), ("apply_update", C.c_int32), ("gemm_f16x3", C.c_int32),
+        ("update_scaler", C.c_int32), ("apply_update", C.c_int32), ("gemm_f16x3", C.c_int32), ("defer_refresh", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -205,6 +205,7 @@ SIGNATURES = {
     "amp_disc_trainer_create": (C.c_int, [_vp, C.POINTER(AmpDiscTrainCfg), _vp, _vp, C.c_double, _vp, C.POINTER(_vp)]),
     "amp_disc_trainer_destroy": (C.c_int, [_vp]),
     "amp_disc_trainer_scaler": (C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_double), _vp]),
+    "amp_disc_trainer_refresh": (C.c_int, [_vp, _vp]),
     "amp_disc_train_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "amp_converter_create": (C.c_int, [C.POINTER(AmpKinModel), C.POINTER(_vp)]),
     "amp_converter_destroy": (C.c_int, [_vp]),

@@ -107,48 +107,40 @@ __global__ void scalar_final_kernel(const float* __restrict__ part, int n, float
   if (threadIdx.x == 0) out[slot] = (accumulate ? out[slot] : 0.0f) + scale * red[0];
 }
 
-__global__ __launch_bounds__(kBlock) void rowdot_kernel(const float* __restrict__ A, int64_t rows, int cols, int64_t lda,
-                                                        const float* __restrict__ w, const float* __restrict__ b,
-                                                        float* __restrict__ out) {
-  // one wave per row: out[i] = A[i] . w + b
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (row >= rows) return;
-  float s = 0.0f;
-  for (int c = lane; c < cols; c += 64) s += A[row * lda + c] * w[c];
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-  if (lane == 0) out[row] = s + b[0];
-}
-
-// BCE-with-logits forward + backward for the two groups; one block, deterministic.
-// loss[0] = 0.5 * (mean softplus(l | fake rows) + mean softplus(-l | motion rows)); dlogit includes loss_scale.
-__global__ __launch_bounds__(1024) void bce_kernel(const float* __restrict__ logit, int64_t n_fake, int64_t n_real,
-                                                   float loss_scale, float* __restrict__ dlogit, float* __restrict__ loss) {
-  __shared__ float red[2][1024];
+// one wave per row: logit[i] = A[i] . w + b, and -- the per-row half of bce_kernel, which was a single-block launch of its own --
+// the row's BCE-with-logits term and dlogit[i]; bce_part[0 | 1][block] = the block's four rows' loss terms of the fake / motion
+// group (summed in row order), reduced by the step's last kernel (reg_final_kernel).
+__global__ __launch_bounds__(kBlock) void rowdot_bce_kernel(const float* __restrict__ A, int64_t rows, int cols, int64_t lda,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            int64_t n_fake, float loss_scale, float* __restrict__ out,
+                                                            float* __restrict__ dlogit, float* __restrict__ bce_part) {
+  __shared__ float s_l[2][4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
   float lf = 0.0f, lr = 0.0f;
-  const int64_t n = n_fake + n_real;
-  for (int64_t i = threadIdx.x; i < n; i += 1024) {
-    const float x = logit[i];
-    const bool real = i >= n_fake;
-    const float y = real ? 1.0f : 0.0f;
-    // torch BCEWithLogits: (1 - y) x + max(-x, 0) + log(exp(-max(-x,0)) + exp(-x - max(-x,0)))
-    const float mx = fmaxf(-x, 0.0f);
-    const float l = (1.0f - y) * x + mx + logf(expf(-mx) + expf(-x - mx));
-    const float sg = 1.0f / (1.0f + expf(-x));
-    if (real) lr += l; else lf += l;
-    dlogit[i] = loss_scale * 0.5f * (sg - y) / (float)(real ? n_real : n_fake);
-  }
-  red[0][threadIdx.x] = lf;
-  red[1][threadIdx.x] = lr;
-  __syncthreads();
-  for (int off = 512; off > 0; off >>= 1) {
-    if (threadIdx.x < off) {
-      red[0][threadIdx.x] += red[0][threadIdx.x + off];
-      red[1][threadIdx.x] += red[1][threadIdx.x + off];
+  if (row < rows) {
+    float s = 0.0f;
+    for (int c = lane; c < cols; c += 64) s += A[row * lda + c] * w[c];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) {
+      const float x = s + b[0];
+      out[row] = x;
+      const bool real = row >= n_fake;
+      const float y = real ? 1.0f : 0.0f;
+      // torch BCEWithLogits: (1 - y) x + max(-x, 0) + log(exp(-max(-x,0)) + exp(-x - max(-x,0)))
+      const float mx = fmaxf(-x, 0.0f);
+      const float l = (1.0f - y) * x + mx + logf(expf(-mx) + expf(-x - mx));
+      const float sg = 1.0f / (1.0f + expf(-x));
+      if (real) lr = l; else lf = l;
+      dlogit[row] = loss_scale * 0.5f * (sg - y) / (float)(real ? rows - n_fake : n_fake);
     }
-    __syncthreads();
   }
-  if (threadIdx.x == 0) loss[0] = 0.5f * (red[0][0] / (float)n_fake + red[1][0] / (float)n_real);
+  if (lane == 0) { s_l[0][wave] = lf; s_l[1][wave] = lr; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const float* v = s_l[threadIdx.x];
+    bce_part[threadIdx.x * gridDim.x + blockIdx.x] = ((v[0] + v[1]) + v[2]) + v[3];
+  }
 }
 
 // dH2[i][n] = dlogit[i] * w3[n] * (H2[i][n] > 0)
@@ -271,10 +263,15 @@ __global__ void train_state_kernel(TrainState* __restrict__ s, double rows_merge
   s->bc2 = (float)(1.0 - pow(beta2, (double)s->step));
 }
 
+// The kernel reads every parameter anyway, so it also leaves the sums of squares of W1 / W2 / w3 BEFORE the update (the reported
+// regulariser terms; reg_sumsq_kernel was a separate 15-us launch): reg_part[k][block], k = 0 (W1), 1 (W2), 2 (w3).
 __global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamSegs a, float lr, float b1, float b2, float eps,
-                                                            const TrainState* __restrict__ state, float* __restrict__ grad_out) {
+                                                            const TrainState* __restrict__ state, float* __restrict__ grad_out,
+                                                            float* __restrict__ reg_part) {
+  __shared__ float red[3][kBlock];
   const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (e >= a.start[6]) return;
+  float sq[3] = {0.0f, 0.0f, 0.0f};
+  if (e < a.start[6]) {
   const float bc1 = state->bc1, bc2 = state->bc2;
   int s = 0;
 #pragma unroll
@@ -284,6 +281,9 @@ __global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamSegs a, float lr
   const int c = (int)(i - r * a.cols[s]);
   float* pp = a.p[s] + r * a.ld_p[s] + c;
   const float pv = *pp;
+  if (s == 0) sq[0] = pv * pv;
+  if (s == 2) sq[1] = pv * pv;
+  if (s == 4) sq[2] = pv * pv;
   const float gr = a.g[s][r * a.ld_g[s] + c] + a.reg2[s] * pv;
   if (grad_out) grad_out[e] = gr;  // parameter order, logical shapes: the segments are laid out that way
   const float mi = b1 * a.m[s][i] + (1.0f - b1) * gr;
@@ -291,34 +291,31 @@ __global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamSegs a, float lr
   a.m[s][i] = mi;
   a.v[s][i] = vi;
   *pp = pv - lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
-}
-
-// sums of squares of W1 (logical [h1, in_dim] inside rows of k1p), W2 and w3 in one launch -> part[3][gridDim.x]
-__global__ __launch_bounds__(kBlock) void reg_sumsq_kernel(const float* __restrict__ w1, int64_t rows1, int cols1, int64_t ld1,
-                                                           const float* __restrict__ w2, int64_t n2, const float* __restrict__ w3,
-                                                           int64_t n3, float* __restrict__ part) {
-  __shared__ float red[3][kBlock];
-  float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-  const int64_t stride = (int64_t)gridDim.x * kBlock, t0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  for (int64_t e = t0; e < rows1 * cols1; e += stride) {
-    const int64_t i = e / cols1;
-    const float v = w1[i * ld1 + (e - i * cols1)];
-    s1 += v * v;
   }
-  for (int64_t e = t0; e < n2; e += stride) s2 += w2[e] * w2[e];
-  for (int64_t e = t0; e < n3; e += stride) s3 += w3[e] * w3[e];
-  red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2; red[2][threadIdx.x] = s3;
+  if (reg_part == nullptr) return;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) red[k][threadIdx.x] = sq[k];
   __syncthreads();
   for (int off = kBlock / 2; off > 0; off >>= 1) {
-    if (threadIdx.x < off)
+    if ((int)threadIdx.x < off)
       for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + off];
     __syncthreads();
   }
-  if (threadIdx.x < 3) part[threadIdx.x * gridDim.x + blockIdx.x] = red[threadIdx.x][0];
+  if (threadIdx.x < 3) reg_part[threadIdx.x * gridDim.x + blockIdx.x] = red[threadIdx.x][0];
 }
+
 // loss[2] = logit_reg * sum w3^2 ; loss[3] = weight_decay * (sum W1^2 + sum W2^2 + sum w3^2)
-__global__ void reg_final_kernel(const float* __restrict__ part, int n, float logit_reg, float weight_decay, float* __restrict__ loss) {
+// ... and loss[4] = loss_scale * (((loss[0] + loss[1]) + loss[2]) + loss[3]): the step's scaled total (skrl's discriminator_loss)
+// ... and loss[0] = 0.5 * (mean BCE term of the fake rows + mean of the motion rows) from rowdot_bce_kernel's block partials
+__global__ void reg_final_kernel(const float* __restrict__ part, int n, float logit_reg, float weight_decay, float loss_scale,
+                                 const float* __restrict__ bce_part, int n_bce, float n_fake, float n_real, float* __restrict__ loss) {
   __shared__ float red[3][256];
+  __shared__ float red2[2][256];
+  for (int k = 0; k < 2; ++k) {
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < n_bce; i += 256) s += bce_part[k * n_bce + i];
+    red2[k][threadIdx.x] = s;
+  }
   for (int k = 0; k < 3; ++k) {
     float s = 0.0f;
     for (int i = threadIdx.x; i < n; i += 256) s += part[k * n + i];
@@ -326,13 +323,19 @@ __global__ void reg_final_kernel(const float* __restrict__ part, int n, float lo
   }
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
-    if (threadIdx.x < off)
+    if (threadIdx.x < off) {
       for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + off];
+      for (int k = 0; k < 2; ++k) red2[k][threadIdx.x] += red2[k][threadIdx.x + off];
+    }
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    loss[2] = logit_reg * red[2][0];
-    loss[3] = ((weight_decay * red[0][0]) + weight_decay * red[1][0]) + weight_decay * red[2][0];
+    loss[0] = 0.5f * (red2[0][0] / n_fake + red2[1][0] / n_real);
+    const float l2 = logit_reg * red[2][0];
+    const float l3 = ((weight_decay * red[0][0]) + weight_decay * red[1][0]) + weight_decay * red[2][0];
+    loss[2] = l2;
+    loss[3] = l3;
+    loss[4] = loss_scale * (((loss[0] + loss[1]) + l2) + l3);
   }
 }
 
@@ -462,9 +465,11 @@ __global__ __launch_bounds__(kBlock) void scaler_merge3_kernel(const double* __r
   var[c] = v;
 }
 // xs rows have a pitch of `pitch` floats (zero beyond k): batch z scaled with (mean + z * vec_stride, den + z * vec_stride)
+// ones_col >= 0: that (padding) column is 1.0 in every row -- the TT product dH1^T Xs then leaves colsum(dH1), the bias gradient
+// of layer 1, in column ones_col of gW1 for free (W1's padding columns are zero, so the forward GEMM does not see it)
 __global__ __launch_bounds__(kBlock) void scale_rows3_kernel(Batch3 b, int64_t row_stride, int64_t rows, int k, int pitch,
                                                              const float* __restrict__ mean, const float* __restrict__ den,
-                                                             int vec_stride, float clip, float* __restrict__ xs) {
+                                                             int vec_stride, float clip, float* __restrict__ xs, int ones_col) {
   const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (e >= rows * pitch) return;
   const int z = blockIdx.y;
@@ -478,6 +483,8 @@ __global__ __launch_bounds__(kBlock) void scale_rows3_kernel(Batch3 b, int64_t r
       v = (v - mean[z * vec_stride + c]) / den[z * vec_stride + c];
       v = fminf(fmaxf(v, -clip), clip);
     }
+  } else if (c == ones_col) {
+    v = 1.0f;
   }
   xs[(int64_t)z * rows * pitch + e] = v;
 }
@@ -669,8 +676,12 @@ int gemm_nt(hipStream_t st, const float* A, int64_t lda, int64_t M, const float*
 // C[M, N] (ld = ldc) (+)= A^T W with A [K, M] (row pitch lda) and W [K, N] (row pitch ldw): the weight-gradient products
 // dW = dY^T X straight on the row-major batch tensors (disc_gemm_tt_kernel: no transposed copies).  M and N are multiples
 // of 64, the row pitches multiples of 4; split-K as gemm_nt.
+// `defer`: the weight-gradient products of a weight come in pairs (prediction loss, gradient penalty): *defer == 0 on entry ->
+// this call writes its k-slices into `split` and returns their number in *defer WITHOUT summing them; *defer > 0 on entry -> this
+// call ACCUMULATES into the first min(*defer, own) slices, then the slices are summed once into C (one sum_slices launch and one
+// pass over the slices per weight instead of two).
 int gemm_tt(hipStream_t st, const float* A, int64_t lda, int M, const float* W, int64_t ldw, int N, int64_t K, float* C, int64_t ldc,
-            int accumulate, float* split) {
+            int accumulate, float* split, int* defer = nullptr) {
   if (M % 64 != 0 || N % 64 != 0 || lda % 4 != 0 || ldw % 4 != 0 || K > INT32_MAX) return kShapeNotSupported;
   GemmArgs g{};
   g.A = A; g.lda = lda; g.M = M; g.K = (int32_t)K; g.W = W; g.Kp = (int32_t)ldw; g.N = N; g.C = C; g.ldc = ldc;
@@ -683,8 +694,14 @@ int gemm_tt(hipStream_t st, const float* A, int64_t lda, int M, const float* W, 
   if (split) {
     while (slices < 16 && tiles * slices < 1024 && nk / (slices * 2) >= 16) slices *= 2;
   }
+  const int first = defer ? *defer : 0;  // slices the first product of the pair left in `split`
+  if (first > 0 && slices > first) slices = first;
+  const bool deferred = defer && slices > 1;
   if (slices > 1) {
-    g.k_slices = slices; g.slice_stride = (int64_t)M * ldc; g.C = split; g.accumulate = 0;
+    g.k_slices = slices; g.slice_stride = (int64_t)M * ldc; g.C = split; g.accumulate = first > 0 ? 1 : 0;
+  } else if (first > 0) {
+    // this product is not sliced: add it to slice 0 of the pair's first product
+    g.C = split; g.accumulate = 1;
   }
   const unsigned grid = (unsigned)(((int64_t)tiles * slices + 7) / 8 * 8);
   {
@@ -692,9 +709,12 @@ int gemm_tt(hipStream_t st, const float* A, int64_t lda, int M, const float* W, 
     disc_gemm_tt_kernel<64, 64, 16, 4><<<grid, kBlock, 0, st>>>(g);
   }
   int rc = launch_status("disc_gemm_tt_kernel");
-  if (rc != AMP_OK || slices == 1) return rc;
+  if (rc != AMP_OK) return rc;
+  if (deferred && first == 0) { *defer = slices; return AMP_OK; }  // the pair's second product sums
+  const int to_sum = first > 0 ? first : slices;
+  if (to_sum == 1 && first == 0) return AMP_OK;
   const int64_t n = (int64_t)M * ldc;
-  sum_slices_kernel<<<(unsigned)((n + kBlock - 1) / kBlock), kBlock, 0, st>>>(split, slices, n, n, C, accumulate);
+  sum_slices_kernel<<<(unsigned)((n + kBlock - 1) / kBlock), kBlock, 0, st>>>(split, to_sum, n, n, C, first > 0 ? 0 : accumulate);
   return launch_status("sum_slices_kernel");
 }
 
@@ -781,7 +801,7 @@ int amp_disc_trainer_create(AmpDisc* disc, const AmpDiscTrainCfg* cfg, const dou
                     B * p.h2 + B * p.h1 + B * t->kN + B * p.h1 + B * p.h2 +                        // a2 a1 g e1 da2
                     (int64_t)p.h1 * Bp + (int64_t)t->kN * Bp + (int64_t)p.h2 * Bp + (int64_t)p.h1 * Bp +  // a1T dgT a2T e1T
                     (int64_t)p.h1 * t->kN + p.h1 + (int64_t)p.h2 * p.h1 + p.h2 + p.h2 + 1 + 64;    // grads + loss
-  t->ws_floats = f + (int64_t)16 * p.h2 * p.h1 + (int64_t)kChunks * 1024 + 1024 + 3 * (up((int64_t)kChunks * p.in_dim * 2, 8) * 2) + 16 +
+  t->ws_floats = f + (int64_t)16 * p.h2 * p.h1 + (int64_t)16 * p.h1 * t->kN + 64 + 2 * ((M + 3) / 4) + 16 + (int64_t)kChunks * 1024 + 1024 + 3 * (up((int64_t)kChunks * p.in_dim * 2, 8) * 2) + 16 +
                  16 * 40 + 6 * up(p.k1p, 16) + M * (t->kN - p.k1p) + 2 * (int64_t)kChunks * 1024;
   if (e == hipSuccess) e = hipMalloc(&t->ws, sizeof(float) * t->ws_floats);
   if (e == hipSuccess && cfg->gemm_f16x3) {
@@ -845,6 +865,7 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
   float* H2 = take(M * H2n);
   float* logit = take(M);
   float* dlogit = take(M);
+  float* bce_part = take(2 * ((M + 3) / 4));   // rowdot_bce_kernel's block partials (alive until the step's last kernel)
   float* dH2 = take(M * H2n);
   float* dH1 = take(M * H1n);
   float* dH2T = take((int64_t)H2n * Mp);
@@ -868,6 +889,7 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
   float* gb3 = take(1);
   float* loss = take(16);  // [0] prediction, [1] gradient penalty, [2] logit reg, [3] weight decay
   float* split = take((int64_t)16 * H2n * H1n);                  // split-K partial products (largest: gW2)
+  float* split1 = take((int64_t)16 * H1n * kN);                  // ... of gW1 (both weights' slices are alive at once: deferred sums)
   float* part = take((int64_t)3 * kChunks * 1024 + 1024);      // column-sum / scalar partials (three planes: dh2_colsum_kernel)
   const int64_t dpart_stride = up((int64_t)kChunks * p.in_dim * 2, 8);                 // doubles per batch
   double* dpart = reinterpret_cast<double*>(take(3 * dpart_stride * 2 + 16));
@@ -887,6 +909,9 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
     scalar_final_kernel<<<1, 256, 0, st>>>(part, nb, scale, loss, slot, accumulate);
   };
   int rc;
+  // layer 1's bias gradient = colsum(dH1) comes out of the TT product dH1^T Xs when Xs carries a column of ones in its padding
+  // (column in_dim; needs a spare column and the TT route: the fp16-split option keeps the separate column sum)
+  const int ones_col = (t->planes[0] == nullptr && p.in_dim < kN) ? p.in_dim : -1;
   // The BACKWARD products whose shape fits run at fp32 accuracy on the fp16 matrix pipe (gemm_f16x3) when cfg.gemm_f16x3 is set;
   // the others (output width kN = 192: the W1-gradient products and g) and the two FORWARD GEMMs stay on the fp32 pipe.
   // The forward decides the ReLU masks: a pre-activation within rounding of zero flips its mask with any change of the
@@ -931,9 +956,10 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
                                                                           den32w, vec_stride);
       if (c.use_scaler) { mean32 = mean32w; den32 = den32w; clip = c.scaler_clip; vstride = vec_stride; }
     }
-    scale_rows3_kernel<<<dim3(blocks(B * kN), 3), kBlock, 0, st>>>(b3, row_stride, B, p.in_dim, kN, mean32, den32, vstride, clip, Xs);
+    scale_rows3_kernel<<<dim3(blocks(B * kN), 3), kBlock, 0, st>>>(b3, row_stride, B, p.in_dim, kN, mean32, den32, vstride, clip, Xs,
+                                                                   ones_col);
   }
-  if (c.use_scaler && c.update_scaler) {
+  if (c.use_scaler && c.update_scaler && !c.defer_refresh) {
     // the discriminator handle serves inference with the statistics after the third batch
     rc = amp_disc_set_scaler(t->disc, t->mean64, t->var64, c.scaler_epsilon, c.scaler_clip, stream);
     if (rc != AMP_OK) return rc;
@@ -946,8 +972,8 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
   if (rc != AMP_OK) return rc;
   rc = gemm_fwd(st, H1, H1n, M, p.w2, H1n, H2n, p.b2, H2);
   if (rc != AMP_OK) return rc;
-  rowdot_kernel<<<(unsigned)((M + 3) / 4), kBlock, 0, st>>>(H2, M, H2n, H2n, p.w3, p.b3, logit);
-  bce_kernel<<<1, 1024, 0, st>>>(logit, 2 * B, B, c.loss_scale, dlogit, loss);
+  const unsigned n_bce = (unsigned)((M + 3) / 4);
+  rowdot_bce_kernel<<<n_bce, kBlock, 0, st>>>(H2, M, H2n, H2n, p.w3, p.b3, 2 * B, c.loss_scale, logit, dlogit, bce_part);
 
   // ---- 3. backward of the prediction loss ----------------------------------------------------------------------
   // dH2 = dlogit (x) w3 * (H2 > 0), gw3 = H2^T dlogit, gb2 = colsum(dH2), gb3 = sum(dlogit): one pass over H2
@@ -957,19 +983,24 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
   transpose(st, p.w1p, H1n, k1p, k1p, t->w1t, H1n, kN);               // W1^T [kN, h1] (zero rows >= k1p)
   rc = nt(dH2, H2n, M, t->w2t, H2n, H1n, dH1, H1n, H1, H1n, 0);   // dH1 = (dH2 W2) * (H1 > 0)
   if (rc != AMP_OK) return rc;
-  colsum(dH1, M, H1n, H1n, nullptr, nullptr, 0, gb1, 0);
+  if (ones_col < 0) colsum(dH1, M, H1n, H1n, nullptr, nullptr, 0, gb1, 0);
   // the weight gradients reduce over the batch: the TT kernel takes both operands as the kernels above left them (rows = batch)
   // (the fp16-split option keeps its transposed-copy route: its kernel is k-contiguous by construction)
-  auto tt = [&](const float* A, int64_t lda, int Mo, const float* W, int64_t ldw, int No, int64_t Kr, float* C, int64_t ldc,
-                int acc) -> int { return f16 ? kShapeNotSupported : gemm_tt(st, A, lda, Mo, W, ldw, No, Kr, C, ldc, acc, split); };
-  rc = tt(dH2, H2n, H2n, H1, H1n, H1n, M, gW2, H1n, 0);       // gW2 = dH2^T H1
+  // each weight's two products (prediction loss, gradient penalty) share one slice sum: the first defers, the second accumulates
+  const bool pair = c.grad_penalty_scale != 0.0f;
+  int def_w1 = 0, def_w2 = 0;
+  auto tt = [&](const float* A, int64_t lda, int Mo, const float* W, int64_t ldw, int No, int64_t Kr, float* C, int64_t ldc, int acc,
+                float* sp, int* defer) -> int {
+    return f16 ? kShapeNotSupported : gemm_tt(st, A, lda, Mo, W, ldw, No, Kr, C, ldc, acc, sp, pair ? defer : nullptr);
+  };
+  rc = tt(dH2, H2n, H2n, H1, H1n, H1n, M, gW2, H1n, 0, split, &def_w2);       // gW2 = dH2^T H1
   if (rc == kShapeNotSupported) {
     transpose(st, dH2, M, H2n, H2n, dH2T, Mp, H2n);
     transpose(st, H1, M, H1n, H1n, H1T, Mp, H1n);
     rc = nt(dH2T, Mp, H2n, H1T, (int)Mp, H1n, gW2, H1n, nullptr, 0, 0, split);
   }
   if (rc != AMP_OK) return rc;
-  rc = tt(dH1, H1n, H1n, Xs, kN, kN, M, gW1, kN, 0);          // gW1 = dH1^T Xs
+  rc = tt(dH1, H1n, H1n, Xs, kN, kN, M, gW1, kN, 0, split1, &def_w1);          // gW1 = dH1^T Xs (+ gb1 in column ones_col)
   if (rc == kShapeNotSupported) {
     transpose(st, dH1, M, H1n, H1n, dH1T, Mp, H1n);
     transpose(st, Xs, M, k1p, kN, XsT, Mp, kN);
@@ -988,7 +1019,7 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
     if (rc != AMP_OK) return rc;
     // loss[1] = gp_scale * mean_rows |g|^2 ;  g <- dL/dg = (2 gp_scale loss_scale / B) g
     sumsq(g, B, p.in_dim, kN, 2.0f * c.grad_penalty_scale * c.loss_scale / (float)B, 1, c.grad_penalty_scale / (float)B, 1, 0);
-    rc = tt(a1, H1n, H1n, g, kN, kN, B, gW1, kN, 1);        // gW1 += a1^T dg
+    rc = tt(a1, H1n, H1n, g, kN, kN, B, gW1, kN, 1, split1, &def_w1);        // gW1 += a1^T dg
     if (rc == kShapeNotSupported) {
       transpose(st, a1, B, H1n, H1n, a1T, Bp, H1n);
       transpose(st, g, B, kN, kN, dgT, Bp, kN);
@@ -997,7 +1028,7 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
     if (rc != AMP_OK) return rc;
     rc = nt(g, kN, B, p.w1p, k1p, H1n, e1, H1n, H1m, H1n, 0);           // e1 = (dg W1^T) * m1   (K = k1p <= kN)
     if (rc != AMP_OK) return rc;
-    rc = tt(a2, H2n, H2n, e1, H1n, H1n, B, gW2, H1n, 1);    // gW2 += a2^T e1
+    rc = tt(a2, H2n, H2n, e1, H1n, H1n, B, gW2, H1n, 1, split, &def_w2);    // gW2 += a2^T e1
     if (rc == kShapeNotSupported) {
       transpose(st, a2, B, H2n, H2n, a2T, Bp, H2n);
       transpose(st, e1, B, H1n, H1n, e1T, Bp, H1n);
@@ -1011,12 +1042,8 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
     AMP_HIP(hipMemsetAsync(loss + 1, 0, sizeof(float), st));
   }
 
-  // ---- 5. regularisers (values for the report; their gradients are folded into the Adam kernel) ----------------
-  reg_sumsq_kernel<<<64, kBlock, 0, st>>>(p.w1p, H1n, p.in_dim, k1p, p.w2, (int64_t)H2n * H1n, p.w3, H2n, part);
-  reg_final_kernel<<<1, 256, 0, st>>>(part, 64, c.logit_reg_scale, c.weight_decay_scale, loss);
-  if (loss_dev) AMP_HIP(hipMemcpyAsync(loss_dev, loss, 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
-
-  // ---- 6. Adam -------------------------------------------------------------------------------------------------
+  // ---- 5 + 6. Adam; the regularisers' values for the report come out of the same pass over the parameters (their gradients
+  //              are folded into the update) ------------------------------------------------------------------------
   // advance the device-side state: scaler count += the batches merged above, Adam step += 1, bias corrections of this step
   train_state_kernel<<<1, 1, 0, st>>>(t->state, c.update_scaler ? 3.0 * (double)B : 0.0, (double)c.beta1, (double)c.beta2);
   const float wd2 = 2.0f * c.loss_scale * c.weight_decay_scale, lr2 = 2.0f * c.loss_scale * c.logit_reg_scale;
@@ -1024,10 +1051,12 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
   {
     AdamSegs a{};
     float* ps[6] = {p.w1p, p.b1, p.w2, p.b2, p.w3, p.b3};
-    const float* gs[6] = {gW1, gb1, gW2, gb2, gw3, gb3};
-    const int64_t ldp[6] = {k1p, H1n, H1n, H2n, H2n, 1}, ldg[6] = {kN, H1n, H1n, H2n, H2n, 1};
-    const int64_t rows_[6] = {H1n, 1, H2n, 1, 1, 1};
-    const int cols_[6] = {p.in_dim, H1n, H1n, H2n, H2n, 1};
+    // b1's gradient: gb1, or column ones_col of gW1 (one element per row of gW1)
+    const bool col = ones_col >= 0;
+    const float* gs[6] = {gW1, col ? gW1 + ones_col : gb1, gW2, gb2, gw3, gb3};
+    const int64_t ldp[6] = {k1p, col ? 1 : H1n, H1n, H2n, H2n, 1}, ldg[6] = {kN, col ? kN : H1n, H1n, H2n, H2n, 1};
+    const int64_t rows_[6] = {H1n, col ? H1n : 1, H2n, 1, 1, 1};
+    const int cols_[6] = {p.in_dim, col ? 1 : H1n, H1n, H2n, H2n, 1};
     const float reg[6] = {wd2, 0.0f, wd2, 0.0f, wd2 + lr2, 0.0f};
     a.start[0] = 0;
     for (int k = 0; k < 6; ++k) {
@@ -1035,11 +1064,26 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
       a.ld_p[k] = ldp[k]; a.ld_g[k] = ldg[k]; a.cols[k] = cols_[k]; a.reg2[k] = reg[k];
       a.start[k + 1] = a.start[k] + rows_[k] * cols_[k];
     }
-    adam_multi_kernel<<<blocks(a.start[6]), kBlock, 0, st>>>(a, lr, c.beta1, c.beta2, c.adam_epsilon, t->state, grads_dev);
+    const unsigned nb = blocks(a.start[6]);
+    AMP_REQUIRE((int64_t)3 * nb <= (int64_t)3 * kChunks * 1024 + 1024, "amp_disc_train_step: too many Adam blocks for the partials buffer");
+    adam_multi_kernel<<<nb, kBlock, 0, st>>>(a, lr, c.beta1, c.beta2, c.adam_epsilon, t->state, grads_dev, part);
+    reg_final_kernel<<<1, 256, 0, st>>>(part, (int)nb, c.logit_reg_scale, c.weight_decay_scale, c.loss_scale, bce_part, (int)n_bce,
+                                        (float)(2 * B), (float)B, loss);
+    if (loss_dev) AMP_HIP(hipMemcpyAsync(loss_dev, loss, 5 * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
   rc = launch_status("adam_multi_kernel");
   if (rc != AMP_OK) return rc;
-  return c.apply_update ? disc_refresh_derived(t->disc, st) : AMP_OK;
+  return (c.apply_update && !c.defer_refresh) ? disc_refresh_derived(t->disc, st) : AMP_OK;
+}
+
+int amp_disc_trainer_refresh(AmpDiscTrainer* t, amp_stream_t stream) {
+  AMP_REQUIRE(t, "amp_disc_trainer_refresh: null handle");
+  const AmpDiscTrainCfg& c = t->cfg;
+  if (c.use_scaler && c.update_scaler) {
+    const int rc = amp_disc_set_scaler(t->disc, t->mean64, t->var64, c.scaler_epsilon, c.scaler_clip, stream);
+    if (rc != AMP_OK) return rc;
+  }
+  return c.apply_update ? disc_refresh_derived(t->disc, (hipStream_t)stream) : AMP_OK;
 }
 
 }  // extern "C"

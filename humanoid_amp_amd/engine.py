@@ -618,7 +618,8 @@ class AmpDiscriminatorTrainer:
                  discriminator_gradient_penalty_scale: float = 5.0, discriminator_weight_decay_scale: float = 1e-4,
                  betas=(0.9, 0.999), adam_epsilon: float = 1e-8, use_scaler: bool = True, update_scaler: bool = True,
                  running_mean: Optional[torch.Tensor] = None, running_variance: Optional[torch.Tensor] = None,
-                 current_count: float = 1.0, apply_update: bool = True, gemm_precision: str = "f32"):
+                 current_count: float = 1.0, apply_update: bool = True, gemm_precision: str = "f32",
+                 defer_refresh: bool = False):
         """``gemm_precision``: "f32" (default) runs every GEMM on the fp32 matrix pipe; "f16x3" runs the large BACKWARD
         products at fp32 accuracy on the fp16 matrix pipe (two fp16 planes per operand, three MFMAs per product -- the
         inference path's engine).  Same gradients to 1e-6, but at BASELINE's minibatch (3 x 4 096 rows) the extra operand
@@ -637,6 +638,10 @@ class AmpDiscriminatorTrainer:
         c.scaler_epsilon, c.scaler_clip = disc.epsilon, disc.clip_threshold
         c.use_scaler, c.update_scaler, c.apply_update = int(use_scaler), int(update_scaler), int(apply_update)
         c.gemm_f16x3 = int(gemm_precision == "f16x3")
+        # defer_refresh: the steps skip refreshing what the discriminator derives from its weights / scaler for INFERENCE (fp16
+        # planes, plane scales, fp32 scaler vectors: ~45 us of small launches per step); call refresh() before the next style reward
+        c.defer_refresh = int(bool(defer_refresh))
+        self.defer_refresh = bool(defer_refresh)
         self.loss_scale = float(discriminator_loss_scale)
         m = None if running_mean is None else running_mean.detach().to(device=self.device, dtype=torch.float64).contiguous()
         v = None if running_variance is None else running_variance.detach().to(device=self.device, dtype=torch.float64).contiguous()
@@ -670,7 +675,7 @@ class AmpDiscriminatorTrainer:
                     or t.stride(0) != policy_states.stride(0):
                 raise nat.AmpEngineError(f"{name}_states must be float32 [B, {self.disc.in_dim}] with the same row stride")
             nat.require_gpu(t.device)
-        loss = torch.empty(4, dtype=torch.float32, device=self.device)
+        loss = torch.empty(5, dtype=torch.float32, device=self.device)  # four terms + the scaled total
         grads = torch.empty(self._n_params, dtype=torch.float32, device=self.device) if want_grads else None
         with torch.cuda.device(self.device):
             nat.check(self._lib.amp_disc_train_step(self._handle, C.c_void_p(policy_states.data_ptr()),
@@ -678,10 +683,16 @@ class AmpDiscriminatorTrainer:
                                                     int(policy_states.stride(0)), nat.dptr(loss), nat.dptr(grads), nat.stream_ptr()),
                       "amp_disc_train_step")
         out = dict(zip(self.LOSS_TERMS, loss.unbind(0)))
-        out["loss"] = self.loss_scale * loss.sum()
+        out["loss"] = loss[4]  # loss_scale * (sum of the four terms), formed on the device by the step's last kernel
         if want_grads:
             out["grads"] = grads
         return out
+
+    def refresh(self) -> None:
+        """With ``defer_refresh=True``: bring the attached discriminator's inference-side data (fp16 weight planes, plane scales,
+        scaler vectors) up to date with the trained weights -- once per agent update instead of once per training step."""
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.amp_disc_trainer_refresh(self._handle, nat.stream_ptr()), "amp_disc_trainer_refresh")
 
     def capture(self, want_grads: bool = False):
         """Capture the training step into a hipGraph over static input buffers (``self.static_inputs`` = policy, replay,
@@ -825,4 +836,6 @@ class AmpDiscriminatorUpdate:
                 if self.record_batches:
                     self.batches.append((policy.clone(), replay.clone(), motion.clone()))
         self.replay.add_samples(rows)
+        if getattr(self.trainer, "defer_refresh", False):
+            self.trainer.refresh()  # the rollouts that follow score with the trained weights
         return losses

@@ -518,6 +518,12 @@ typedef struct {
   int32_t gemm_f16x3;           /* 0 (default, also what a zero-initialised struct gets): every GEMM on the fp32 matrix pipe -- the
                                  * faster choice at 3 x 4 096 rows; 1: opt in to the large backward products at fp32 accuracy on the
                                  * fp16 matrix pipe (two fp16 planes per operand, three MFMAs per product, like the inference path) */
+  int32_t defer_refresh;        /* 0 (default): every step ends by refreshing what the attached AmpDisc derives from its weights / scaler
+                                 * for INFERENCE (fp16 planes, plane scales, fp32 scaler vectors: ~45 us of small launches); 1: the
+                                 * steps leave them stale (the handle is then IN BETWEEN -- trained biases, old weight planes -- and
+                                 * must not score) and the caller runs amp_disc_trainer_refresh() once before the next style-reward
+                                 * call -- skrl's AMP._update runs 12 training steps between two rollouts */
+  int32_t reserved;
 } AmpDiscTrainCfg;
 
 /* The trainer updates `disc`'s weights (and, with use_scaler, its scaler) in place; `disc` must outlive it.
@@ -526,12 +532,14 @@ int amp_disc_trainer_create(AmpDisc* disc, const AmpDiscTrainCfg* cfg, const dou
                             const double* running_variance_dev, double current_count, amp_stream_t stream,
                             AmpDiscTrainer** out);
 int amp_disc_trainer_destroy(AmpDiscTrainer* t);
+/* With cfg.defer_refresh: bring the attached AmpDisc's inference-side derived data up to date with the trained weights / scaler. */
+int amp_disc_trainer_refresh(AmpDiscTrainer* t, amp_stream_t stream);
 /* Copies the running statistics (fp64 [in_dim]) into caller-owned device buffers; *count (host) = samples seen. */
 int amp_disc_trainer_scaler(const AmpDiscTrainer* t, double* mean_out_dev, double* var_out_dev, double* count,
                             amp_stream_t stream);
 /* One step on three batches of `rows` raw AMP observations each ([rows, in_dim], row stride in elements).
- * loss_dev (may be NULL): [4] = prediction, gradient penalty, logit regularisation, weight decay (unscaled terms;
- * total = loss_scale * sum).  grads_dev (may be NULL): dL/d(W1, b1, W2, b2, W3, b3) concatenated, logical shapes. */
+ * loss_dev (may be NULL): [5] = prediction, gradient penalty, logit regularisation, weight decay (unscaled terms) and
+ * [4] = loss_scale * their sum (skrl's discriminator_loss).  grads_dev (may be NULL): dL/d(W1, b1, W2, b2, W3, b3) concatenated, logical shapes. */
 int amp_disc_train_step(AmpDiscTrainer* t, const float* policy_dev, const float* replay_dev, const float* motion_dev,
                         int64_t rows, int64_t row_stride, float* loss_dev, float* grads_dev, amp_stream_t stream);
 

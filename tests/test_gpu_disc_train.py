@@ -161,3 +161,30 @@ def test_captured_training_step_equals_eager():
     assert torch.equal(me, mg) and torch.equal(ve, vg) and ce == cg == 1.0 + 7 * 3 * B
     x = batches[0][0]
     assert torch.equal(d_e.style_reward(x)["style"], d_g.style_reward(x)["style"])  # the inference planes followed
+
+
+def test_deferred_refresh_gives_the_same_discriminator():
+    """defer_refresh=True: the steps leave the discriminator's inference-side derived data stale; after refresh() the handle
+    scores exactly like one trained with the default per-step refresh (same weights, same scaler, same planes)."""
+    from humanoid_amp_amd.engine import AmpDiscriminator, AmpDiscriminatorTrainer
+    from humanoid_amp_amd.workloads import make_disc_weights
+
+    B, dim = 512, 166
+    gen = torch.Generator().manual_seed(6)
+    batches = [[(torch.randn(B, dim, generator=gen) * (1.0 + 0.2 * k)).cuda() for k in range(3)] for _ in range(4)]
+    x = (torch.randn(3000, dim, generator=gen) * 1.3).cuda()   # the LDS-DMA-free register-staged plan; planes are used either way
+    outs = []
+    for defer in (False, True):
+        disc = AmpDiscriminator(make_disc_weights(dim, seed=2), "cuda:0")
+        tr = AmpDiscriminatorTrainer(disc, batch_size=B, learning_rate=2e-3, defer_refresh=defer)
+        before = disc.style_reward(x)["style"].clone()
+        for b in batches:
+            tr.step(*b)
+        if defer:
+            # until refresh() the handle is in between (trained biases / output layer, weight planes and scaler vectors from
+            # before the training): its scores are undefined and must not be used -- only finite
+            assert bool(torch.isfinite(disc.style_reward(x)["style"]).all())
+            tr.refresh()
+        outs.append(disc.style_reward(x, want_logits=True))
+    assert torch.equal(outs[0]["logits"], outs[1]["logits"]) and torch.equal(outs[0]["style"], outs[1]["style"])
+    assert not torch.equal(outs[0]["style"], before)
