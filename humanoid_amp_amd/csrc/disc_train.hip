@@ -306,36 +306,41 @@ __global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamSegs a, float lr
 
 // loss[2] = logit_reg * sum w3^2 ; loss[3] = weight_decay * (sum W1^2 + sum W2^2 + sum w3^2)
 // ... and loss[4] = loss_scale * (((loss[0] + loss[1]) + loss[2]) + loss[3]): the step's scaled total (skrl's discriminator_loss)
-// ... and loss[0] = 0.5 * (mean BCE term of the fake rows + mean of the motion rows) from rowdot_bce_kernel's block partials
-__global__ void reg_final_kernel(const float* __restrict__ part, int n, float logit_reg, float weight_decay, float loss_scale,
-                                 const float* __restrict__ bce_part, int n_bce, float n_fake, float n_real, float* __restrict__ loss) {
-  __shared__ float red[3][256];
-  __shared__ float red2[2][256];
-  for (int k = 0; k < 2; ++k) {
-    float s = 0.0f;
-    for (int i = threadIdx.x; i < n_bce; i += 256) s += bce_part[k * n_bce + i];
-    red2[k][threadIdx.x] = s;
+// ... and loss[0] = 0.5 * (mean BCE term of the fake rows + mean of the motion rows) from rowdot_bce_kernel's block partials.
+// One block of 1 024 lanes: the five partial arrays (~2 700 + ~3 100 entries each) are two or three independent loads per lane
+// (256 lanes walked them in 11 dependent trips: 15 us).
+constexpr int kFinalBlock = 1024;
+__global__ __launch_bounds__(kFinalBlock) void reg_final_kernel(const float* __restrict__ part, int n, float logit_reg,
+                                                                float weight_decay, float loss_scale,
+                                                                const float* __restrict__ bce_part, int n_bce, float n_fake,
+                                                                float n_real, float* __restrict__ loss) {
+  __shared__ float red[5][kFinalBlock];
+  float s[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  for (int i = threadIdx.x; i < n; i += kFinalBlock) {
+    s[0] += part[i];
+    s[1] += part[n + i];
+    s[2] += part[2 * n + i];
   }
-  for (int k = 0; k < 3; ++k) {
-    float s = 0.0f;
-    for (int i = threadIdx.x; i < n; i += 256) s += part[k * n + i];
-    red[k][threadIdx.x] = s;
+  for (int i = threadIdx.x; i < n_bce; i += kFinalBlock) {
+    s[3] += bce_part[i];
+    s[4] += bce_part[n_bce + i];
   }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) red[k][threadIdx.x] = s[k];
   __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (threadIdx.x < off) {
-      for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + off];
-      for (int k = 0; k < 2; ++k) red2[k][threadIdx.x] += red2[k][threadIdx.x + off];
-    }
+  for (int off = kFinalBlock / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off)
+      for (int k = 0; k < 5; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + off];
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    loss[0] = 0.5f * (red2[0][0] / n_fake + red2[1][0] / n_real);
+    const float l0 = 0.5f * (red[3][0] / n_fake + red[4][0] / n_real);
     const float l2 = logit_reg * red[2][0];
     const float l3 = ((weight_decay * red[0][0]) + weight_decay * red[1][0]) + weight_decay * red[2][0];
+    loss[0] = l0;
     loss[2] = l2;
     loss[3] = l3;
-    loss[4] = loss_scale * (((loss[0] + loss[1]) + l2) + l3);
+    loss[4] = loss_scale * (((l0 + loss[1]) + l2) + l3);
   }
 }
 
@@ -446,7 +451,8 @@ __global__ __launch_bounds__(kBlock) void scaler_merge3_kernel(const double* __r
     const double count = state->count + (double)g * n;
     const double* pg = part + (int64_t)g * part_stride;
     double s = 0.0, q = 0.0;
-    for (int ch = 0; ch < kChunks; ++ch) {
+#pragma unroll 16
+    for (int ch = 0; ch < kChunks; ++ch) {  // summed in chunk order; unrolled so that the loads are in flight together
       s += pg[((int64_t)ch * cols + c) * 2 + 0];
       q += pg[((int64_t)ch * cols + c) * 2 + 1];
     }
@@ -1067,7 +1073,7 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
     const unsigned nb = blocks(a.start[6]);
     AMP_REQUIRE((int64_t)3 * nb <= (int64_t)3 * kChunks * 1024 + 1024, "amp_disc_train_step: too many Adam blocks for the partials buffer");
     adam_multi_kernel<<<nb, kBlock, 0, st>>>(a, lr, c.beta1, c.beta2, c.adam_epsilon, t->state, grads_dev, part);
-    reg_final_kernel<<<1, 256, 0, st>>>(part, (int)nb, c.logit_reg_scale, c.weight_decay_scale, c.loss_scale, bce_part, (int)n_bce,
+    reg_final_kernel<<<1, kFinalBlock, 0, st>>>(part, (int)nb, c.logit_reg_scale, c.weight_decay_scale, c.loss_scale, bce_part, (int)n_bce,
                                         (float)(2 * B), (float)B, loss);
     if (loss_dev) AMP_HIP(hipMemcpyAsync(loss_dev, loss, 5 * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
