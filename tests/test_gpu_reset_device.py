@@ -210,3 +210,33 @@ def test_captured_step_equals_eager(task):
             assert torch.equal(getattr(eager.robot.data, k), getattr(graph.robot.data, k)), k
         n_reset += int((te | oe_t).sum())
     assert n_reset > 100
+
+
+def test_scatter_rows_equals_index_assignment():
+    """amp_scatter_rows: `dst[ids[i]] = src[i]` for i < count (count on the device) against torch's index assignment: plain
+    rows, a fill, a per-body repeat with an added offset table, a strided destination; count = 0 and count = capacity."""
+    from humanoid_amp_amd.engine import RowScatter
+
+    N, nb = 1000, 7
+    gen = torch.Generator().manual_seed(9)
+    for n_valid in (0, 1, 137, N):
+        perm = torch.randperm(N, generator=gen)
+        ids = torch.cat([perm[:n_valid].sort().values, torch.full((N - n_valid,), -5)]).cuda()   # entries past count are junk
+        count = torch.tensor([n_valid], dtype=torch.int64, device="cuda")
+        src_a, src_b = torch.randn(N, 29, generator=gen).cuda(), torch.randn(N, 13, generator=gen).cuda()
+        off = torch.randn(nb, 3, generator=gen).cuda()
+        dst = dict(a=torch.randn(N, 29, generator=gen).cuda(), fill=torch.randn(N, 29, generator=gen).cuda(),
+                   body=torch.randn(N, nb, 3, generator=gen).cuda(), quat=torch.randn(N, nb, 4, generator=gen).cuda(),
+                   wide=torch.randn(N, 40, generator=gen).cuda())
+        want = {k: v.clone() for k, v in dst.items()}
+        sel = ids[:n_valid]
+        want["a"][sel] = src_a[:n_valid]
+        want["fill"][sel] = 2.5
+        want["body"][sel] = src_b[:n_valid, None, 0:3] + off[None]
+        want["quat"][sel] = src_b[:n_valid, None, 3:7].expand(-1, nb, -1)
+        want["wide"][sel, :29] = src_a[:n_valid]                                     # a [N, 29] view of wider rows
+        RowScatter([dict(dst=dst["a"], src=src_a), dict(dst=dst["fill"], fill=2.5),
+                    dict(dst=dst["body"], src=src_b[:, 0:3], repeat=nb, add=off), dict(dst=dst["quat"], src=src_b[:, 3:7], repeat=nb),
+                    dict(dst=dst["wide"][:, :29], src=src_a)], ids, count)()
+        for k in dst:
+            assert torch.equal(dst[k], want[k]), (n_valid, k)
