@@ -308,7 +308,7 @@ __device__ __forceinline__ void env_step_body(const EnvPlan& p, const AmpSimStat
 
 // ------------------------------------------------------------------------------------------------
 // DMA tile body -- any phase subset (the hot path launches all three at once; the DirectRLEnv hooks launch DONES | REWARD
-// before the reset and OBS after it), any K >= 1, no actor history, whole tiles (checked on the host; anything else runs the
+// before the reset and OBS after it), any K >= 1, with or without actor history, whole tiles (checked on the host; anything else runs the
 // generic body).  Same arithmetic as the generic body, bit for bit.  The generic body
 // spends ~40 VALU instructions per output float on row/column splits, 64-bit addressing and 4-B stores and is bound by
 // instruction issue, and so was its first replacement (registers -> LDS scatter, ~1 900 VALU instructions per lane
@@ -639,8 +639,8 @@ __device__ __forceinline__ void env_step_dma_pass(const EnvPlan& p, const AmpSim
     if (scaled) { if (blocks) walk(yes{}, yes{}); else walk(yes{}, no{}); }
     else { if (blocks) walk(no{}, yes{}); else walk(no{}, no{}); }
   }
-  {  // policy observation (g1_amp_env.py:195-242; humanoid_amp_env.py:126), P == Pcur (no actor history here)
-    const int P = p.P, Db = p.Db;
+  {  // policy observation (g1_amp_env.py:195-242; humanoid_amp_env.py:126): Pcur current columns of a P-float row
+    const int P = p.P, Pcur = p.Pcur, Db = p.Db;
     float* pol = bf.policy_obs + tile_base * P;
     const int la_off = (int)(s_la - smem), cmd_off = (int)(s_cmd - smem);
     auto source = [&](const int c, int& src_pitch) -> const float* {  // LDS column c of the policy row (selects, no table)
@@ -648,7 +648,7 @@ __device__ __forceinline__ void env_step_dma_pass(const EnvPlan& p, const AmpSim
       src_pitch = in_img ? KD : (in_la ? nd : 2);
       return smem + (in_img ? c : (in_la ? la_off + (c - Db) : cmd_off + (c - Db - nd)));
     };
-    if ((P & 1) == 0) {
+    if (((P | Pcur) & 1) == 0) {
       auto column_pair = [&](const int c, const int r0, const int step) {
         int pa, pb;
         const float* a = source(c, pa);
@@ -664,7 +664,7 @@ __device__ __forceinline__ void env_step_dma_pass(const EnvPlan& p, const AmpSim
           __builtin_nontemporal_store(o, reinterpret_cast<env_f2*>(dst));
         }
       };
-      const int PR = P >> 1;
+      const int PR = Pcur >> 1;
       if (PR >= kBlock) {
         for (int c2 = tid; c2 < PR; c2 += kBlock) column_pair(2 * c2, 0, 1);
       } else {
@@ -678,12 +678,53 @@ __device__ __forceinline__ void env_step_dma_pass(const EnvPlan& p, const AmpSim
         float* dst = pol + (int64_t)r0 * P + c;
         for (int r = r0; r < T; r += step, a += step * pa, dst += step * P) __builtin_nontemporal_store(*a, dst);
       };
-      if (P >= kBlock) {
-        for (int c = tid; c < P; c += kBlock) column(c, 0, 1);
+      if (Pcur >= kBlock) {
+        for (int c = tid; c < Pcur; c += kBlock) column(c, 0, 1);
       } else {
-        const int G = kBlock / P, g = row_of(tid, 1.0f / (float)P);
-        if (g < G) column(tid - g * P, g, G);
+        const int G = kBlock / Pcur, g = row_of(tid, 1.0f / (float)Pcur);
+        if (g < G) column(tid - g * Pcur, g, G);
       }
+    }
+    if (p.n_actor > 1) {
+      // actor history (g1_amp_env.py:207-242): H = n_actor - 1 older frames of `per` floats behind the current columns.  A
+      // lane owns one column of the frame [obs[:Db] | last_actions? | command?] (per-lane constant LDS source) and steps down
+      // the tile's rows: shift the env's slots one back in place (a freshly reset env fills them all with its first frame,
+      // :216-222) and mirror them into the policy row.  Same copies as the generic body.
+      const int per = p.per, H = p.n_actor - 1;
+      const int la_h = p.hist_actions ? nd : 0;
+      auto column = [&](const int c, const int r0, const int step) {
+        const bool in_img = c < Db, in_la = c < Db + la_h;
+        const int pa = in_img ? KD : (in_la ? nd : 2);
+        const float* a = smem + (in_img ? c : (in_la ? la_off + (c - Db) : cmd_off + (c - Db - la_h))) + r0 * pa;
+        for (int r = r0; r < T; r += step, a += step * pa) {
+          const float hv = *a;
+          const int64_t env = tile_base + r;
+          float* hb = bf.actor_history + (env * H) * per + c;
+          float* po = pol + (int64_t)r * P + Pcur + c;
+          if (bf.just_reset[env]) {
+            for (int i = 0; i < H; ++i) {
+              hb[(int64_t)i * per] = hv;
+              __builtin_nontemporal_store(hv, po + (int64_t)i * per);
+            }
+          } else {
+            for (int i = H - 2; i >= 0; --i) {
+              const float x = hb[(int64_t)i * per];
+              hb[(int64_t)(i + 1) * per] = x;
+              __builtin_nontemporal_store(x, po + (int64_t)(i + 1) * per);
+            }
+            hb[0] = hv;
+            __builtin_nontemporal_store(hv, po);
+          }
+        }
+      };
+      if (per >= kBlock) {
+        for (int c = tid; c < per; c += kBlock) column(c, 0, 1);
+      } else {
+        const int G = kBlock / per, g = row_of(tid, 1.0f / (float)per);
+        if (g < G) column(tid - g * per, g, G);
+      }
+      __syncthreads();  // every lane has read its rows' flags
+      if (tid < T) bf.just_reset[tile_base + tid] = 0;
     }
   }
 }
@@ -892,12 +933,12 @@ static int env_step_launch(const AmpEnvCfg* cfg, const AmpSimState* st, const Am
   // tile, and every other configuration, runs the generic body.
   auto aligned = [](const void* ptr, uintptr_t a) { return (reinterpret_cast<uintptr_t>(ptr) & (a - 1)) == 0; };
   auto rows16 = [&](const float* ptr, int64_t stride) { return stride == p.n_dof && aligned(ptr, 16); };
-  // DMA tile body: any phase subset, no actor history, whole tiles, K*D even; the alignment conditions of a phase's inputs
+  // DMA tile body: any phase subset, whole tiles, K*D even; the alignment conditions of a phase's inputs
   // and outputs apply only when that phase is asked for
   const int KD = p.K * p.D;
   const bool obs = phases & AMP_PHASE_OBS;
   const size_t lds_dma = sizeof(float) * (size_t)env_dma_lds_floats(tile, KD, p.n_dof, per_env_limits, obs);
-  bool dma = p.n_actor == 1 && (KD & 1) == 0 && N >= tile && lds_dma <= 64 * 1024;
+  bool dma = (KD & 1) == 0 && N >= tile && lds_dma <= 64 * 1024;
   if (dma && g1_rew) dma = rows16(st->actions, st->actions_stride) && rows16(st->joint_acc, st->joint_acc_stride);
   if (dma && obs) {
     dma = aligned(bf->amp_obs_buffer, 16) && aligned(bf->policy_obs, 8);

@@ -280,6 +280,62 @@ def test_dma_tile_body_matches_generic_body(N, K, nd, precision):
     assert a.disc_input.abs().sum() > 0
 
 
+@pytest.mark.parametrize("N,K,n_actor,hist_actions,hist_command,track", [
+    (4100, 10, 2, True, True, 1.0),     # the Deploy task's shape (g1_amp_env_cfg.py:160-206): 8-env tiles, ragged tail
+    (40000, 2, 3, True, True, 1.0),     # two older frames, 32-env tiles
+    (3000, 2, 4, False, False, 1.0),    # ablated history frame (odd width: scalar stores), 16-env tiles
+    (2500, 3, 2, True, True, 0.0),      # no command anywhere
+    (1000, 2, 3, False, True, 1.0),     # command without last actions in the history frame
+])
+def test_dma_tile_body_actor_history_matches_generic_body(N, K, n_actor, hist_actions, hist_command, track):
+    """Actor history (g1_amp_env.py:207-242) in the DMA tile body: shift / warm start of the per-env history slots and their
+    mirror in the policy row, against the generic body (row-strided inputs) over three steps with random just-reset flags."""
+    from humanoid_amp_amd.engine import EnvStepConfig, EnvStepKernel
+    from humanoid_amp_amd import _native as nat
+
+    nd = 29
+    g = torch.Generator(device="cuda").manual_seed(N + n_actor)
+    r = lambda *s: torch.randn(*s, generator=g, device="cuda")  # noqa: E731
+    cfg = EnvStepConfig(n_dof=nd, num_amp_observations=K, max_episode_length=300, rew_termination=-1.0, rew_action_l2=-0.1,
+                        rew_joint_pos_limits=-10.0, rew_joint_acc_l2=-1e-6, rew_joint_vel_l2=-1e-3, rew_track_vel=track,
+                        num_actor_observations=n_actor, history_include_last_actions=hist_actions,
+                        history_include_command=hist_command)
+    D = cfg.amp_frame_size
+    a, b = EnvStepKernel(cfg, N, "cuda:0"), EnvStepKernel(cfg, N, "cuda:0")
+    init, hist0 = r(N, K, D), r(*a.actor_obs_history_buffer.shape)
+    for k in (a, b):
+        k.amp_observation_buffer.copy_(init)
+        k.actor_obs_history_buffer.copy_(hist0)
+    for step in range(3):
+        st = dict(joint_pos=r(N, nd), joint_vel=r(N, nd), joint_acc=r(N, nd) * 30, actions=r(N, nd) * 0.5,
+                  root_pos=torch.cat([r(N, 2), torch.rand(N, 1, generator=g, device="cuda") * 0.6 + 0.35], 1).contiguous(),
+                  root_quat=torch.nn.functional.normalize(r(N, 4), dim=1), root_lin_vel=r(N, 3), root_ang_vel=r(N, 3),
+                  body_pos=r(N, 4, 3), key_body_indexes=[0, 1, 2, 3], soft_limits=torch.tensor([[-1.41, 1.41]] * nd, device="cuda"),
+                  episode_length=torch.randint(0, 300, (N,), generator=g, device="cuda"), command=r(N, 2), last_actions=r(N, nd))
+        strided = dict(st)
+        for name in ("joint_acc", "actions"):  # [N, nd] views of [N, nd + 3] rows: the generic body
+            wide = torch.zeros(N, nd + 3, device="cuda")
+            wide[:, :nd] = st[name]
+            strided[name] = wide[:, :nd]
+        flags = (torch.rand(N, generator=g, device="cuda") < (1.0 if step == 0 else 0.1))
+        old = a.actor_obs_history_buffer.clone()
+        for k, s in ((a, st), (b, strided)):
+            k.just_reset_mask.copy_(flags)
+            k.launch(nat.AMP_PHASE_ALL, **s)
+        for name in ("amp_observation_buffer", "policy_obs", "actor_obs_history_buffer", "reward", "died", "time_out"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), (step, name)
+        assert not bool(a.just_reset_mask.any()) and not bool(b.just_reset_mask.any())
+        # the semantics themselves: slot 0 = this step's frame, older slots shifted (or all = the frame after a reset)
+        H, per, Pcur = n_actor - 1, a.actor_obs_history_buffer.shape[-1], a.policy_obs.shape[1] - (n_actor - 1) * a.actor_obs_history_buffer.shape[-1]
+        hb = a.actor_obs_history_buffer.view(N, H, per)
+        assert torch.equal(a.policy_obs[:, Pcur:].reshape(N, H, per), hb)
+        assert torch.equal(hb[:, 0, :D - 12], a.policy_obs[:, :D - 12])
+        keep = ~flags
+        for i in range(1, H):
+            assert torch.equal(hb[keep, i], old.view(N, H, per)[keep, i - 1])
+            assert torch.equal(hb[flags, i], hb[flags, 0])
+
+
 @pytest.mark.parametrize("nd,n_key,K,last_actions,reward_mode,track,N", [
     (5, 1, 4, True, 1, 1.0, 1000),      # tiny rows, one key body, K = 4
     (64, 8, 2, True, 1, 0.0, 2000),     # 64 DoFs, the maximum of key bodies, odd policy width, no command

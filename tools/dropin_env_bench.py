@@ -19,9 +19,9 @@ from humanoid_amp_amd import _native as nat
 
 def dropin_env_step(num_envs: int, steps: int = 50, warmup: int = 10, physics: bool = True, task: str = "walk",
                     device: str = "cuda:0", graph: bool = False):
-    from humanoid_amp_amd.envs import G1AmpEnv, G1AmpDanceEnvCfg, G1AmpWalkEnvCfg
+    from humanoid_amp_amd.envs import G1AmpEnv, G1AmpDanceEnvCfg, G1AmpDeployEnvCfg, G1AmpWalkEnvCfg
 
-    cfg = {"walk": G1AmpWalkEnvCfg, "dance": G1AmpDanceEnvCfg}[task]()
+    cfg = {"walk": G1AmpWalkEnvCfg, "dance": G1AmpDanceEnvCfg, "deploy": G1AmpDeployEnvCfg}[task]()
     cfg.scene.num_envs = int(num_envs)
     cfg.sim.device = device
     with contextlib.redirect_stdout(io.StringIO()):
@@ -82,10 +82,11 @@ def hotpath_env_launch(num_envs: int, workload: str = "g1_walk", device: str = "
 
 if __name__ == "__main__":
     sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [4096, 8192, 65536]
+    task = next((a for a in sys.argv[1:] if a in ("walk", "dance", "deploy")), "walk")
     for n in sizes:
         for physics, graph in ((True, False), (False, False), (True, True), (False, True)):
             try:
-                print(json.dumps(dropin_env_step(n, physics=physics, graph=graph)), flush=True)
+                print(json.dumps(dropin_env_step(n, physics=physics, graph=graph, task=task)), flush=True)
             except Exception as e:  # e.g. a torch build that cannot capture a custom generator
                 print(json.dumps({"envs": n, "physics": physics, "graph": graph, "error": repr(e)[:300]}), flush=True)
         print(json.dumps({"envs": n, "hotpath_kernels_us": hotpath_env_launch(n)}), flush=True)
