@@ -18,6 +18,8 @@
 // clamp an abs-max pass over the scaled input supplies it), |W| <= max |W|, |H1| <= max_j sum_k |W1[j,k]| * bound_x +
 // max |b1|.  A loose bound costs nothing (fp16 keeps 2^-11 relative precision over 2^30 below the bound), and results
 // do not depend on which other rows share the batch.
+#include <algorithm>
+
 #include "disc_gemm.hpp"
 #include "disc_gemm_f16.hpp"
 #include "disc_gemm_f16_dma.hpp"
@@ -344,13 +346,29 @@ static int launch_f16(GemmF16Args g, int64_t rows, int N, const char* name, hipS
   disc_gemm_f16_kernel<TM, TN, BK, MODE, MINW><<<grid, kBlock, gemm_f16_lds_bytes<TM, TN, BK>(), st>>>(g);
   return launch_status(name);
 }
+// CUs of the current device, rounded down to a multiple of 8 (the tile order of a persistent grid keeps a workgroup's tiles on
+// its XCD only when the grid is a multiple of 8); cached per device
+static int dma_cu_count() {
+  static int cus[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (!cus[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+    cus[dev] = n / 8 * 8;
+  }
+  return cus[dev];
+}
 // LDS-DMA launch of one layer on a (64 TM) x (128 TN) tile (block-layout operands)
 template <int MODE, int TM, int TN, int KB2 = 0>
 static int launch_dma(GemmF16Args g, int64_t rows, int N, const char* name, hipStream_t st) {
   using T = DmaTile<TM, TN, KB2 ? KB2 : 2>;
   g.n_tiles = N / T::BN;
   g.m_tiles = (int)((rows + T::BM - 1) / T::BM);
-  const unsigned grid = (unsigned)(((int64_t)g.m_tiles * g.n_tiles + 7) / 8 * 8);
+  unsigned grid = (unsigned)(((int64_t)g.m_tiles * g.n_tiles + 7) / 8 * 8);
+  // layer 1 (MODE 0): persistent workgroups -- one per LDS slot of the chip, each walking its tiles vb, vb + grid, ... with the
+  // next tile's first k-blocks in flight under the current tile's epilogue (no 3-us workgroup hand-over, no exposed first fill)
+  if (MODE == 0) grid = std::min(grid, (unsigned)(dma_cu_count() * T::kWgPerCu));
   amp::TraceScope trace__(name, st);
   disc_gemm_f16_dma_kernel<MODE, TM, TN, KB2><<<grid, kDmaThreads, T::kLds, st>>>(g);
   return launch_status(name);

@@ -133,14 +133,20 @@ static __global__ __launch_bounds__(kBlock) void split_rows_f16_kernel(const flo
   *reinterpret_cast<h4*>(&dst[plane + r * ld_dst + c]) = p1;
 }
 
-__device__ __forceinline__ bool f16_tile_of_block(const GemmF16Args& g, int& mt, int& nt) {
+// `b`: the (virtual) block index -- blockIdx.x, or blockIdx.x + i * gridDim.x for the i-th tile of a persistent workgroup
+// (gridDim.x is a multiple of 8, so every tile of a workgroup belongs to the XCD the workgroup runs on)
+__device__ __forceinline__ bool f16_tile_of_block(const GemmF16Args& g, unsigned b, int& mt, int& nt) {
   const int total = g.m_tiles * g.n_tiles;
   const int per_xcd = (total + 7) / 8;
-  const int v = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);  // one XCD (one L2) owns a run of row tiles
-  if (v >= total) return false;
+  const int in_xcd = (int)(b >> 3);
+  const int v = (int)(b & 7) * per_xcd + in_xcd;  // one XCD (one L2) owns a run of row tiles
+  if (in_xcd >= per_xcd || v >= total) return false;
   mt = v / g.n_tiles;
   nt = v - mt * g.n_tiles;
   return true;
+}
+__device__ __forceinline__ bool f16_tile_of_block(const GemmF16Args& g, int& mt, int& nt) {
+  return f16_tile_of_block(g, blockIdx.x, mt, nt);
 }
 
 __device__ __forceinline__ void f16_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }

@@ -85,6 +85,16 @@ static __global__ __launch_bounds__(kBlock) void split_rows_blocks_kernel(const 
 // flight).  Measured at 8 192 rows: two stages 31.8 us (no gain over the k-step schedule's 31.5), three 29.1, four 28.2.
 // Accumulation order per accumulator is unchanged (k ascending, the same three products per k-step): bit-identical results.
 // (KB2 = the number of stages of that ring: 3, or 4 = one more k-block of fill cover.)
+#ifdef AMP_DMA_TIMELINE  // microbenchmark builds only (tools/gemm_f16_bench.hip TIMELINE=1): per-workgroup phase stamps
+__device__ unsigned long long* g_dma_timeline;  // [grid][8]: start, k-loop start, k-loop end, stores issued, stores done, hw id
+#define AMP_DMA_STAMP(slot)                                                                                           \
+  do {                                                                                                                \
+    if (g_dma_timeline && threadIdx.x == 0) g_dma_timeline[(size_t)stamp_row * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define AMP_DMA_STAMP(slot) do {} while (0)
+#endif
+
 template <int MODE, int TM = 4, int TN = 2, int KB2 = 0>
 __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPerCu)) void disc_gemm_f16_dma_kernel(GemmF16Args g) {
   using T = DmaTile<TM, TN, KB2 ? KB2 : 2>;
@@ -92,6 +102,10 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
   static_assert(!KB2 || MODE == 1, "the k-block-per-segment schedule is wired for layer 2 (no zero-padding k-step skip, no split-K)");
   constexpr int BM = T::BM, BN = T::BN, kOpA = T::kA, kStage = T::kStage;
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+#ifdef AMP_DMA_TIMELINE
+  unsigned stamp_row = blockIdx.x;
+#endif
+  AMP_DMA_STAMP(0);
   int mt, nt, slice = 0;
   if (MODE == 2 && g.k_slices > 1) {
     // split-K: the grid is k_slices copies of the tile grid; slice s owns the k-blocks [s * nq, (s + 1) * nq)
@@ -107,8 +121,8 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
   const int wm = wave >> 2, wn = wave & 3;
   const int li = lane & 31, lh = lane >> 5;
   const int grp = wave >> 2;
-  const int64_t m0 = (int64_t)mt * BM;
-  const int n0 = nt * BN;
+  int64_t m0 = (int64_t)mt * BM;  // (MODE 0: a persistent workgroup moves on to its next tile, see the end of the epilogue)
+  int n0 = nt * BN;
   const int nq = (MODE == 2 && g.k_slices > 1) ? g.Kp / kDmaKB / g.k_slices : g.Kp / kDmaKB;  // k-blocks (of this slice)
   const int q0 = slice * nq;
   const int ksteps = (MODE != 2 && g.ksteps > 0) ? g.ksteps : 2 * nq;
@@ -119,7 +133,7 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
   constexpr int NPA = BM / 32, NPB = BN / 32, NP = NPA > NPB ? NPA : NPB;
   const int np = grp == 0 ? NPA : NPB;
   const _Float16* src[NP];
-  {
+  auto plan_fills = [&]() {  // the wave's source addresses for the tile at (m0, n0)
     const int64_t last = g.M - 1;  // rows past M re-read the last row; their results are never stored
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
@@ -132,7 +146,8 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
         src[j] = g.W + (int64_t)(n0 + r) * (2 * (int64_t)g.Kp) + 8 * c + (int64_t)q0 * 64;
       }
     }
-  }
+  };
+  plan_fills();
   const int fill_base = grp * kOpA + (wave & 3) * (np * 1024);
   auto fill = [&](int q, int stage) {  // the wave's pieces of k-block q
     unsigned char* sb = lds + stage * kStage + fill_base;
@@ -158,13 +173,6 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
   }
 
   fx16 acc[TM][TN];
-#pragma unroll
-  for (int a = 0; a < TM; ++a)
-#pragma unroll
-    for (int b = 0; b < TN; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-
   h8 x0[TM], x1[TM], w0[TN], w1[TN];
   auto read_frags = [&](const unsigned char* sb, const int s) {
 #pragma unroll
@@ -214,6 +222,15 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
     __builtin_amdgcn_sched_barrier(0);
   };
 
+  unsigned vb = blockIdx.x;  // the (virtual) block whose tile is being computed
+  bool first_tile = true;
+  for (;;) {  // MODE 0: one pass per tile of a persistent workgroup; the other modes leave from their epilogues
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
   if constexpr (KB2) {
     h8 y0[2][TM], y1[2][TM], v0[2][TN], v1[2][TN];  // fragments of both k-steps
     constexpr int NS = KB2;
@@ -282,18 +299,25 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
     for (; q + NS - 1 < nq; ++q) kb(q, true, NS - 2);
     for (; q < nq; ++q) kb(q, false, nq - 2 - q > 0 ? nq - 2 - q : 0);  // the tail: nothing left to issue, fewer k-blocks in flight
   } else {
-  fill(0, 0);
-  if (nq > 1) {
-    fill(1, 1);
-    // k-block 0 has landed, k-block 1 (np pieces) is in flight
-    if (np == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (np == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if (np == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (first_tile) {
+    fill(0, 0);
+    if (nq > 1) {
+      fill(1, 1);
+      // k-block 0 has landed, k-block 1 (np pieces) is in flight
+      if (np == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (np == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (np == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
   } else {
+    // a later tile of a persistent workgroup: its k-blocks 0 and 1 were issued in front of the previous tile's epilogue; its
+    // stores and these fills retire out of order with each other, so the wait is for all of them
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();  // k-block 0 is visible to every wave
+  AMP_DMA_STAMP(1);
   if (grp == 1) __builtin_amdgcn_s_barrier();
   // one k-block = R0 M0 [R1 M1]; `second` = false drops the second k-step of the LAST k-block when it is zero padding only
   // (GemmF16Args::ksteps; uniform over the grid, so both wave groups drop the same two barriers; nothing is in flight then:
@@ -319,6 +343,7 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
   __syncthreads();  // every wave is done with the stages: the scratch below reuses them
+  AMP_DMA_STAMP(2);
 
   if (MODE == 2) {
     // ---- plain fp32 product (training step).  Same register map as MODE 0: register r of lane (li, lh) is output ROW
@@ -351,6 +376,23 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
   const LayerScales sc = layer_scales(g.range, g.amax, g.layer);
   const float descale = sc.descale;
   if (MODE == 0) {
+    // Persistent workgroup (the grid is smaller than the tile count: launch_dma): move on to tile vb + gridDim.x.  Every
+    // wave is past its last read of both stages (the __syncthreads above) and this epilogue does not touch the LDS, so
+    // k-blocks 0 and 1 of the NEXT tile are issued here and land while this tile's hidden-layer rows are converted and
+    // stored.  Measured per 256 x 256 tile of a 32 768-row launch (two tiles per CU, per-workgroup s_memrealtime stamps,
+    // profiles/r03_l1_timeline.txt): start -> first k-step 2.5-5 us, k-loop 13.6-14.6 us, epilogue 4.6 us + 0.7-1.3 us of
+    // store drain -- and 3.0 us between a workgroup's end and the start of its successor on the CU.
+    const int64_t tile_m0 = m0;
+    const int tile_n0 = n0;
+    vb += gridDim.x;
+    const bool more = f16_tile_of_block(g, vb, mt, nt);
+    if (more) {
+      m0 = (int64_t)mt * BM;
+      n0 = nt * BN;
+      plan_fills();
+      fill(0, 0);
+      if (nq > 1) fill(1, 1);
+    }
     // ---- layer-1 epilogue.  Accumulator register r of lane (li, lh) is output ROW (r & 3) + 8 (r >> 2) + 4 lh of the
     // 32 x 32 block and COLUMN li: relu_split4's arithmetic per value (fma, max, two roundings to fp16), then adjacent lanes
     // swap their (p0, p1) words (one DPP move + one v_perm_b32) so that even lanes hold the p0 halves of columns (li, li + 1)
@@ -362,32 +404,58 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
     const float s_h = sc.s_out, ds = descale * s_h;
     const uint32_t row_pitch = (uint32_t)(2 * g.ldh * (int64_t)sizeof(_Float16));
     const int band = __builtin_amdgcn_readfirstlane(wm) * (32 * TM);       // the wave's first row inside the tile
-    const int col0 = n0 + __builtin_amdgcn_readfirstlane(wn) * (32 * TN);  // ... and first column
-    const int64_t rows_left = g.M - (m0 + band);
+    const int col0 = tile_n0 + __builtin_amdgcn_readfirstlane(wn) * (32 * TN);  // ... and first column
+    const int64_t rows_left = g.M - (tile_m0 + band);
     const int valid = rows_left <= 0 ? 0 : (rows_left < 32 * TM ? (int)rows_left : 32 * TM);
-    unsigned char* const hband = reinterpret_cast<unsigned char*>(g.H) + (m0 + band) * (int64_t)row_pitch + (col0 >> 5) * 128;
+    unsigned char* const hband = reinterpret_cast<unsigned char*>(g.H) + (tile_m0 + band) * (int64_t)row_pitch + (col0 >> 5) * 128;
     const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(hband, 0, (int)((uint32_t)valid * row_pitch), 0x00020000);
     const uint32_t lane_off = (uint32_t)(4 * lh) * row_pitch + (uint32_t)((li & 1) * 64 + (li >> 1) * 4);
     const uint32_t sel = (li & 1) ? 0x03020706u : 0x05040100u;  // v_perm_b32(neighbour, own, sel): odd [nb.hi, own.hi], even [own.lo, nb.lo]
     float bs[TN];
 #pragma unroll
     for (int b = 0; b < TN; ++b) bs[b] = g.bias[col0 + b * 32 + li] * s_h;
+    // Per value: half a v_pk_fma_f32, v_max, v_cvt_f16_f32 (p0 into the low half of the word) and ONE v_fma_mixhi_f16 that
+    // writes rn16(v - p0) into the word's high half (v - p0 is exact in fp32, so this is the same single rounding as
+    // (_Float16)(v - (float)p0) -- hipcc's version of that line was cvt, sub, cvt_sdwa, or: 9 VALU instructions per value with
+    // the exchange, now 5.5; at K = 192 the epilogue's VALU time is of the order of the tile's MFMA time).
+    typedef float fv2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
+      for (int r = 0; r < 16; r += 2)
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
-          const float v = fmaxf(__builtin_fmaf(acc[a][b][r], ds, bs[b]), 0.0f);
-          const _Float16 p0 = (_Float16)v;
-          const _Float16 p1 = (_Float16)__builtin_fmaf((float)p0, -1.0f, v);
-          const uint32_t own = (uint32_t)__builtin_bit_cast(uint16_t, p0) | ((uint32_t)__builtin_bit_cast(uint16_t, p1) << 16);
-          const uint32_t nb = (uint32_t)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);  // quad_perm [1, 0, 3, 2]
-          const uint32_t word = __builtin_amdgcn_perm(nb, own, sel);
-          const int soff = (int)((uint32_t)(a * 32 + (r & 3) + 8 * (r >> 2)) * row_pitch) + b * 128;  // wave-uniform
-          __builtin_amdgcn_raw_buffer_store_b32(word, hrsrc, (int)lane_off, soff, 0);
+          fv2 t;
+          t.x = acc[a][b][r];
+          t.y = acc[a][b][r + 1];
+          const fv2 dsv = {ds, ds}, bsv = {bs[b], bs[b]};
+          t = __builtin_elementwise_fma(t, dsv, bsv);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const float v = fmaxf(i ? t.y : t.x, 0.0f);
+            uint32_t own;
+            asm("v_cvt_f16_f32 %0, %1" : "=v"(own) : "v"(v));
+            asm("v_fma_mixhi_f16 %0, -%0, 1.0, %1 op_sel_hi:[1,0,0]" : "+v"(own) : "v"(v));
+            const uint32_t nb = (uint32_t)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);  // quad_perm [1, 0, 3, 2]
+            const uint32_t word = __builtin_amdgcn_perm(nb, own, sel);
+            const int rr = r + i;
+            const int soff = (int)((uint32_t)(a * 32 + (rr & 3) + 8 * (rr >> 2)) * row_pitch) + b * 128;  // wave-uniform
+            __builtin_amdgcn_raw_buffer_store_b32(word, hrsrc, (int)lane_off, soff, 0);
+          }
         }
-    return;
+#ifdef AMP_DMA_TIMELINE
+    AMP_DMA_STAMP(3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    AMP_DMA_STAMP(4);
+    if (g_dma_timeline && threadIdx.x == 0) g_dma_timeline[(size_t)stamp_row * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_ID
+#endif
+    if (!more) return;
+    first_tile = false;
+#ifdef AMP_DMA_TIMELINE
+    stamp_row = vb;
+    AMP_DMA_STAMP(0);
+#endif
+    continue;
   }
   // ---- layer-2 epilogue: register r of lane half lh is output column (r & 3) + 8 (r >> 2) + 4 lh of the 32-wide block,
   //      lane li is activation row li
@@ -424,6 +492,8 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
     const int64_t row = m0 + r;
     if (row < g.M) g.partial[row * n_blocks + nt * BPT + j] = red[j * BM + r];
   }
+  return;
+  }  // tile loop
 }
 
 }  // namespace amp

@@ -257,7 +257,9 @@ static void run_dma(GemmF16Args g, int64_t M, int N, int K, bool quiet) {
   g_dma_last = true;
   g.n_tiles = N / T::BN;
   g.m_tiles = (int)((M + T::BM - 1) / T::BM);
-  const unsigned grid = (unsigned)(((int64_t)g.m_tiles * g.n_tiles + 7) / 8 * 8);
+  unsigned grid = (unsigned)(((int64_t)g.m_tiles * g.n_tiles + 7) / 8 * 8);
+  // layer 1 of the product: persistent workgroups, one per LDS slot (NOPERSIST=1: one workgroup per tile, as before round 3)
+  if (MODE == 0 && XP == 0 && !getenv("NOPERSIST")) grid = std::min(grid, 256u * T::kWgPerCu);
   // XP = 0: the PRODUCT kernel; XP != 0: the ablation copy under tools/experiments (round-1 epilogue)
   void (*kern)(GemmF16Args) = disc_gemm_f16_dma_xp_kernel<MODE, XP, TM, TN>;
   if (XP == 0) kern = disc_gemm_f16_dma_kernel<MODE, TM, TN>;
@@ -669,6 +671,84 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
+  if (getenv("CONC0") && mode == 0) {
+    // Layer 1 WITHOUT its global stores (ablation XP = 3 of the round-1-epilogue copy: everything else kept) next to a kernel that
+    // does nothing but store the hidden layer's bytes, on a second stream: do a compute phase and a store phase overlap AT ALL
+    // on this chip when they are not the same workgroups?
+    using T = DmaTile<4, 2>;
+    GemmF16Args gx = g;
+    gx.W = g_Wb;
+    gx.n_tiles = N / T::BN;
+    gx.m_tiles = (int)((M + T::BM - 1) / T::BM);
+    const unsigned gridx = (unsigned)(((int64_t)gx.m_tiles * gx.n_tiles + 7) / 8 * 8);
+    void (*kx)(GemmF16Args) = disc_gemm_f16_dma_xp_kernel<0, 3, 4, 2>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kx), hipFuncAttributeMaxDynamicSharedMemorySize, T::kLds));
+    unsigned char* sink;
+    CK(hipMalloc(&sink, (size_t)M * 4096));
+    const unsigned grids = (unsigned)((M + 255) / 256 * 4);
+    hipStream_t s2;
+    CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    const int reps = 12;
+    auto timed = [&](const char* label, bool gemm, bool stores) {
+      for (int warm = 0; warm < 2; ++warm) {
+        CK(hipDeviceSynchronize());
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < reps; ++i) {
+          if (gemm) kx<<<gridx, kDmaThreads, T::kLds>>>(gx);
+          if (stores) store_tiles_kernel<<<grids, 256, 0, s2>>>(sink, M, 4096);
+        }
+        CK(hipDeviceSynchronize());
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+        if (warm) printf("%-70s %8.1f us per iteration\n", label, us);
+      }
+    };
+    timed("layer 1 without its global stores, alone", true, false);
+    timed("store-only kernel (the hidden layer's bytes), alone", false, true);
+    timed("both, on two streams", true, true);
+    run_dma<0, 0, 4, 2>(g, M, N, K, false);
+    return 0;
+  }
+#ifdef AMP_DMA_TIMELINE
+  if (getenv("TIMELINE") && mode == 0) {  // per-workgroup phase stamps of ONE layer-1 launch (100 MHz wall clock: 10 ns ticks)
+    using T = DmaTile<4, 2>;
+    g.W = g_Wb;
+    g.n_tiles = N / T::BN;
+    g.m_tiles = (int)((M + T::BM - 1) / T::BM);
+    const unsigned tiles = (unsigned)(((int64_t)g.m_tiles * g.n_tiles + 7) / 8 * 8);
+    const unsigned launch = getenv("NOPERSIST") ? tiles : std::min(tiles, 256u);
+    const unsigned grid = tiles;  // stamp rows
+    unsigned long long* tl;
+    CK(hipMalloc(&tl, (size_t)grid * 64));
+    CK(hipMemset(tl, 0, (size_t)grid * 64));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gemm_f16_dma_kernel<0, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, T::kLds));
+    for (int i = 0; i < 3; ++i) disc_gemm_f16_dma_kernel<0, 4, 2><<<launch, kDmaThreads, T::kLds>>>(g);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_dma_timeline), &tl, sizeof(tl)));
+    disc_gemm_f16_dma_kernel<0, 4, 2><<<launch, kDmaThreads, T::kLds>>>(g);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> h((size_t)grid * 8);
+    CK(hipMemcpy(h.data(), tl, h.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull;
+    for (unsigned b = 0; b < grid; ++b) if (h[b * 8]) t0 = std::min(t0, h[b * 8]);
+    double sum[5] = {0, 0, 0, 0, 0};
+    int n = 0;
+    for (unsigned b = 0; b < grid; ++b) {
+      if (!h[b * 8 + 4]) continue;
+      ++n;
+      for (int i = 0; i < 4; ++i) sum[i] += (double)(h[b * 8 + i + 1] - h[b * 8 + i]) * 0.01;
+      sum[4] += (double)(h[b * 8 + 4] - t0) * 0.01;
+    }
+    printf("timeline over %d workgroups (us): start->k-loop %.2f | k-loop %.2f | epilogue issue %.2f | store drain %.2f | mean end %.2f\n", n,
+           sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n);
+    for (unsigned b = 0; b < grid; b += grid / 16) {
+      const unsigned hw = (unsigned)h[b * 8 + 5];
+      printf("  wg %4u cu %2u se %u xcc?: start %7.2f  kloop %7.2f  kend %7.2f  issued %7.2f  done %7.2f\n", b, (hw >> 8) & 15, (hw >> 13) & 7,
+             (h[b * 8] - t0) * 0.01, (h[b * 8 + 1] - t0) * 0.01, (h[b * 8 + 2] - t0) * 0.01, (h[b * 8 + 3] - t0) * 0.01, (h[b * 8 + 4] - t0) * 0.01);
+    }
+    // per-CU view: the workgroups that ran on the same (xcd = b & 7, hw id) in start order
+    return 0;
+  }
+#endif
   if (getenv("TILES")) {
     for (int rep = 0; rep < 3; ++rep) {
       if (mode == 0) {
