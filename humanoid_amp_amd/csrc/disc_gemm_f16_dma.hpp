@@ -85,6 +85,16 @@ static __global__ __launch_bounds__(kBlock) void split_rows_blocks_kernel(const 
 // flight).  Measured at 8 192 rows: two stages 31.8 us (no gain over the k-step schedule's 31.5), three 29.1, four 28.2.
 // Accumulation order per accumulator is unchanged (k ascending, the same three products per k-step): bit-identical results.
 // (KB2 = the number of stages of that ring: 3, or 4 = one more k-block of fill cover.)
+#ifndef AMP_L1_STORE_AUX
+// Cache-policy bits of the hidden layer's stores: sc1 (agent scope: the line is written through the XCD's L2 instead of
+// sitting in it dirty until the next 4 MB of the 134-MB stream push it out).  Measured, same box, 32 768-row launches: aux 0
+// 53.1 us, 2 (non-temporal) 53.5, 16 (sc1) 51.7, 17 (sc1 + sc0) 51.9, 18 53.3; inside the step at 65 536 envs layer 1
+// 108.0-108.7 -> 105.0-106.5 us (the env launch that follows gives ~2 of the 3 us back: 0.326 -> 0.324 ms per step), at 8 192
+// envs 59.2-59.6 -> 57.3-58.3 us per step.
+// (The FILLS keep the default policy: non-temporal / sc1 on the activation fills cost layer 2 +8-11 us and layer 1 +4-7 us per
+// step, gpurun_out/r03_y.)
+#define AMP_L1_STORE_AUX 16
+#endif
 #ifdef AMP_DMA_TIMELINE  // microbenchmark builds only (tools/gemm_f16_bench.hip TIMELINE=1): per-workgroup phase stamps
 __device__ unsigned long long* g_dma_timeline;  // [grid][8]: start, k-loop start, k-loop end, stores issued, stores done, hw id
 #define AMP_DMA_STAMP(slot)                                                                                           \
@@ -440,7 +450,7 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
             const uint32_t word = __builtin_amdgcn_perm(nb, own, sel);
             const int rr = r + i;
             const int soff = (int)((uint32_t)(a * 32 + (rr & 3) + 8 * (rr >> 2)) * row_pitch) + b * 128;  // wave-uniform
-            __builtin_amdgcn_raw_buffer_store_b32(word, hrsrc, (int)lane_off, soff, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(word, hrsrc, (int)lane_off, soff, AMP_L1_STORE_AUX);
           }
         }
 #ifdef AMP_DMA_TIMELINE

@@ -1,0 +1,23 @@
+#!/bin/bash
+# A/B of engine-library variants on ONE box: tools/ab_bench.sh <out_dir> <variant.so> [<variant.so> ...]
+# Runs bench.py --no-dropin on the in-tree library and on every variant (copied over it), interleaved, twice; puts the tree's
+# library back at the end.  Variants are built by hand (hipcc -D... -c disc.hip; link with csrc/build/*.o) into tools/bin/.
+set -u
+out=$1; shift
+mkdir -p "$out"
+L=humanoid_amp_amd/csrc/libamp_engine.so
+cp $L /tmp/ab_base.so
+for rep in 1 2; do
+  for v in base "$@"; do
+    if [ "$v" = base ]; then cp /tmp/ab_base.so $L; n=base; else cp "$v" $L; n=$(basename "$v" .so); fi
+    timeout -k 10 200 python bench.py --no-dropin --steps 100 > "$out/bench_${n}_$rep.json" 2>/dev/null
+    python - "$out/bench_${n}_$rep.json" "$n" <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+k = d["kernel_us_per_step"]
+print(f"{sys.argv[2]:28s} {d['ms_per_step']*1e3:7.1f} us/step  env {k['env_step_reference_kernel']:6.1f}  L1 {k['disc_gemm_f16_dma_kernel<0>']:6.1f}  "
+      f"L2 {k['disc_gemm_f16_dma_kernel<1>']:6.1f}  tail {k['step_tail_kernel']:4.1f} | 8192: {d['envs_8192']['ms_per_step']*1e3:5.1f}  4096: {d['envs_4096']['ms_per_step']*1e3:5.1f}")
+PY
+  done
+done
+cp /tmp/ab_base.so $L
