@@ -393,6 +393,8 @@ static int f16_kernels_init() {
   AMP_HIP((dma_kernel_init<0, 2, 1>()));
   AMP_HIP((dma_kernel_init<1, 2, 1>()));
   AMP_HIP((dma_kernel_init<1, 2, 1, 4>()));
+  AMP_HIP((dma_kernel_init<1, 1, 1, 4>()));
+  AMP_HIP((dma_kernel_init<1, 1, 1>()));
   if (dev >= 0 && dev < 64) done[dev] = true;
   return AMP_OK;
 }
@@ -411,13 +413,16 @@ constexpr int64_t kChunkRows = 32768;
 //   16 384    28.9 / 66.7   33.6 / 44.3  30.8 / 47.1
 //   12 288    26.6 / 64.2   31.1 / 40.6  25.4 / 42.8
 //    8 192    24.8 / 62.0   19.1 / 37.9  18.0 / 29.0   18.5 / 34.6, 20.8 / 37.6
-//    4 096    22.7 / 60.2   16.1 / 35.6  12.0 / 25.9   (64 x 64: 12 / 22 inside the step)
-enum { kPlanRegister = 0, kPlanDmaSmall = 1, kPlanDmaMid = 2, kPlanDmaLarge = 3 };
+//    4 096    22.7 / 60.2   16.1 / 35.6  12.0 / 25.9   (64 x 64: 12 / 22 inside the step; 64 x 128 LDS-DMA layer 2: 20.4, ~18 on a 4-stage ring)
+enum { kPlanRegister = 0, kPlanDmaSmall = 1, kPlanDmaMid = 2, kPlanDmaLarge = 3, kPlanDmaTiny = 4 };
 static int f16_plan(const AmpDisc* h, int64_t rows) {
   if (h->h1 % kDmaBN != 0 || h->h2 % kDmaBN != 0) return kPlanRegister;   // the LDS-DMA tiles need 256-column multiples
   if ((rows + kDmaBM - 1) / kDmaBM * (h->h2 / kDmaBN) >= 192) return kPlanDmaLarge;  // >= ~1 tile of 256 x 256 per CU
   if (rows >= 12288) return kPlanDmaMid;     // layer 1: 256 x 256, layer 2: 256 x 128
   if (rows > 5120) return kPlanDmaSmall;     // both layers 128 x 128 (the 8 192-env shards of the multi-GPU configurations)
+  // layer 1 128 x 128, layer 2 64 x 128 on the four-stage k-block ring (one workgroup per CU at 4 096 rows): the 4 096-env
+  // configuration, 47.2 -> 43.6 us per step against the register-staged 64 x 64 tiles (same box, tools/ab_bench.sh, round 3)
+  if (rows >= 3072) return kPlanDmaTiny;
   return kPlanRegister;
 }
 static bool f16_use_dma(const AmpDisc* h, int64_t rows) { return f16_plan(h, rows) != kPlanRegister; }
@@ -447,7 +452,7 @@ static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* a
       g1.W = h->w1b;  // block layout; the hidden layer comes out in block layout too (row pitch 2 * h1)
       g1.H = H1p;     // every chunk reuses the SAME 134 MB: rewritten while still dirty in the Infinity Cache, the hidden
                       // layer is (mostly) never written back to HBM, and the lines it evicts are not dirty either
-      if (plan == kPlanDmaSmall) rc = launch_dma<0, 2, 1>(g1, m, h->h1, "disc_gemm_f16_dma_kernel<0>", st);
+      if (plan == kPlanDmaSmall || plan == kPlanDmaTiny) rc = launch_dma<0, 2, 1>(g1, m, h->h1, "disc_gemm_f16_dma_kernel<0>", st);
       else rc = launch_dma<0, 4, 2>(g1, m, h->h1, "disc_gemm_f16_dma_kernel<0>", st);
     } else if (big_tiles(h->h1)) {
       rc = launch_f16<2, 2, 32, 0, 3>(g1, m, h->h1, "disc_gemm_f16_kernel<0>", st);
@@ -472,6 +477,8 @@ static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* a
       const bool one_round = (m + 127) / 128 * (h->h2 / 128) <= 256;
       if (plan == kPlanDmaSmall) rc = one_round ? launch_dma<1, 2, 1, 4>(g2, m, h->h2, "disc_gemm_f16_dma_kernel<1>", st)
                                                 : launch_dma<1, 2, 1>(g2, m, h->h2, "disc_gemm_f16_dma_kernel<1>", st);
+      else if (plan == kPlanDmaTiny) rc = (m + 63) / 64 * (h->h2 / 128) <= 256 ? launch_dma<1, 1, 1, 4>(g2, m, h->h2, "disc_gemm_f16_dma_kernel<1>", st)
+                                                                              : launch_dma<1, 1, 1>(g2, m, h->h2, "disc_gemm_f16_dma_kernel<1>", st);
       else if (plan == kPlanDmaMid) rc = launch_dma<1, 4, 1>(g2, m, h->h2, "disc_gemm_f16_dma_kernel<1>", st);
       else rc = launch_dma<1, 4, 2>(g2, m, h->h2, "disc_gemm_f16_dma_kernel<1>", st);
     } else if (big_tiles(h->h2)) {

@@ -167,11 +167,14 @@ def test_graph_replay_matches_eager():
 
 
 @pytest.mark.parametrize("precision,bar", [("f16x3", 1e-6), ("f32", 1e-6)])
-@pytest.mark.parametrize("in_dim,rows", [(166, 4096), (830, 777), (162, 70000), (166, 20000), (166, 30001), (830, 49153)])
+@pytest.mark.parametrize("in_dim,rows", [(166, 4096), (830, 777), (162, 70000), (166, 20000), (166, 30001), (830, 49153),
+                                         (166, 2500), (166, 3500), (830, 5000)])
 def test_gemm_engines_vs_fp64(precision, bar, in_dim, rows):
     """Both GEMM engines (fp16-split default, fp32 MFMA) must be as accurate as an fp32 forward: <= 1e-6 against the
     fp64 evaluation of the same fp32 weights on O(1) logits, a tenth of the path's 1e-5 budget.  The row counts walk
-    through every kernel selection of the fp16 engine: 64 x 64 tiles (4 096, 777), 128 x 128 register-staged (20 000),
+    through every kernel selection of the fp16 engine: 64 x 64 register-staged tiles (777, 2 500), the 4 096-env plan --
+    LDS-DMA 128 x 128 layer 1 + 64 x 128 layer 2 on the four-stage ring (3 500 with a ragged tile, 4 096) or on two stages
+    (5 000: more tiles than CUs) --, 128 x 128 LDS-DMA (20 000),
     one 256 x 256 LDS-DMA launch with a ragged last tile (30 001), 32 768-row chunks with a short last chunk (49 153,
     70 000).  Checked rows: the first 2 048 and the LAST 2 048 (ragged tiles / last chunk)."""
     from humanoid_amp_amd.engine import AmpDiscriminator
