@@ -450,7 +450,11 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
             const uint32_t word = __builtin_amdgcn_perm(nb, own, sel);
             const int rr = r + i;
             const int soff = (int)((uint32_t)(a * 32 + (rr & 3) + 8 * (rr >> 2)) * row_pitch) + b * 128;  // wave-uniform
+#ifdef AMP_L1_NO_STORES  // microbenchmark ablation (CONC0=1): everything but the stores; `word` is kept alive by an empty asm
+            asm volatile("" ::"v"(word));
+#else
             __builtin_amdgcn_raw_buffer_store_b32(word, hrsrc, (int)lane_off, soff, AMP_L1_STORE_AUX);
+#endif
           }
         }
 #ifdef AMP_DMA_TIMELINE

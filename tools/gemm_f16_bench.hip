@@ -681,7 +681,13 @@ int main(int argc, char** argv) {
     gx.n_tiles = N / T::BN;
     gx.m_tiles = (int)((M + T::BM - 1) / T::BM);
     const unsigned gridx = (unsigned)(((int64_t)gx.m_tiles * gx.n_tiles + 7) / 8 * 8);
-    void (*kx)(GemmF16Args) = disc_gemm_f16_dma_xp_kernel<0, 3, 4, 2>;
+#ifdef AMP_L1_NO_STORES
+    void (*kx)(GemmF16Args) = disc_gemm_f16_dma_kernel<0, 4, 2>;  // the PRODUCT kernel compiled without its stores, one workgroup per tile
+    puts("(product kernel built with -DAMP_L1_NO_STORES)");
+#else
+    void (*kx)(GemmF16Args) = disc_gemm_f16_dma_xp_kernel<0, 3, 4, 2>;  // round-1-epilogue copy: no stores, no fills, no fragment reads
+    puts("(ablation copy XP = 3: no stores AND no fills / fragment reads in the loop)");
+#endif
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kx), hipFuncAttributeMaxDynamicSharedMemorySize, T::kLds));
     unsigned char* sink;
     CK(hipMalloc(&sink, (size_t)M * 4096));
