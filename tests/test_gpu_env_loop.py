@@ -45,6 +45,11 @@ def _shadow_run(env, mt, keys_names, root_body, z_lift, steps, is_g1):
     obs, _ = env.reset()
     r = env.ref_body_index
     shadow = env.amp_observation_buffer.clone().cpu()  # after reset + first obs: adopt, then track independently
+    n_actor = getattr(cfg, "num_actor_observations", 1)
+    if n_actor > 1:  # actor history (g1_amp_env.py:198-235): adopt after the warm start, then track independently
+        shadow_hist = env.actor_obs_history_buffer.clone().cpu()
+        shadow_just = torch.zeros(N, dtype=torch.bool)
+        assert not bool(env._just_reset_mask.any())
     n_resets = 0
     for step in range(steps):
         snap.pop("reset", None)
@@ -73,6 +78,8 @@ def _shadow_run(env, mt, keys_names, root_body, z_lift, steps, is_g1):
             n_resets += len(ids)
             rows = oenv.collect_reference(mt, m_t, m_ids, K, perm, ref, m_keys).view(len(ids), K, -1)
             shadow[ids] = rows
+            if n_actor > 1:
+                shadow_just[ids] = True  # _reset_idx: _just_reset_mask[env_ids] = True (g1_amp_env.py:352-358)
             root, dpos, dvel = oenv.reset_reference_state(mt, m_t, m_ids, perm, mt.body_names.index(root_body),
                                                           env.scene.env_origins.cpu()[ids], z_lift)
             d = env.robot.data
@@ -89,7 +96,15 @@ def _shadow_run(env, mt, keys_names, root_body, z_lift, steps, is_g1):
         assert float((got.cpu() - amp).abs().max()) <= TOL
         if is_g1:
             la = env.last_actions.clone().cpu()
-            pol = oenv.actor_observation(ob, la, env.command_target_speed.cpu(), use_command=cfg.rew_track_vel > 0.0)
+            if n_actor > 1:
+                pol = oenv.actor_observation(ob, la, env.command_target_speed.cpu(), use_command=cfg.rew_track_vel > 0.0, n_actor=n_actor,
+                                             hist_buf=shadow_hist, just_reset=shadow_just,
+                                             hist_actions=cfg.history_include_last_actions, hist_command=cfg.history_include_command)
+                assert obs["policy"].shape[1] == cfg.observation_space
+                assert float((env.actor_obs_history_buffer.cpu() - shadow_hist).abs().max()) <= TOL
+                assert not bool(env._just_reset_mask.any())
+            else:
+                pol = oenv.actor_observation(ob, la, env.command_target_speed.cpu(), use_command=cfg.rew_track_vel > 0.0)
             assert float((obs["policy"].cpu() - pol).abs().max()) <= TOL
         else:
             assert float((obs["policy"].cpu() - ob).abs().max()) <= TOL
@@ -122,6 +137,23 @@ def test_g1_walk_env_loop_random_reset():
     env = G1AmpEnv(cfg)
     mt = om.load_tables([cfg.motion_file])
     assert _shadow_run(env, mt, G1_KEY_BODY_NAMES, "pelvis", 0.05, steps=25, is_g1=True) > 100
+
+
+@pytest.mark.parametrize("n_actor,hist_actions,hist_command", [(2, True, True), (3, False, True)])
+def test_g1_deploy_env_loop_actor_history(n_actor, hist_actions, hist_command):
+    """The Deploy task (g1_amp_env_cfg.py:160-206): multi-clip yaml table, K = 10, actor history with reset warm start -- the
+    history buffer and the policy row follow an independent oracle shadow over 25 steps with resets."""
+    from humanoid_amp_amd.envs import G1AmpDeployEnvCfg, G1AmpEnv
+    from humanoid_amp_amd.motions.motion_loader import _resolve_motion_files
+    from humanoid_amp_amd.robots import G1_KEY_BODY_NAMES
+
+    cfg = G1AmpDeployEnvCfg(num_actor_observations=n_actor, history_include_last_actions=hist_actions,
+                            history_include_command=hist_command)
+    cfg.scene.num_envs = 150
+    cfg.episode_length_s = 0.2
+    env = G1AmpEnv(cfg)
+    mt = om.load_tables(_resolve_motion_files(cfg.motion_file))
+    assert _shadow_run(env, mt, G1_KEY_BODY_NAMES, "pelvis", 0.05, steps=25, is_g1=True) > 150
 
 
 def test_humanoid_env_loop():
