@@ -136,6 +136,43 @@ def test_sample_tiles_vs_oracle(tag, loaders):
             assert float(d[~torch.isnan(d)].max()) <= TOL and torch.equal(torch.isnan(g.cpu()), torch.isnan(w)), name
 
 
+@pytest.mark.parametrize("tag", list(gu.CLIPSETS))
+def test_sample_large_batch_equals_its_chunks(tag, loaders):
+    """One large ragged batch (33 545 samples) against the same samples in chunks of 5 000, bit for bit, NaN patterns included
+    -- and the first 2 000 samples against the oracle; with four outputs NULL the remaining two do not change.  (Written for the
+    LDS-resident-table variant of the kernel tried in round 3 -- profiles/r03_sample_kernel.md -- and kept: whatever kernel a batch
+    size selects, a sample's result may not depend on its neighbours.)"""
+    import ctypes as C
+
+    from humanoid_amp_amd import _native as nat
+    from oracle import motion as om
+
+    ml = loaders[tag]
+    mt = om.load_tables(gu.clip_files(tag))
+    rng = np.random.default_rng(23)
+    n = 16384 * 2 + 777
+    ids = rng.integers(0, ml.num_trajectories, size=n)
+    t = rng.uniform(-0.1, 1.03, size=n) * mt.durations[ids]
+    big = ml.sample(n, times=t, motion_ids=ids)
+    for a in range(0, n, 5000):
+        part = ml.sample(min(5000, n - a), times=t[a:a + 5000], motion_ids=ids[a:a + 5000])
+        for name, g, w in zip(TABLE_KEYS, big, part):
+            gs = g[a:a + 5000]
+            assert torch.equal(torch.isnan(gs), torch.isnan(w)) and torch.equal(torch.nan_to_num(gs), torch.nan_to_num(w)), (name, a)
+    want = om.sample(mt, t[:2000], ids[:2000])
+    for name, g, w in zip(TABLE_KEYS, big, want):
+        if name in LERP_TABLES:
+            assert torch.equal(g[:2000].cpu(), w), name
+    # NULL outputs: only body_positions and body_rotations asked for
+    td, idd = torch.from_numpy(t).cuda(), torch.from_numpy(ids).cuda()
+    bp, br = torch.full_like(big[2], -7.0), torch.full_like(big[3], -7.0)
+    null = C.c_void_p(None)
+    with torch.cuda.device("cuda:0"):
+        nat.check(nat.load().amp_motion_sample(ml._need_handle(), nat.dptr(td), nat.dptr(idd), n, null, null, nat.dptr(bp), nat.dptr(br), null,
+                                               null, nat.stream_ptr()), "amp_motion_sample")
+    assert torch.equal(torch.nan_to_num(bp), torch.nan_to_num(big[2])) and torch.equal(torch.nan_to_num(br), torch.nan_to_num(big[3]))
+
+
 def test_sample_skips_null_outputs(loaders):
     """amp_motion_sample: any output pointer may be NULL (include/amp_engine.h); the others are unchanged by that."""
     import ctypes as C
