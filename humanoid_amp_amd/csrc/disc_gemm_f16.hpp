@@ -149,6 +149,32 @@ __device__ __forceinline__ bool f16_tile_of_block(const GemmF16Args& g, int& mt,
   return f16_tile_of_block(g, blockIdx.x, mt, nt);
 }
 
+// ---- layer 2 on v_mfma_f32_16x16x32_f16 ------------------------------------------------------------------------------
+// On MI355X the matrix pipes are power-limited on real operands, and two waves per SIMD sustain 13 % more FLOP/s with the
+// 16 x 16 x 32 shape than with 32 x 32 x 16 (bare streams 1 820-1 836 vs 1 617-1 626 TFLOP/s at 1.85 vs 1.61 GHz,
+// tools/mfma_shape_power.hip; inside the 256 x 256 layer-2 kernel 78.8 -> 69.3 us per 32 768 rows).  Every layer-2 (MODE 1)
+// kernel of the fp16 engine therefore uses it -- all of them, so that a row's logit stays independent of the kernel its shard
+// size selects (the instruction's own reduction over its 32 k-values is part of the result).  Operand / result layout of
+//   D[i][j] (16 x 16, fp32) += sum_k A[i][k] B[k][j],  k = 0 .. 31:
+//   A: lane l holds row i = l & 15, k = 8 (l >> 4) .. + 7;  B: lane l holds column j = l & 15, the same k;
+//   D: lane l holds column j = l & 15, rows i = 4 (l >> 4) + r in register r = 0 .. 3.
+// Layer 2 passes the WEIGHT rows as A and the activation rows as B: a lane owns ONE activation row (l & 15) and four
+// output columns 4 (l >> 4) + r of the 16-column block.  Per accumulator and k-block (32 values): (w0, x1), (w1, x0), (w0, x0).
+typedef float fx4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ fx4 mfma16(const h8 a, const h8 b, const fx4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+// CANONICAL partial logit of one (activation row, 16-column block): the lane's four columns in register order, then the four
+// lane groups as (g0 + g1) + (g2 + g3) -- every lane of the row ends up with the same value.  bs / ws: bias and output-layer
+// weights of the lane's four columns.
+__device__ __forceinline__ float l2_partial16(const fx4 acc, const float descale, const fv4 bs, const fv4 ws) {
+  float s = fmaxf(acc[0] * descale + bs[0], 0.0f) * ws[0];
+  s += fmaxf(acc[1] * descale + bs[1], 0.0f) * ws[1];
+  s += fmaxf(acc[2] * descale + bs[2], 0.0f) * ws[2];
+  s += fmaxf(acc[3] * descale + bs[3], 0.0f) * ws[3];
+  s = s + __shfl_xor(s, 16, 64);
+  s = s + __shfl_xor(s, 32, 64);
+  return s;
+}
+
 __device__ __forceinline__ void f16_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int BM, int BN, int BK, bool BLOCKS>
@@ -233,7 +259,46 @@ __global__ __launch_bounds__(kBlock, MINW) void disc_gemm_f16_kernel(GemmF16Args
   // hipcc orders the fragment reads itself (explicitly double-buffered fragment sets pinned with sched_barrier were
   // measured: +3 % on the bare ds_read + MFMA loop, spills at 3 workgroups / CU)
   const int ksteps = g.ksteps > 0 ? g.ksteps : g.Kp / 16;
+  // MODE 1 (layer 2): v_mfma_f32_16x16x32_f16, one MFMA per k-block of 32 (see the top of this file); lane (i16, kq)
+  fx4 c16[2 * TM][2 * TN];
+#pragma unroll
+  for (int a = 0; a < 2 * TM; ++a)
+#pragma unroll
+    for (int b = 0; b < 2 * TN; ++b) c16[a][b] = fx4{0.0f, 0.0f, 0.0f, 0.0f};
+  const int i16 = lane & 15, kq = lane >> 4;
+  const _Float16* xa16 = smem + (wm * TM * 32 + i16) * LDK + 8 * kq;
+  const _Float16* wb16 = smem + 2 * BM * LDK + (wn * TN * 32 + i16) * LDK + 8 * kq;
+  auto compute16 = [&](const int) {
+    static_assert(MODE != 1 || BK % 32 == 0, "layer 2 consumes whole k-blocks of 32");
+#pragma unroll
+    for (int kb = 0; kb < BK / 32; ++kb) {
+      h8 x0[2 * TM], x1[2 * TM], w0[2 * TN], w1[2 * TN];
+#pragma unroll
+      for (int a = 0; a < 2 * TM; ++a) {
+        x0[a] = *reinterpret_cast<const h8*>(xa16 + a * 16 * LDK + 32 * kb);
+        x1[a] = *reinterpret_cast<const h8*>(xa16 + BM * LDK + a * 16 * LDK + 32 * kb);
+      }
+#pragma unroll
+      for (int b = 0; b < 2 * TN; ++b) {
+        w0[b] = *reinterpret_cast<const h8*>(wb16 + b * 16 * LDK + 32 * kb);
+        w1[b] = *reinterpret_cast<const h8*>(wb16 + BN * LDK + b * 16 * LDK + 32 * kb);
+      }
+#pragma unroll
+      for (int a = 0; a < 2 * TM; ++a)
+#pragma unroll
+        for (int b = 0; b < 2 * TN; ++b) c16[a][b] = mfma16(w0[b], x1[a], c16[a][b]);
+#pragma unroll
+      for (int a = 0; a < 2 * TM; ++a)
+#pragma unroll
+        for (int b = 0; b < 2 * TN; ++b) c16[a][b] = mfma16(w1[b], x0[a], c16[a][b]);
+#pragma unroll
+      for (int a = 0; a < 2 * TM; ++a)
+#pragma unroll
+        for (int b = 0; b < 2 * TN; ++b) c16[a][b] = mfma16(w0[b], x0[a], c16[a][b]);
+    }
+  };
   auto compute = [&](const int kt) {
+    if constexpr (MODE == 1) { compute16(kt); return; }
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
       if (kt * (BK / 16) + s >= ksteps) break;  // zero padding only (workgroup-uniform)
@@ -323,35 +388,23 @@ __global__ __launch_bounds__(kBlock, MINW) void disc_gemm_f16_kernel(GemmF16Args
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
   } else {
-    // CANONICAL partial logits: one value per (row, 32-column block) = (lane half 0's sequential sum over its 16
-    // registers) + (lane half 1's), written to partial[row][block] with `n_blocks` = N / 32 blocks per row.  Every f16
-    // kernel, whatever its tile, produces the same 16 values per row bit for bit (the accumulators are identical: same k
-    // order, same three products per k-step), and disc_finalize_kernel adds them in one fixed tree -- so a row's logit
+    // CANONICAL partial logits: one value per (row, 32-column block) = the sum of its two 16-column blocks' l2_partial16
+    // (top of this file), written to partial[row][block] with `n_blocks` = N / 32 blocks per row.  Every f16 kernel,
+    // whatever its tile, produces the same 16 values per row bit for bit (the accumulators are identical: same MFMA shape,
+    // same k order, same three products per k-block), and disc_finalize_kernel adds them in one fixed tree -- so a row's logit
     // does not depend on the tile shape the shard size selected (shard equivalence, tests/test_gpu_shard_equivalence.py).
     float* red = reinterpret_cast<float*>(smem);  // [2 TN][BM]
-    const fv4* w34 = reinterpret_cast<const fv4*>(g.w3 + n0 + wn * (TN * 32) + 4 * lh);
-    float sum[TM][TN];
+    const fv4* b16 = reinterpret_cast<const fv4*>(g.bias + n0 + wn * (TN * 32) + 4 * kq);
+    const fv4* w16 = reinterpret_cast<const fv4*>(g.w3 + n0 + wn * (TN * 32) + 4 * kq);
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
+      const fv4 bs0 = b16[(2 * b) * 4], ws0 = w16[(2 * b) * 4], bs1 = b16[(2 * b + 1) * 4], ws1 = w16[(2 * b + 1) * 4];
 #pragma unroll
-      for (int a = 0; a < TM; ++a) sum[a][b] = 0.0f;
-#pragma unroll
-      for (int grp = 0; grp < 4; ++grp) {
-        const fv4 bs = bias4[b * 8 + grp * 2], ws = w34[b * 8 + grp * 2];
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            sum[a][b] += fmaxf(acc[a][b][4 * grp + i] * descale + bs[i], 0.0f) * ws[i];
+      for (int a = 0; a < 2 * TM; ++a) {
+        const float v = l2_partial16(c16[a][2 * b], descale, bs0, ws0) + l2_partial16(c16[a][2 * b + 1], descale, bs1, ws1);
+        if (kq == 0) red[(wn * TN + b) * BM + wm * (TM * 32) + a * 16 + i16] = v;
       }
     }
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-      for (int b = 0; b < TN; ++b) {
-        const float v = sum[a][b] + __shfl_xor(sum[a][b], 32, 64);  // the other lane half holds the other columns
-        if (lh == 0) red[(wn * TN + b) * BM + wm * (TM * 32) + a * 32 + li] = v;
-      }
     __syncthreads();
     constexpr int BPT = 2 * TN;  // 32-column blocks per tile
     const int n_blocks = g.N >> 5;

@@ -31,6 +31,8 @@
 // + a barrier the reader has passed).  Every refill is issued behind a barrier that follows the lgkmcnt(0) of the
 // stage's last reads.  The slow operand has three intervals (>= 2 400 cycles) to land, the L2-warm one two.
 #pragma once
+#include <type_traits>
+
 #include "disc_gemm_f16.hpp"
 
 namespace amp {
@@ -184,6 +186,47 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
 
   fx16 acc[TM][TN];
   h8 x0[TM], x1[TM], w0[TN], w1[TN];
+  // ---- MODE 1 (layer 2) runs on v_mfma_f32_16x16x32_f16 (disc_gemm_f16.hpp): one MFMA covers a whole k-block.  Fragment of
+  // a 16-row block at row R (a multiple of 16), plane pl: lane (i = lane & 15, kq = lane >> 4) reads chunk 4 pl + kq of row
+  // R + i, stored at (4 pl + kq) ^ ((i >> 1) & 7) -- the same swizzle; a ds_read_b128's four 16-lane groups still touch
+  // every bank once.  A k-block is R0 (all weight fragments + the activation fragments of the wave's upper TM 16-row
+  // blocks) M0 (3 x TM x 2 TN MFMAs of 16 cycles = the old 24 of 32) R1 (the lower TM blocks) M1.
+  fx4 c16[2 * TM][2 * TN];
+  h8 xf0[TM], xf1[TM], wf0[2 * TN], wf1[2 * TN];
+  const int i16 = lane & 15, kq = lane >> 4, swz16 = (i16 >> 1) & 7;
+  const int arow16 = (wm * (32 * TM) + i16) * 128, brow16 = kOpA + (wn * (32 * TN) + i16) * 128;
+  const int ch16[2] = {(kq ^ swz16) * 16, ((4 + kq) ^ swz16) * 16};  // plane 0 / 1
+  auto read_w16 = [&](const unsigned char* sb) {
+#pragma unroll
+    for (int b = 0; b < 2 * TN; ++b) {
+      wf0[b] = *reinterpret_cast<const h8*>(sb + brow16 + b * 16 * 128 + ch16[0]);
+      wf1[b] = *reinterpret_cast<const h8*>(sb + brow16 + b * 16 * 128 + ch16[1]);
+    }
+  };
+  auto read_x16 = [&](const unsigned char* sb, const int half) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      xf0[a] = *reinterpret_cast<const h8*>(sb + arow16 + (half * TM + a) * 16 * 128 + ch16[0]);
+      xf1[a] = *reinterpret_cast<const h8*>(sb + arow16 + (half * TM + a) * 16 * 128 + ch16[1]);
+    }
+  };
+  auto mfmas16 = [&](auto half_c) {  // the 3 TM 2 TN MFMAs of one row half, products in the order of every f16 kernel
+    constexpr int H = decltype(half_c)::value;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < 2 * TN; ++b) c16[H * TM + a][b] = mfma16(wf0[b], xf1[a], c16[H * TM + a][b]);
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < 2 * TN; ++b) c16[H * TM + a][b] = mfma16(wf1[b], xf0[a], c16[H * TM + a][b]);
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < 2 * TN; ++b) c16[H * TM + a][b] = mfma16(wf0[b], xf0[a], c16[H * TM + a][b]);
+  };
+  using half0_t = std::integral_constant<int, 0>;
+  using half1_t = std::integral_constant<int, 1>;
   auto read_frags = [&](const unsigned char* sb, const int s) {
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
@@ -198,7 +241,7 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
   };
   // matrix segment: the 24 MFMAs at raised priority between two barriers; `drain`: the wave's outstanding pieces must
   // have landed before the closing barrier (group 0, second k-step of a k-block)
-  auto matrix_segment = [&](bool drain) {
+  auto matrix_segment = [&](bool drain, const int half = 0) {  // half: MODE 1, which TM 16-row blocks the MFMAs are for
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -207,6 +250,10 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
     // fragment first (accumulator registers = output columns: the 512 -> 1 layer is a per-lane sum); MODE 0 passes the
     // ACTIVATION fragment first (registers = output rows, lanes = columns: rows store without a transpose).  The element
     // arithmetic is the same either way -- the MFMA's reduction order depends on k alone.
+    if constexpr (MODE == 1) {
+      if (half == 0) mfmas16(half0_t{});
+      else mfmas16(half1_t{});
+    } else {
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -225,6 +272,7 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
       for (int b = 0; b < TN; ++b)
         acc[a][b] = MODE != 1 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(x0[a], w0[b], acc[a][b], 0, 0, 0)
                               : __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[b], x0[a], acc[a][b], 0, 0, 0);
+    }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -241,8 +289,12 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
     for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+#pragma unroll
+  for (int a = 0; a < 2 * TM; ++a)
+#pragma unroll
+    for (int b = 0; b < 2 * TN; ++b) c16[a][b] = fx4{0.0f, 0.0f, 0.0f, 0.0f};
   if constexpr (KB2) {
-    h8 y0[2][TM], y1[2][TM], v0[2][TN], v1[2][TN];  // fragments of both k-steps
+    h8 y0[2 * TM], y1[2 * TM];  // activation fragments of the wave's 2 TM 16-row blocks, both planes (weights: wf0 / wf1)
     constexpr int NS = KB2;
     auto wait_younger = [&](const int younger) {  // all of the wave's pieces but those of the `younger` newest k-blocks have landed
       const int pieces = younger * np;
@@ -261,44 +313,34 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
     // `younger`: k-blocks q + 2 .. that are in flight when k-block q + 1 is awaited (NS - 2 in the steady loop)
     auto kb = [&](const int q, const bool ahead, const int younger) {  // ahead: k-block q + NS - 1 exists and is issued here
       const unsigned char* sb = lds + (q % NS) * kStage;
-      // R: fragments of both k-steps; stage (q + NS - 1) % NS held k-block q - 1, whose last reads were retired in front of
+      // R: fragments of the whole k-block; stage (q + NS - 1) % NS held k-block q - 1, whose last reads were retired in front of
       // a barrier this wave has passed
+      read_w16(sb);
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-        for (int a = 0; a < TM; ++a) {
-          y0[ks][a] = *reinterpret_cast<const h8*>(sb + arow + a * 32 * 128 + ca[ks][0]);
-          y1[ks][a] = *reinterpret_cast<const h8*>(sb + arow + a * 32 * 128 + ca[ks][1]);
-        }
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-          v0[ks][b] = *reinterpret_cast<const h8*>(sb + brow + b * 32 * 128 + cb[ks][0]);
-          v1[ks][b] = *reinterpret_cast<const h8*>(sb + brow + b * 32 * 128 + cb[ks][1]);
-        }
+      for (int a = 0; a < 2 * TM; ++a) {
+        y0[a] = *reinterpret_cast<const h8*>(sb + arow16 + a * 16 * 128 + ch16[0]);
+        y1[a] = *reinterpret_cast<const h8*>(sb + arow16 + a * 16 * 128 + ch16[1]);
       }
       if (ahead) fill(q + NS - 1, (q + NS - 1) % NS);
       if (grp == 1) wait_younger(younger);  // group 1's pieces of k-block q + 1: before the barrier that ends this interval
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      // M: 2 x 3 TM TN MFMAs between two barriers
+      // M: 3 x 2 TM x 2 TN MFMAs (16 cycles each) between two barriers
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int a = 0; a < 2 * TM; ++a)
 #pragma unroll
-        for (int a = 0; a < TM; ++a)
+        for (int b = 0; b < 2 * TN; ++b) c16[a][b] = mfma16(wf0[b], y1[a], c16[a][b]);
 #pragma unroll
-          for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0[ks][b], y1[ks][a], acc[a][b], 0, 0, 0);
+      for (int a = 0; a < 2 * TM; ++a)
 #pragma unroll
-        for (int a = 0; a < TM; ++a)
+        for (int b = 0; b < 2 * TN; ++b) c16[a][b] = mfma16(wf1[b], y0[a], c16[a][b]);
 #pragma unroll
-          for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1[ks][b], y0[ks][a], acc[a][b], 0, 0, 0);
+      for (int a = 0; a < 2 * TM; ++a)
 #pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-          for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0[ks][b], y0[ks][a], acc[a][b], 0, 0, 0);
-      }
+        for (int b = 0; b < 2 * TN; ++b) c16[a][b] = mfma16(wf0[b], y0[a], c16[a][b]);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       if (grp == 0) wait_younger(younger);  // group 0's pieces of k-block q + 1: behind its MFMAs
@@ -337,16 +379,19 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
     const unsigned char* sb = lds + (q & 1) * kStage;
     // R0: fragments of k-step 0; the other stage (k-block q - 1: its last reads were retired in front of a barrier
     // this wave has passed) takes k-block q + 1 (k-block 1 was issued in the prologue)
-    read_frags(sb, 0);
+    if constexpr (MODE == 1) { read_w16(sb); read_x16(sb, 0); }
+    else read_frags(sb, 0);
     if (q >= 1 && q + 1 < nq) fill(q + 1, (q + 1) & 1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    matrix_segment(false);
+    matrix_segment(false, 0);
     if (!second) return;
-    // R1: fragments of k-step 1; group 1's pieces of k-block q + 1 must have landed before the next barrier
-    read_frags(sb, 1);
+    // R1: fragments of k-step 1 (MODE 1: of the lower TM 16-row blocks); group 1's pieces of k-block q + 1 must have landed
+    // before the next barrier
+    if constexpr (MODE == 1) read_x16(sb, 1);
+    else read_frags(sb, 1);
     if (grp == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    matrix_segment(grp == 0);  // group 0's pieces: behind its MFMAs
+    matrix_segment(grp == 0, 1);  // group 0's pieces: behind its MFMAs
   };
   for (int q = 0; q + 1 < nq; ++q) kblock(q, true);
   kblock(nq - 1, 2 * nq - 1 < ksteps);
@@ -471,33 +516,21 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
 #endif
     continue;
   }
-  // ---- layer-2 epilogue: register r of lane half lh is output column (r & 3) + 8 (r >> 2) + 4 lh of the 32-wide block,
-  //      lane li is activation row li
-  const fv4* bias4 = reinterpret_cast<const fv4*>(g.bias + n0 + wn * (32 * TN) + 4 * lh);
-  const fv4* w34 = reinterpret_cast<const fv4*>(g.w3 + n0 + wn * (32 * TN) + 4 * lh);
-  // canonical partial logits, one per (row, 32-column block): see disc_gemm_f16_kernel's MODE 1 epilogue
+  // ---- layer-2 epilogue: lane (i16, kq) holds activation row i16 of each 16-row block and output columns 4 kq + r of each
+  //      16-column block; canonical partial logits, one per (row, 32-column block) = the sum of its two 16-column blocks'
+  //      l2_partial16 (disc_gemm_f16.hpp) -- the same value whatever kernel / tile computed the accumulators
+  const fv4* bias4 = reinterpret_cast<const fv4*>(g.bias + n0 + wn * (32 * TN) + 4 * kq);
+  const fv4* w34 = reinterpret_cast<const fv4*>(g.w3 + n0 + wn * (32 * TN) + 4 * kq);
   float* red = reinterpret_cast<float*>(lds);  // [4 TN][BM]
-  float sum[TM][TN];
 #pragma unroll
   for (int b = 0; b < TN; ++b) {
+    const fv4 bs0 = bias4[(2 * b) * 4], ws0 = w34[(2 * b) * 4], bs1 = bias4[(2 * b + 1) * 4], ws1 = w34[(2 * b + 1) * 4];
 #pragma unroll
-    for (int a = 0; a < TM; ++a) sum[a][b] = 0.0f;
-#pragma unroll
-    for (int grp4 = 0; grp4 < 4; ++grp4) {
-      const fv4 bs = bias4[b * 8 + grp4 * 2], ws = w34[b * 8 + grp4 * 2];
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) sum[a][b] += fmaxf(acc[a][b][4 * grp4 + i] * descale + bs[i], 0.0f) * ws[i];
+    for (int a = 0; a < 2 * TM; ++a) {
+      const float v = l2_partial16(c16[a][2 * b], descale, bs0, ws0) + l2_partial16(c16[a][2 * b + 1], descale, bs1, ws1);
+      if (kq == 0) red[(wn * TN + b) * BM + wm * (32 * TM) + a * 16 + i16] = v;
     }
   }
-#pragma unroll
-  for (int a = 0; a < TM; ++a)
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-      const float v = sum[a][b] + __shfl_xor(sum[a][b], 32, 64);  // the other lane half holds the other columns
-      if (lh == 0) red[(wn * TN + b) * BM + wm * (32 * TM) + a * 32 + li] = v;
-    }
   __syncthreads();
   constexpr int BPT = 4 * TN;  // 32-column blocks per tile
   const int n_blocks = g.N >> 5;
