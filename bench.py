@@ -453,8 +453,13 @@ def main():
         # limited, and on operands that change from one MFMA to the next the figure is well below the nominal peak
         tc, fc = nat.calibrate_mfma_f16(False, 256, device, with_clock=True)
         tr_, fr = nat.calibrate_mfma_f16(True, 256, device, with_clock=True)
+        # ... and on the stream of the dominant kernel since round 3: v_mfma_f32_16x16x32_f16, two waves per SIMD
+        t16, f16c = nat.calibrate_mfma_f16(True, 256, device, with_clock=True, layer2_stream=True)
         sustained = {"constant_operands": tc, "random_operands": tr_, "core_clock_mhz_constant_operands": fc,
-                     "core_clock_mhz_random_operands": fr}
+                     "core_clock_mhz_random_operands": fr, "random_operands_16x16x32_two_waves": t16,
+                     "core_clock_mhz_random_operands_16x16x32_two_waves": f16c,
+                     "note": "constant / random_operands: bare v_mfma_f32_32x32x16_f16 stream, one wave per SIMD; the dominant kernel "
+                             "(layer 2) issues v_mfma_f32_16x16x32_f16 from two waves per SIMD: its ceiling is the 16x16x32 figure"}
     if rank == 0:
         # HBM traffic of the dominant kernel: PMC FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE per launch, collected
         # in separate rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh) and committed: STATIC
@@ -511,7 +516,7 @@ def main():
                          "vs_fp32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS,
                          # measured on this device in this process: a bare v_mfma_f32_32x32x16_f16 stream, one wave per SIMD
                          "mfma_sustained_tflops": sustained,
-                         "frac_executed_of_sustained_random": (nprod * achieved / sustained["random_operands"]) if sustained else None},
+                         "frac_executed_of_sustained_random": (nprod * achieved / sustained["random_operands_16x16x32_two_waves"]) if sustained else None},
             "roofline_hbm": {"bound": "hbm", "kernels": list(hbm_kernels), "achieved": alg_bytes / (hbm_us * 1e-6) / 1e9 if hbm_us else None,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (alg_bytes / (hbm_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if hbm_us else None,
                              "bytes_per_env_step": algorithmic_bytes_per_env_step(spec), "us": hbm_us,

@@ -336,25 +336,28 @@ class KernelTrace:
 
 
 
-def calibrate_mfma_f16(random_operands: bool, iters: int = 256, device="cuda:0", reps: int = 3, with_clock: bool = False):
+def calibrate_mfma_f16(random_operands: bool, iters: int = 256, device="cuda:0", reps: int = 3, with_clock: bool = False,
+                       layer2_stream: bool = False):
     """TFLOP/s the matrix pipes sustain on a bare fp16 MFMA stream (``amp_calibrate_mfma_f16``): the best of ``reps``
     launches of ~``iters`` x 48 MFMAs per wave, timed by the engine's tracer.  ``with_clock``: also the core clock (MHz)
     the chip sustained inside that launch's MFMA loop (shader-clock ticks / 100 MHz wall ticks, median over workgroups)."""
     lib = load()
     dev = require_gpu(device)
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
-    scratch = torch.zeros(cus * 256 + cus * 4, dtype=torch.float32, device=dev)
+    per_cu = 512 if layer2_stream else 256   # layer2_stream: v_mfma_f32_16x16x32_f16, two waves per SIMD (layer 2's shape)
+    mode = int(bool(random_operands)) | (2 if layer2_stream else 0)
+    scratch = torch.zeros(cus * per_cu + cus * 4, dtype=torch.float32, device=dev)
     flops = C.c_double()
     best, mhz = 0.0, None
     with torch.cuda.device(dev):
         for _ in range(reps + 1):
             with KernelTrace(capacity=4, kernel_filter="mfma_f16_calibration_kernel") as tr:
-                check(lib.amp_calibrate_mfma_f16(int(bool(random_operands)), int(iters), dptr(scratch), scratch.numel(), C.byref(flops),
+                check(lib.amp_calibrate_mfma_f16(mode, int(iters), dptr(scratch), scratch.numel(), C.byref(flops),
                                                  stream_ptr()), "amp_calibrate_mfma_f16")
             ms = tr.records()[-1][1]
             tf = flops.value / (ms * 1e-3) / 1e12
             if tf > best:
                 best = tf
-                ticks = scratch[cus * 256:].view(torch.int64).view(cus, 2).double().cpu()
+                ticks = scratch[cus * per_cu:].view(torch.int64).view(cus, 2).double().cpu()
                 mhz = float((ticks[:, 0] / ticks[:, 1].clamp(min=1)).median()) * 100.0
     return (best, mhz) if with_clock else best

@@ -56,6 +56,50 @@ __global__ __launch_bounds__(256, 1) void mfma_f16_calibration_kernel(float* out
   out[blockIdx.x * 256 + threadIdx.x] = t;
 }
 
+// The layer-2 stream since round 3: v_mfma_f32_16x16x32_f16, TWO waves per SIMD (512 threads), sixteen accumulators of four
+// registers per wave -- the shape and occupancy of the discriminator's dominant kernels.  Same MACs per instruction-cycle as the
+// 32 x 32 x 16 stream; on operands that change from one MFMA to the next it sustains ~13 % more (1.82-1.84 vs 1.62 PFLOP/s).
+typedef float cal_fx4 __attribute__((ext_vector_type(4)));
+template <int ENTROPY>
+__global__ __launch_bounds__(512, 1) void mfma_f16_calibration16_kernel(float* out, int iters, unsigned long long* clocks) {
+  cal_fx4 acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = cal_fx4{0.0f, 0.0f, 0.0f, 0.0f};
+  cal_h8 a[8], b[8];
+  unsigned s = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (ENTROPY) {
+        s = s * 1664525u + 1013904223u;
+        a[k][i] = (_Float16)(((int)((s >> 9) & 0xFFFF) - 32768) * (1.0f / 32768.0f));
+        s = s * 1664525u + 1013904223u;
+        b[k][i] = (_Float16)(((int)((s >> 9) & 0xFFFF) - 32768) * (1.0f / 32768.0f));
+      } else {
+        a[k][i] = (_Float16)(0.5f);
+        b[k][i] = (_Float16)(0.25f);
+      }
+    }
+  const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 96; ++u)  // 96 x (16 x 16 x 32) = 48 x (32 x 32 x 16) MACs
+      acc[u & 15] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u & 7], b[(u * 3 + (u >> 3)) & 7], acc[u & 15], 0, 0, 0);
+  }
+  const unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+  if (threadIdx.x == 0 && clocks) {
+    clocks[2 * blockIdx.x] = c1 - c0;
+    clocks[2 * blockIdx.x + 1] = w1 - w0;
+  }
+  float t = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t += acc[i][r];
+  out[blockIdx.x * 512 + threadIdx.x] = t;
+}
+
 }  // namespace amp
 
 extern "C" {
@@ -67,8 +111,19 @@ int amp_calibrate_mfma_f16(int32_t random_operands, int32_t iters, float* scratc
   int dev = 0, cus = 0;
   AMP_HIP(hipGetDevice(&dev));
   AMP_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  AMP_REQUIRE(scratch_floats >= (int64_t)cus * 256, "amp_calibrate_mfma_f16: scratch must hold %d floats", cus * 256);
   hipStream_t st = (hipStream_t)stream;
+  if (random_operands & 2) {  // bit 1: the 16 x 16 x 32 / two-waves-per-SIMD stream (layer 2's shape); bit 0: random operands
+    AMP_REQUIRE(scratch_floats >= (int64_t)cus * 512, "amp_calibrate_mfma_f16: scratch must hold %d floats", cus * 512);
+    unsigned long long* clocks16 = scratch_floats >= (int64_t)cus * 512 + (int64_t)cus * 4
+                                       ? reinterpret_cast<unsigned long long*>(scratch_dev + (int64_t)cus * 512) : nullptr;
+    { amp::TraceScope trace__("mfma_f16_calibration_kernel", st);
+      if (random_operands & 1) amp::mfma_f16_calibration16_kernel<1><<<(unsigned)cus, 512, 0, st>>>(scratch_dev, iters, clocks16);
+      else amp::mfma_f16_calibration16_kernel<0><<<(unsigned)cus, 512, 0, st>>>(scratch_dev, iters, clocks16);
+    }
+    *flops_out = (double)cus * 8.0 * (double)iters * 96.0 * 16384.0;  // CUs x 8 waves x iters x 96 MFMAs x 2*16*16*32
+    return amp::launch_status("mfma_f16_calibration_kernel");
+  }
+  AMP_REQUIRE(scratch_floats >= (int64_t)cus * 256, "amp_calibrate_mfma_f16: scratch must hold %d floats", cus * 256);
   // clock samples: 2 x uint64 per workgroup (shader-clock ticks, 100 MHz wall ticks) behind the 256 floats per CU
   unsigned long long* clocks = scratch_floats >= (int64_t)cus * 256 + (int64_t)cus * 4
                                    ? reinterpret_cast<unsigned long long*>(scratch_dev + (int64_t)cus * 256) : nullptr;

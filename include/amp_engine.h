@@ -67,7 +67,10 @@ int amp_trace_get(int64_t i, char* name_buf, int64_t name_len, float* ms);
  * scratch_dev: >= 256 floats per CU; with 4 more floats per CU the launch also leaves, behind those 256 * CUs floats, two
  * uint64 per workgroup: shader-clock ticks (s_memtime) and 100 MHz wall ticks (s_memrealtime) across the MFMA loop --
  * their ratio is the core clock the chip sustained under the load.  What the result is for: MI355X is power-limited, the matrix pipes sustain 0.55-0.62
- * of the nominal fp16 peak on changing operands -- the ceiling the discriminator GEMMs' roofline fraction is read against. */
+ * of the nominal fp16 peak on changing operands -- the ceiling the discriminator GEMMs' roofline fraction is read against.
+ * random_operands bit 1 (values 2 / 3): the stream of layer 2 since round 3 instead -- v_mfma_f32_16x16x32_f16, one 8-wave
+ * workgroup per CU (two waves per SIMD), iters x 96 MFMAs per wave, 512 floats (+ 4) of scratch per CU; on changing operands it
+ * sustains ~13 % more than the 32 x 32 x 16 stream. */
 int amp_calibrate_mfma_f16(int32_t random_operands, int32_t iters, float* scratch_dev, int64_t scratch_floats,
                            double* flops_out, amp_stream_t stream);
 
