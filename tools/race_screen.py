@@ -18,7 +18,9 @@ for in_dim in (166, 830, 162):
     g = torch.Generator(device="cuda").manual_seed(in_dim)
     deadline = time.time() + seconds / 3
     while time.time() < deadline:
-        rows = int(torch.randint(24576, 90000, (1,)).item())
+        # half of the draws from the large-shard plans (256 x 256 tiles, 32 768-row chunks), half from the small ones
+        # (64 x 128 / 128 x 128 / 256 x 128 tiles, the k-block-per-segment ring, persistent layer-1 workgroups, register-staged)
+        rows = int(torch.randint(24576, 90000, (1,)).item()) if launches % 8 < 4 else int(torch.randint(1, 24576, (1,)).item())
         x = torch.randn(rows, in_dim, device="cuda", generator=g) * 1.5
         ref = slow.style_reward(x, want_logits=True)["logits"]
         for _ in range(4):  # the same input several times: a race would make the launches disagree
