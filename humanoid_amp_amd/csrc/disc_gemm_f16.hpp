@@ -268,8 +268,12 @@ __global__ __launch_bounds__(kBlock, MINW) void disc_gemm_f16_kernel(GemmF16Args
   const int i16 = lane & 15, kq = lane >> 4;
   const _Float16* xa16 = smem + (wm * TM * 32 + i16) * LDK + 8 * kq;
   const _Float16* wb16 = smem + 2 * BM * LDK + (wn * TN * 32 + i16) * LDK + 8 * kq;
+  // MODE 0 (layer 1): the MFMA of parity beta of a 32-column block takes the weight rows rho(beta, i) = 4 (i >> 1) + (i & 1) + 2 beta
+  // (disc_gemm_f16_dma.hpp: after the epilogue's adjacent-lane exchange a lane holds four consecutive columns of a row)
+  const _Float16* wb0[2] = {smem + 2 * BM * LDK + (wn * TN * 32 + 4 * (i16 >> 1) + (i16 & 1)) * LDK + 8 * kq,
+                            smem + 2 * BM * LDK + (wn * TN * 32 + 4 * (i16 >> 1) + (i16 & 1) + 2) * LDK + 8 * kq};
   auto compute16 = [&](const int) {
-    static_assert(MODE != 1 || BK % 32 == 0, "layer 2 consumes whole k-blocks of 32");
+    static_assert(BK % 32 == 0, "the 16 x 16 x 32 layers consume whole k-blocks of 32");
 #pragma unroll
     for (int kb = 0; kb < BK / 32; ++kb) {
       h8 x0[2 * TM], x1[2 * TM], w0[2 * TN], w1[2 * TN];
@@ -280,25 +284,26 @@ __global__ __launch_bounds__(kBlock, MINW) void disc_gemm_f16_kernel(GemmF16Args
       }
 #pragma unroll
       for (int b = 0; b < 2 * TN; ++b) {
-        w0[b] = *reinterpret_cast<const h8*>(wb16 + b * 16 * LDK + 32 * kb);
-        w1[b] = *reinterpret_cast<const h8*>(wb16 + BN * LDK + b * 16 * LDK + 32 * kb);
+        const _Float16* wsrc = MODE == 0 ? wb0[b & 1] + (b >> 1) * 32 * LDK : wb16 + b * 16 * LDK;
+        w0[b] = *reinterpret_cast<const h8*>(wsrc + 32 * kb);
+        w1[b] = *reinterpret_cast<const h8*>(wsrc + BN * LDK + 32 * kb);
       }
 #pragma unroll
       for (int a = 0; a < 2 * TM; ++a)
 #pragma unroll
-        for (int b = 0; b < 2 * TN; ++b) c16[a][b] = mfma16(w0[b], x1[a], c16[a][b]);
+        for (int b = 0; b < 2 * TN; ++b) c16[a][b] = MODE == 1 ? mfma16(w0[b], x1[a], c16[a][b]) : mfma16(x1[a], w0[b], c16[a][b]);
 #pragma unroll
       for (int a = 0; a < 2 * TM; ++a)
 #pragma unroll
-        for (int b = 0; b < 2 * TN; ++b) c16[a][b] = mfma16(w1[b], x0[a], c16[a][b]);
+        for (int b = 0; b < 2 * TN; ++b) c16[a][b] = MODE == 1 ? mfma16(w1[b], x0[a], c16[a][b]) : mfma16(x0[a], w1[b], c16[a][b]);
 #pragma unroll
       for (int a = 0; a < 2 * TM; ++a)
 #pragma unroll
-        for (int b = 0; b < 2 * TN; ++b) c16[a][b] = mfma16(w0[b], x0[a], c16[a][b]);
+        for (int b = 0; b < 2 * TN; ++b) c16[a][b] = MODE == 1 ? mfma16(w0[b], x0[a], c16[a][b]) : mfma16(x0[a], w0[b], c16[a][b]);
     }
   };
   auto compute = [&](const int kt) {
-    if constexpr (MODE == 1) { compute16(kt); return; }
+    if constexpr (MODE == 0 || MODE == 1) { compute16(kt); return; }
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
       if (kt * (BK / 16) + s >= ksteps) break;  // zero padding only (workgroup-uniform)
@@ -351,42 +356,41 @@ __global__ __launch_bounds__(kBlock, MINW) void disc_gemm_f16_kernel(GemmF16Args
   const float descale = sc.descale;
   const fv4* bias4 = reinterpret_cast<const fv4*>(g.bias + n0 + wn * (TN * 32) + 4 * lh);
   if (MODE == 0) {
-    // relu(. + bias) -> planes of s_h H, transposed through LDS per 32-row slab so that a lane stores 16 B and a
-    // quarter wave covers one contiguous row segment of each plane
-    constexpr int W = TN * 32, EPL = W + 8, CPRO = W / 8;  // slab width, padded row (halves), 16-B chunks per row
-    const float s_h = sc.s_out;
-    _Float16* ep = smem + wave * (2 * 32 * EPL);
+    // relu(. + bias) -> planes of s_h H (planar: plane p at H + p * plane_h, rows of ldh halves).  Register r of lane (i16, kq)
+    // is row 4 kq + r of the 16-row block and column rho(beta, i16) of the 32-column block (beta = MFMA parity): the same
+    // arithmetic and adjacent-lane exchange as the LDS-DMA kernel's layer-1 epilogue -- even lanes end up with the p0 halves of
+    // four consecutive columns 2 i .. 2 i + 3, odd lanes with the p1 halves of 2 (i - 1) .. + 3 -- stored as 8 bytes into the
+    // lane's plane: 64 contiguous bytes per row, plane and 32-column block.
+    const float s_h = sc.s_out, ds = descale * s_h;
+    const uint32_t sel = (i16 & 1) ? 0x03020706u : 0x05040100u;  // v_perm_b32(neighbour, own, sel): odd [nb.hi, own.hi], even [own.lo, nb.lo]
+    const int colw = n0 + wn * (TN * 32);
+    float bsv[TN][2];
 #pragma unroll
-    for (int a = 0; a < TM; ++a) {
+    for (int b = 0; b < TN; ++b)
 #pragma unroll
-      for (int b = 0; b < TN; ++b)
+      for (int be = 0; be < 2; ++be) bsv[b][be] = g.bias[colw + b * 32 + 4 * (i16 >> 1) + (i16 & 1) + 2 * be] * s_h;
+    _Float16* const hp = g.H + (i16 & 1) * g.plane_h + colw + 4 * (i16 >> 1);  // this lane's plane, its first of four columns
+    typedef uint32_t uw2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int grp = 0; grp < 4; ++grp) {
-          const fv4 bs = bias4[b * 8 + grp * 2] * s_h;
-          fv4 v;
+    for (int a = 0; a < 2 * TM; ++a)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = acc[a][b][4 * grp + i];
-          h4 p0, p1;
-          relu_split4(v, descale * s_h, bs, p0, p1);
-          const int col = b * 32 + 8 * grp + 4 * lh;
-          *reinterpret_cast<h4*>(&ep[li * EPL + col]) = p0;
-          *reinterpret_cast<h4*>(&ep[32 * EPL + li * EPL + col]) = p1;
+      for (int r = 0; r < 4; ++r) {
+        const int64_t grow = m0 + wm * (TM * 32) + a * 16 + 4 * kq + r;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          uw2 words;
+#pragma unroll
+          for (int be = 0; be < 2; ++be) {
+            const float v = fmaxf(__builtin_fmaf(c16[a][2 * b + be][r], ds, bsv[b][be]), 0.0f);
+            uint32_t own;
+            asm("v_cvt_f16_f32 %0, %1" : "=v"(own) : "v"(v));
+            asm("v_fma_mixhi_f16 %0, -%0, 1.0, %1 op_sel_hi:[1,0,0]" : "+v"(own) : "v"(v));
+            const uint32_t nb = (uint32_t)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);  // quad_perm [1, 0, 3, 2]
+            words[be] = __builtin_amdgcn_perm(nb, own, sel);
+          }
+          if (grow < g.M) *reinterpret_cast<uw2*>(hp + grow * g.ldh + b * 32) = words;
         }
-      // the slab is private to this wave and a wave's LDS operations execute in order: no workgroup barrier
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-      for (int i = 0; i < (2 * 32 * CPRO) / 64; ++i) {
-        const int idx = lane + 64 * i, p = idx / (32 * CPRO), row = (idx / CPRO) % 32, q = idx % CPRO;
-        const h8 v = *reinterpret_cast<const h8*>(&ep[p * 32 * EPL + row * EPL + 8 * q]);
-        const int64_t grow = m0 + wm * (TM * 32) + a * 32 + row;
-        if (grow < g.M) *reinterpret_cast<h8*>(&g.H[p * g.plane_h + grow * g.ldh + n0 + wn * W + 8 * q]) = v;
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
   } else {
     // CANONICAL partial logits: one value per (row, 32-column block) = the sum of its two 16-column blocks' l2_partial16
     // (top of this file), written to partial[row][block] with `n_blocks` = N / 32 blocks per row.  Every f16 kernel,

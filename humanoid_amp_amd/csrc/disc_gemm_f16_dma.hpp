@@ -133,7 +133,15 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
   const int wm = wave >> 2, wn = wave & 3;
   const int li = lane & 31, lh = lane >> 5;
   const int grp = wave >> 2;
-  int64_t m0 = (int64_t)mt * BM;  // (MODE 0: a persistent workgroup moves on to its next tile, see the end of the epilogue)
+  // Row origin of tile mt.  MODE 0 / 1: the last row tile of a ragged M is moved UP so that it ends at M (its first rows are
+  // computed twice, by this tile and by the one above it, from the same operands: the same bits land twice) -- every tile is
+  // then a full tile, the per-lane fill offsets below do not depend on the tile, and no fill ever leaves the matrix.  MODE 2
+  // (one tile per workgroup, possibly accumulating into C) keeps mt * BM and clamps its rows instead.
+  auto tile_origin = [&](const int mt_) -> int64_t {
+    const int64_t o = (int64_t)mt_ * BM;
+    return (MODE != 2 && o + BM > g.M && g.M >= BM) ? g.M - BM : o;
+  };
+  int64_t m0 = tile_origin(mt);  // (MODE 0: a persistent workgroup moves on to its next tile, see the end of the epilogue)
   int n0 = nt * BN;
   const int nq = (MODE == 2 && g.k_slices > 1) ? g.Kp / kDmaKB / g.k_slices : g.Kp / kDmaKB;  // k-blocks (of this slice)
   const int q0 = slice * nq;
@@ -144,28 +152,40 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
   // chunk (l & 7) = source chunk (l & 7) ^ ((row >> 1) & 7)
   constexpr int NPA = BM / 32, NPB = BN / 32, NP = NPA > NPB ? NPA : NPB;
   const int np = grp == 0 ? NPA : NPB;
-  const _Float16* src[NP];
-  auto plan_fills = [&]() {  // the wave's source addresses for the tile at (m0, n0)
-    const int64_t last = g.M - 1;  // rows past M re-read the last row; their results are never stored
+  // A piece's source = a wave-uniform base (the tile's first row of the wave's operand, k-block q0: SGPRs) + a 32-bit
+  // per-lane offset (row inside the tile x row pitch + swizzled chunk): eight VGPRs instead of eight 64-bit pointers.
+  uint32_t soff[NP];
+  const unsigned char* sbase;
+  const uint32_t pitch = (uint32_t)(4 * (grp == 0 ? g.lda : (int64_t)g.Kp));  // bytes per row: 2 * ld halves
+  {
+    // rows past M (only when M < BM, or in MODE 2's last row tile) re-read the last valid row; their results are never stored
+    const int64_t left = MODE == 2 ? g.M - m0 : g.M;
+    const int rows_ok = grp == 0 ? (left < BM ? (int)left : BM) : BN;
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       const int r = (wave & 3) * (8 * np) + j * 8 + (lane >> 3);
       const int c = (lane & 7) ^ ((r >> 1) & 7);
-      if (grp == 0) {
-        const int64_t m = m0 + r < last ? m0 + r : last;
-        src[j] = g.A + m * (2 * g.lda) + 8 * c + (int64_t)q0 * 64;
-      } else {
-        src[j] = g.W + (int64_t)(n0 + r) * (2 * (int64_t)g.Kp) + 8 * c + (int64_t)q0 * 64;
-      }
+      const int rr = r < rows_ok ? r : rows_ok - 1;
+      soff[j] = (uint32_t)rr * pitch + 16u * (uint32_t)c;
     }
+  }
+  auto plan_fills = [&]() {  // the wave-uniform base of the tile at (m0, n0)
+    const unsigned char* base = grp == 0 ? reinterpret_cast<const unsigned char*>(g.A) + m0 * (int64_t)pitch
+                                         : reinterpret_cast<const unsigned char*>(g.W) + (int64_t)n0 * pitch;
+    base += (int64_t)q0 * 128;
+    // wave-uniform by construction (grp, m0, n0 are): pin it into SGPRs
+    const uint64_t bits = reinterpret_cast<uint64_t>(base);
+    sbase = reinterpret_cast<const unsigned char*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(bits >> 32)) << 32) |
+                                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bits));
   };
   plan_fills();
   const int fill_base = grp * kOpA + (wave & 3) * (np * 1024);
   auto fill = [&](int q, int stage) {  // the wave's pieces of k-block q
     unsigned char* sb = lds + stage * kStage + fill_base;
+    const unsigned char* qb = sbase + q * 128;
 #pragma unroll
     for (int j = 0; j < NP; ++j)
-      if (j < np) __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + q * 64), (lptr_t)(sb + j * 1024), 16, 0, 0);
+      if (j < np) __builtin_amdgcn_global_load_lds((gptr_t)(qb + soff[j]), (lptr_t)(sb + j * 1024), 16, 0, 0);
   };
   // outstanding pieces after a k-block's fill, for the counted wait of the prologue
   (void)np;
@@ -196,11 +216,28 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
   const int i16 = lane & 15, kq = lane >> 4, swz16 = (i16 >> 1) & 7;
   const int arow16 = (wm * (32 * TM) + i16) * 128, brow16 = kOpA + (wn * (32 * TN) + i16) * 128;
   const int ch16[2] = {(kq ^ swz16) * 16, ((4 + kq) ^ swz16) * 16};  // plane 0 / 1
+  // MODE 0 (layer 1: lanes of the result = output COLUMNS) feeds the two MFMAs of a 32-column block with the weight rows
+  //   rho(beta, i) = 4 (i >> 1) + (i & 1) + 2 beta,  beta = 0 / 1:  {0,1,4,5,...,28,29} and {2,3,6,7,...,30,31},
+  // so that after the adjacent-lane exchange of the epilogue a lane holds FOUR consecutive columns of a row (one word from
+  // each MFMA): an 8-byte store, a whole 128-B line per row and instruction.  The gather is free: a per-lane row offset;
+  // its swizzle term is ((rho >> 1) & 7) = (2 (i >> 1) + beta) & 7, and a ds_read_b128's 16-lane groups still cover the banks.
+  int waddr0[2][2];  // [beta][plane]: byte offset of the lane's chunk of its weight row inside a stage
+#pragma unroll
+  for (int be = 0; be < 2; ++be) {
+    const int rho = 4 * (i16 >> 1) + (i16 & 1) + 2 * be, sw = (2 * (i16 >> 1) + be) & 7;
+    waddr0[be][0] = kOpA + (wn * (32 * TN) + rho) * 128 + (kq ^ sw) * 16;
+    waddr0[be][1] = kOpA + (wn * (32 * TN) + rho) * 128 + ((4 + kq) ^ sw) * 16;
+  }
   auto read_w16 = [&](const unsigned char* sb) {
 #pragma unroll
     for (int b = 0; b < 2 * TN; ++b) {
-      wf0[b] = *reinterpret_cast<const h8*>(sb + brow16 + b * 16 * 128 + ch16[0]);
-      wf1[b] = *reinterpret_cast<const h8*>(sb + brow16 + b * 16 * 128 + ch16[1]);
+      if constexpr (MODE == 0) {
+        wf0[b] = *reinterpret_cast<const h8*>(sb + waddr0[b & 1][0] + (b >> 1) * 32 * 128);
+        wf1[b] = *reinterpret_cast<const h8*>(sb + waddr0[b & 1][1] + (b >> 1) * 32 * 128);
+      } else {
+        wf0[b] = *reinterpret_cast<const h8*>(sb + brow16 + b * 16 * 128 + ch16[0]);
+        wf1[b] = *reinterpret_cast<const h8*>(sb + brow16 + b * 16 * 128 + ch16[1]);
+      }
     }
   };
   auto read_x16 = [&](const unsigned char* sb, const int half) {
@@ -215,15 +252,18 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
-      for (int b = 0; b < 2 * TN; ++b) c16[H * TM + a][b] = mfma16(wf0[b], xf1[a], c16[H * TM + a][b]);
+      for (int b = 0; b < 2 * TN; ++b)
+        c16[H * TM + a][b] = MODE == 1 ? mfma16(wf0[b], xf1[a], c16[H * TM + a][b]) : mfma16(xf1[a], wf0[b], c16[H * TM + a][b]);
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
-      for (int b = 0; b < 2 * TN; ++b) c16[H * TM + a][b] = mfma16(wf1[b], xf0[a], c16[H * TM + a][b]);
+      for (int b = 0; b < 2 * TN; ++b)
+        c16[H * TM + a][b] = MODE == 1 ? mfma16(wf1[b], xf0[a], c16[H * TM + a][b]) : mfma16(xf0[a], wf1[b], c16[H * TM + a][b]);
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
-      for (int b = 0; b < 2 * TN; ++b) c16[H * TM + a][b] = mfma16(wf0[b], xf0[a], c16[H * TM + a][b]);
+      for (int b = 0; b < 2 * TN; ++b)
+        c16[H * TM + a][b] = MODE == 1 ? mfma16(wf0[b], xf0[a], c16[H * TM + a][b]) : mfma16(xf0[a], wf0[b], c16[H * TM + a][b]);
   };
   using half0_t = std::integral_constant<int, 0>;
   using half1_t = std::integral_constant<int, 1>;
@@ -250,7 +290,7 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
     // fragment first (accumulator registers = output columns: the 512 -> 1 layer is a per-lane sum); MODE 0 passes the
     // ACTIVATION fragment first (registers = output rows, lanes = columns: rows store without a transpose).  The element
     // arithmetic is the same either way -- the MFMA's reduction order depends on k alone.
-    if constexpr (MODE == 1) {
+    if constexpr (MODE != 2) {
       if (half == 0) mfmas16(half0_t{});
       else mfmas16(half1_t{});
     } else {
@@ -379,7 +419,7 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
     const unsigned char* sb = lds + (q & 1) * kStage;
     // R0: fragments of k-step 0; the other stage (k-block q - 1: its last reads were retired in front of a barrier
     // this wave has passed) takes k-block q + 1 (k-block 1 was issued in the prologue)
-    if constexpr (MODE == 1) { read_w16(sb); read_x16(sb, 0); }
+    if constexpr (MODE != 2) { read_w16(sb); read_x16(sb, 0); }
     else read_frags(sb, 0);
     if (q >= 1 && q + 1 < nq) fill(q + 1, (q + 1) & 1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -387,14 +427,14 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
     if (!second) return;
     // R1: fragments of k-step 1 (MODE 1: of the lower TM 16-row blocks); group 1's pieces of k-block q + 1 must have landed
     // before the next barrier
-    if constexpr (MODE == 1) read_x16(sb, 1);
+    if constexpr (MODE != 2) read_x16(sb, 1);
     else read_frags(sb, 1);
     if (grp == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     matrix_segment(grp == 0, 1);  // group 0's pieces: behind its MFMAs
   };
   for (int q = 0; q + 1 < nq; ++q) kblock(q, true);
-  kblock(nq - 1, 2 * nq - 1 < ksteps);
+  kblock(nq - 1, MODE != 2 || 2 * nq - 1 < ksteps);  // (the 16 x 16 x 32 layers consume whole k-blocks: R1 / M1 are row halves there)
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
   __syncthreads();  // every wave is done with the stages: the scratch below reuses them
@@ -442,20 +482,21 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
     vb += gridDim.x;
     const bool more = f16_tile_of_block(g, vb, mt, nt);
     if (more) {
-      m0 = (int64_t)mt * BM;
+      m0 = tile_origin(mt);
       n0 = nt * BN;
       plan_fills();
       fill(0, 0);
       if (nq > 1) fill(1, 1);
     }
-    // ---- layer-1 epilogue.  Accumulator register r of lane (li, lh) is output ROW (r & 3) + 8 (r >> 2) + 4 lh of the
-    // 32 x 32 block and COLUMN li: relu_split4's arithmetic per value (fma, max, two roundings to fp16), then adjacent lanes
-    // swap their (p0, p1) words (one DPP move + one v_perm_b32) so that even lanes hold the p0 halves of columns (li, li + 1)
-    // and odd lanes the p1 halves of (li - 1, li), and ONE buffer_store_dword per (row, 32-column k-block) writes the
-    // block's [p0 x 32 | p1 x 32] line: 128 contiguous bytes per lane half, no transpose through LDS (round 1's slab
-    // transposes cost 1.6 M bank-conflict cycles per launch and ran with the matrix pipes idle).
-    // The buffer is the wave's band of rows: base and extent in four SGPRs, a scalar offset per (register, block), one
-    // per-lane offset for everything -- and rows past M fall outside the extent, so the hardware drops them (no mask).
+    // ---- layer-1 epilogue.  Accumulator register r of lane (i16, kq) is output ROW 4 kq + r of the 16-row block and, in
+    // the MFMA of parity beta of a 32-column block, COLUMN rho(beta, i16) (see read_w16).  Per value relu_split4's arithmetic
+    // (fma, max, two roundings to fp16: v_cvt_f16_f32 for p0 into the word's low half, ONE v_fma_mixhi_f16 for rn16(v - p0) --
+    // exact difference, single rounding -- into its high half), then adjacent lanes swap words (one DPP move + one v_perm_b32):
+    // even lanes hold the p0 halves of columns (rho(i), rho(i + 1)), odd lanes the p1 halves of (rho(i - 1), rho(i)) -- for
+    // beta = 0 AND beta = 1, i.e. FOUR consecutive columns 2 i .. 2 i + 3 (i even) -- and ONE buffer_store_dwordx2 per
+    // (row, 32-column k-block) writes the block's [p0 x 32 | p1 x 32] line: 128 contiguous bytes per 16 lanes, four rows per
+    // instruction, no transpose through LDS.  The buffer is the wave's band of rows: base and extent in four SGPRs, a scalar
+    // offset per (register, block), one per-lane offset for everything -- rows past M fall outside the extent and are dropped.
     const float s_h = sc.s_out, ds = descale * s_h;
     const uint32_t row_pitch = (uint32_t)(2 * g.ldh * (int64_t)sizeof(_Float16));
     const int band = __builtin_amdgcn_readfirstlane(wm) * (32 * TM);       // the wave's first row inside the tile
@@ -464,43 +505,36 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
     const int valid = rows_left <= 0 ? 0 : (rows_left < 32 * TM ? (int)rows_left : 32 * TM);
     unsigned char* const hband = reinterpret_cast<unsigned char*>(g.H) + (tile_m0 + band) * (int64_t)row_pitch + (col0 >> 5) * 128;
     const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(hband, 0, (int)((uint32_t)valid * row_pitch), 0x00020000);
-    const uint32_t lane_off = (uint32_t)(4 * lh) * row_pitch + (uint32_t)((li & 1) * 64 + (li >> 1) * 4);
-    const uint32_t sel = (li & 1) ? 0x03020706u : 0x05040100u;  // v_perm_b32(neighbour, own, sel): odd [nb.hi, own.hi], even [own.lo, nb.lo]
-    float bs[TN];
+    const uint32_t lane_off = (uint32_t)(4 * kq) * row_pitch + (uint32_t)((i16 & 1) * 64 + (i16 >> 1) * 8);
+    const uint32_t sel = (i16 & 1) ? 0x03020706u : 0x05040100u;  // v_perm_b32(neighbour, own, sel): odd [nb.hi, own.hi], even [own.lo, nb.lo]
+    float bs[TN][2];
 #pragma unroll
-    for (int b = 0; b < TN; ++b) bs[b] = g.bias[col0 + b * 32 + li] * s_h;
-    // Per value: half a v_pk_fma_f32, v_max, v_cvt_f16_f32 (p0 into the low half of the word) and ONE v_fma_mixhi_f16 that
-    // writes rn16(v - p0) into the word's high half (v - p0 is exact in fp32, so this is the same single rounding as
-    // (_Float16)(v - (float)p0) -- hipcc's version of that line was cvt, sub, cvt_sdwa, or: 9 VALU instructions per value with
-    // the exchange, now 5.5; at K = 192 the epilogue's VALU time is of the order of the tile's MFMA time).
-    typedef float fv2 __attribute__((ext_vector_type(2)));
+    for (int b = 0; b < TN; ++b)
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+      for (int be = 0; be < 2; ++be) bs[b][be] = g.bias[col0 + b * 32 + 4 * (i16 >> 1) + (i16 & 1) + 2 * be] * s_h;
+    typedef uint32_t uw2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-      for (int r = 0; r < 16; r += 2)
+    for (int a = 0; a < 2 * TM; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
-          fv2 t;
-          t.x = acc[a][b][r];
-          t.y = acc[a][b][r + 1];
-          const fv2 dsv = {ds, ds}, bsv = {bs[b], bs[b]};
-          t = __builtin_elementwise_fma(t, dsv, bsv);
+          uw2 words;
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const float v = fmaxf(i ? t.y : t.x, 0.0f);
+          for (int be = 0; be < 2; ++be) {
+            const float v = fmaxf(__builtin_fmaf(c16[a][2 * b + be][r], ds, bs[b][be]), 0.0f);
             uint32_t own;
             asm("v_cvt_f16_f32 %0, %1" : "=v"(own) : "v"(v));
             asm("v_fma_mixhi_f16 %0, -%0, 1.0, %1 op_sel_hi:[1,0,0]" : "+v"(own) : "v"(v));
             const uint32_t nb = (uint32_t)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);  // quad_perm [1, 0, 3, 2]
-            const uint32_t word = __builtin_amdgcn_perm(nb, own, sel);
-            const int rr = r + i;
-            const int soff = (int)((uint32_t)(a * 32 + (rr & 3) + 8 * (rr >> 2)) * row_pitch) + b * 128;  // wave-uniform
-#ifdef AMP_L1_NO_STORES  // microbenchmark ablation (CONC0=1): everything but the stores; `word` is kept alive by an empty asm
-            asm volatile("" ::"v"(word));
-#else
-            __builtin_amdgcn_raw_buffer_store_b32(word, hrsrc, (int)lane_off, soff, AMP_L1_STORE_AUX);
-#endif
+            words[be] = __builtin_amdgcn_perm(nb, own, sel);
           }
+          const int soff = (int)((uint32_t)(a * 16 + r) * row_pitch) + b * 128;  // wave-uniform
+#ifdef AMP_L1_NO_STORES  // microbenchmark ablation (CONC0=1): everything but the stores; the words are kept alive by an empty asm
+          asm volatile("" ::"v"(words[0]), "v"(words[1]));
+#else
+          __builtin_amdgcn_raw_buffer_store_b64(words, hrsrc, (int)lane_off, soff, AMP_L1_STORE_AUX);
+#endif
         }
 #ifdef AMP_DMA_TIMELINE
     AMP_DMA_STAMP(3);
