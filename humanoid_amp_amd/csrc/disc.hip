@@ -418,7 +418,10 @@ enum { kPlanRegister = 0, kPlanDmaSmall = 1, kPlanDmaMid = 2, kPlanDmaLarge = 3,
 static int f16_plan(const AmpDisc* h, int64_t rows) {
   if (h->h1 % kDmaBN != 0 || h->h2 % kDmaBN != 0) return kPlanRegister;   // the LDS-DMA tiles need 256-column multiples
   if ((rows + kDmaBM - 1) / kDmaBM * (h->h2 / kDmaBN) >= 192) return kPlanDmaLarge;  // >= ~1 tile of 256 x 256 per CU
-  if (rows >= 12288) return kPlanDmaMid;     // layer 1: 256 x 256, layer 2: 256 x 128
+  // layer 1: 256 x 256, layer 2: 256 x 128 -- only where those tiles fill the chip in whole rounds (16 384 rows: 256 layer-2
+  // tiles); between 16 384 and 24 576 rows the 128 x 128 tiles' finer granularity wins (20 000 envs: 142 -> 124 us per step,
+  // same box, round 3)
+  if (rows >= 12288 && rows <= 16384) return kPlanDmaMid;
   if (rows > 5120) return kPlanDmaSmall;     // both layers 128 x 128 (the 8 192-env shards of the multi-GPU configurations)
   // layer 1 128 x 128, layer 2 64 x 128 on the four-stage k-block ring (one workgroup per CU at 4 096 rows): the 4 096-env
   // configuration, 47.2 -> 43.6 us per step against the register-staged 64 x 64 tiles (same box, tools/ab_bench.sh, round 3)
