@@ -77,3 +77,27 @@ def test_discriminator_argument_checks():
     a = d.style_reward(big[:, :166])["style"]
     b = d.style_reward(big[:, :166].contiguous())["style"]
     assert torch.equal(a, b)
+
+
+def test_mfma_calibration_streams_and_argument_checks():
+    """amp_calibrate_mfma_f16 (the measurement aid behind bench.py's roofline.mfma_sustained_tflops): both streams run and land in a
+    plausible band of the nominal 2 516.8 TFLOP/s; the layer-2 stream (v_mfma_f32_16x16x32_f16, two waves per SIMD) needs 512 floats
+    of scratch per CU and says so."""
+    import ctypes as C
+
+    from humanoid_amp_amd import _native as nat
+
+    legacy, mhz = nat.calibrate_mfma_f16(True, 64, with_clock=True)
+    layer2, mhz2 = nat.calibrate_mfma_f16(True, 64, with_clock=True, layer2_stream=True)
+    const2 = nat.calibrate_mfma_f16(False, 64, layer2_stream=True)
+    for v in (legacy, layer2, const2):
+        assert 500.0 < v < 2600.0, v
+    assert 800.0 < mhz < 2600.0 and 800.0 < mhz2 < 2600.0
+    assert const2 > layer2  # constant operands: no multiplier toggling, higher clock
+    lib = nat.load()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    small = torch.zeros(cus * 256, device="cuda")
+    flops = C.c_double()
+    with torch.cuda.device(0):
+        rc = lib.amp_calibrate_mfma_f16(3, 8, nat.dptr(small), small.numel(), C.byref(flops), nat.stream_ptr())
+    assert rc < 0 and b"scratch must hold" in lib.amp_last_error()
