@@ -352,6 +352,19 @@ __host__ __device__ inline int env_dma_lds_floats(int T, int KD, int nd, bool pe
   return ((T * env_dma_row_pitch(KD, nd, obs) + 3) & ~3) + 3 * ndT + 2 * T + 4 * T + 2 * ((KD + 3) & ~3) + (per_env_limits ? T : 1) * (2 * nd + 1);
 }
 
+#ifdef AMP_ENV_TIMELINE  // diagnostic builds only (tools/env_timeline.py): per-workgroup phase stamps, 100 MHz wall clock
+__device__ unsigned long long* g_env_timeline;  // [workgroups][8]
+#define AMP_ENV_STAMP(slot)                                                                                              \
+  do {                                                                                                                   \
+    if (g_env_timeline && threadIdx.x == 0) g_env_timeline[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+extern "C" int amp_debug_env_timeline(unsigned long long* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_env_timeline), &buf, sizeof(buf)) == hipSuccess ? 0 : -2;
+}
+#else
+#define AMP_ENV_STAMP(slot) do {} while (0)
+#endif
+
 template <int T>
 __device__ __forceinline__ void env_step_dma_pass(const EnvPlan& p, const AmpSimState& st, const AmpEnvBuffers& bf,
                                                   int64_t N, int64_t block, float* smem) {
@@ -374,6 +387,7 @@ __device__ __forceinline__ void env_step_dma_pass(const EnvPlan& p, const AmpSim
   const int ndT = (T * nd + 3) & ~3;
   const int RP = env_dma_row_pitch(KD, nd, do_obs);  // == KD whenever observations are written
 
+  AMP_ENV_STAMP(0);
   float* s_img = smem;                     // [T, K*D]  the tile's new AMP rows (== its span of the AMP buffer)
   float* s_act = s_img + ((T * RP + 3) & ~3);  // [T, nd]   flat copies (reward / policy obs)
   float* s_acc = s_act + ndT;
@@ -443,6 +457,7 @@ __device__ __forceinline__ void env_step_dma_pass(const EnvPlan& p, const AmpSim
       for (int e = tid; e < 2 * nd; e += kBlock) s_lim[e] = st.soft_limits[e];
     }
   }
+  AMP_ENV_STAMP(1);  // every DMA piece issued
   // ---- per-env work: one env per lane of the role-0 wave, under the DMA's flight time -------------------------
   const bool env_lane = role == 0 && lane < T;
   const int64_t env = tile_base + lane;
@@ -514,8 +529,10 @@ __device__ __forceinline__ void env_step_dma_pass(const EnvPlan& p, const AmpSim
       if (lane == 0) bf.reset_tile_counts[block] = __popcll(bits);
     }
   }
+  AMP_ENV_STAMP(2);  // (thread 0's wave) per-env work done
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA pieces have landed
   __syncthreads();
+  AMP_ENV_STAMP(3);  // inputs landed, barrier passed
 
   // ---- task reward -------------------------------------------------------------------------------
   if (!g1) {
@@ -571,6 +588,7 @@ __device__ __forceinline__ void env_step_dma_pass(const EnvPlan& p, const AmpSim
     }
   }
 
+  AMP_ENV_STAMP(4);  // reward done
   // ---- outputs: LDS image -> HBM ----------------------------------------------------------------------------
   if (!do_obs) return;
   {  // AMP buffer: the tile's rows are one contiguous 16-B aligned span.  Non-temporal stores (here and for the policy
@@ -580,6 +598,7 @@ __device__ __forceinline__ void env_step_dma_pass(const EnvPlan& p, const AmpSim
     f4* dst4 = reinterpret_cast<f4*>(buf);
     for (int i = tid; i < T * KD / 4; i += kBlock) __builtin_nontemporal_store(img4[i], dst4 + i);
   }
+  AMP_ENV_STAMP(5);  // AMP buffer stores issued
   if (fused) {
     // the same rows, scaled, as the discriminator's input.  A lane owns the column pair (c, c + 1) -- c even, so both
     // sit in one 32-column k-block -- and walks rows r0, r0 + step, ...; `scaled` / `blocks` are compile-time inside
@@ -639,6 +658,7 @@ __device__ __forceinline__ void env_step_dma_pass(const EnvPlan& p, const AmpSim
     if (scaled) { if (blocks) walk(yes{}, yes{}); else walk(yes{}, no{}); }
     else { if (blocks) walk(no{}, yes{}); else walk(no{}, no{}); }
   }
+  AMP_ENV_STAMP(6);  // discriminator input issued
   {  // policy observation (g1_amp_env.py:195-242; humanoid_amp_env.py:126): Pcur current columns of a P-float row
     const int P = p.P, Pcur = p.Pcur, Db = p.Db;
     float* pol = bf.policy_obs + tile_base * P;
@@ -685,6 +705,7 @@ __device__ __forceinline__ void env_step_dma_pass(const EnvPlan& p, const AmpSim
         if (g < G) column(tid - g * Pcur, g, G);
       }
     }
+    AMP_ENV_STAMP(7);  // policy observation issued
     if (p.n_actor > 1) {
       // actor history (g1_amp_env.py:207-242): H = n_actor - 1 older frames of `per` floats behind the current columns.  A
       // lane owns one column of the frame [obs[:Db] | last_actions? | command?] (per-lane constant LDS source) and steps down

@@ -1,0 +1,40 @@
+"""Per-workgroup phase stamps of the fused env-step + expert launch (diagnostic build of the engine: env_step.hip compiled with
+-DAMP_ENV_TIMELINE and linked into tools/bin/libamp_env_tl.so; the product library carries no stamp).  Usage on the GPU box:
+   cp tools/bin/libamp_env_tl.so humanoid_amp_amd/csrc/libamp_engine.so && python tools/env_timeline.py [envs]"""
+import ctypes as C
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from humanoid_amp_amd import _native as nat  # noqa: E402
+from humanoid_amp_amd.workloads import WORKLOADS, HotPath  # noqa: E402
+
+envs = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+lib = nat.load()
+hot = HotPath(WORKLOADS["g1_walk"], envs, "cuda:0", seed=1)
+for _ in range(8):
+    hot.step()
+torch.cuda.synchronize()
+n_wg = 8192
+buf = torch.zeros(n_wg * 8, dtype=torch.int64, device="cuda")
+lib.amp_debug_env_timeline.argtypes = [C.c_void_p]
+assert lib.amp_debug_env_timeline(C.c_void_p(buf.data_ptr())) == 0
+hot.step()
+torch.cuda.synchronize()
+assert lib.amp_debug_env_timeline(C.c_void_p(0)) == 0
+t = buf.view(n_wg, 8).cpu().numpy().astype(np.float64)
+used = (t[:, 0] > 0) & (t[:, 7] > 0)
+t = t[used]
+t0 = t[:, 0].min()
+names = ["start->DMA issued", "per-env work (wave 0)", "wait for inputs + barrier", "reward", "AMP buffer stores issued", "disc input walk",
+         "policy walk"]
+d = np.diff(t, axis=1) * 0.01
+print(f"{used.sum()} env workgroups stamped; launch spans {(t[:, 7].max() - t0) * 0.01:.1f} us")
+for i, nm in enumerate(names):
+    print(f"  {nm:28s} mean {d[:, i].mean():6.2f} us   p90 {np.percentile(d[:, i], 90):6.2f}")
+life = (t[:, 7] - t[:, 0]) * 0.01
+print(f"  workgroup life (0 -> 7)       mean {life.mean():6.2f} us   p90 {np.percentile(life, 90):6.2f}")
+starts = np.sort((t[:, 0] - t0) * 0.01)
+print("  start times (us), deciles:", np.round(np.percentile(starts, [0, 10, 20, 30, 40, 50, 60, 70, 80, 90, 100]), 1))
