@@ -403,28 +403,23 @@ __device__ __forceinline__ void env_step_dma_pass(const EnvPlan& p, const AmpSim
   //  measured equal at K = 2 and 13 % slower at K = 10)
   float* const buf = bf.amp_obs_buffer + tile_base * KD;
   if (do_obs || g1) {
-    // ONE flat sweep of 4-B pieces over the tile's LDS image (T rows of RP floats, contiguous): lane `idx` of the image takes
-    // joint_pos (columns [0, nd)), joint_vel ([nd, 2 nd)) or -- when observations are written -- the old history slot one to
-    // the left (columns [D, K D) <- old [0, K D - D): slot k + 1 <- old slot k, g1_amp_env.py:187-190); the derived columns
-    // [2 nd, D) are masked out (the role-0 wave writes them while these pieces are in flight).  A piece is 64 consecutive
-    // image floats whatever rows they belong to: ceil(T RP / 64) pieces per tile -- 83 for 32 envs at K = 2 -- instead of four
-    // per row (128): issuing the pieces is the longest phase of a workgroup (profiles/r03_env_step_timeline.txt).
-    const int total = T * RP;
-    const float inv_rp = 1.0f / (float)RP;
-    const float* const gp0 = st.joint_pos + tile_base * st.joint_pos_stride;
-    const float* const gv0 = st.joint_vel + tile_base * st.joint_vel_stride;
 #pragma unroll 1
-    for (int p0 = wave * 64; p0 < total; p0 += kBlock) {
-      const int idx = p0 + lane;
-      const int r = row_of(idx, inv_rp), c = idx - r * RP;
-      const float* src = nullptr;
-      if (idx < total) {
-        if (c < nd) src = gp0 + (int64_t)r * st.joint_pos_stride + c;
-        else if (c < 2 * nd) src = gv0 + (int64_t)r * st.joint_vel_stride + (c - nd);
-        else if (do_obs && c >= D) src = buf + r * KD + (c - D);
-      }
-      if (src) dma4_nt(src, s_img + p0);
+  for (int r = wave; r < T; r += 4) {
+    float* row = s_img + r * RP;
+    if (do_obs) {
+#pragma unroll 1
+      for (int c0 = 0; c0 < C; c0 += 64)  // slot k + 1 <- old slot k (g1_amp_env.py:187-190)
+        if (c0 + lane < C) dma4_nt(buf + r * KD + c0 + lane, row + D + c0);
     }
+    const float* gp = st.joint_pos + (tile_base + r) * st.joint_pos_stride;
+    const float* gv = st.joint_vel + (tile_base + r) * st.joint_vel_stride;
+#pragma unroll 1
+    for (int c0 = 0; c0 < nd; c0 += 64)
+      if (c0 + lane < nd) {
+        dma4_nt(gp + c0 + lane, row + c0);
+        dma4_nt(gv + c0 + lane, row + nd + c0);
+      }
+  }
   }
   {
     const int n16 = T * nd / 4;  // T * nd is a multiple of 4 (T >= 8)
