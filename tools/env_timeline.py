@@ -1,6 +1,7 @@
 """Per-workgroup phase stamps of the fused env-step + expert launch (diagnostic build of the engine: env_step.hip compiled with
--DAMP_ENV_TIMELINE and linked into tools/bin/libamp_env_tl.so; the product library carries no stamp).  Usage on the GPU box:
-   cp tools/bin/libamp_env_tl.so humanoid_amp_amd/csrc/libamp_engine.so && python tools/env_timeline.py [envs]"""
+-DAMP_ENV_TIMELINE; the product library carries no stamp).  Build here, run on the GPU box:
+   tools/build_variant.sh env_tl env_step.hip -DAMP_ENV_TIMELINE
+   gpurun -- 'cp tools/bin/libamp_env_tl.so humanoid_amp_amd/csrc/libamp_engine.so && python tools/env_timeline.py [envs]'"""
 import ctypes as C
 import sys
 
