@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of engine-library variants on ONE box: tools/ab_bench.sh <out_dir> <variant.so> [<variant.so> ...]
 # Runs bench.py --no-dropin on the in-tree library and on every variant (copied over it), interleaved, twice; puts the tree's
-# library back at the end.  Variants are built by hand (hipcc -D... -c disc.hip; link with csrc/build/*.o) into tools/bin/.
+# library back at the end.  Variants: tools/build_variant.sh <name> <source.hip> -D...  ->  tools/bin/libamp_<name>.so.
 set -u
 out=$1; shift
 mkdir -p "$out"
