@@ -129,7 +129,8 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
   } else if (!f16_tile_of_block(g, mt, nt)) {
     return;
   }
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: everything derived from it (group, fill duty, tile offsets) stays in SGPRs
   const int wm = wave >> 2, wn = wave & 3;
   const int li = lane & 31, lh = lane >> 5;
   const int grp = wave >> 2;
