@@ -357,3 +357,32 @@ def test_a_rows_logit_does_not_depend_on_the_kernel_plan(in_dim):
     # ... and the rows at the END of a ragged batch (the last row tile is moved up to end at M) equal the same rows scored alone
     tail = d.style_reward(x[30000 - 1500:30000], want_logits=True)["logits"]
     assert torch.equal(d.style_reward(x[:30000], want_logits=True)["logits"][-1500:], tail)
+
+
+@pytest.mark.parametrize("hidden,rows", [((384, 128), 900), ((640, 384), 7000), ((512, 256), 3500), ((512, 256), 40000),
+                                         ((1024, 256), 9000), ((128, 128), 300)])
+def test_other_hidden_widths_vs_fp64(hidden, rows):
+    """Hidden widths other than the reference's 1024 / 512 (agents/*.yaml:31-39): multiples of 128 (the engine's granularity) that are not multiples of 256 stay on
+    the register-staged kernels at every batch size (their 64 x 64 and 128 x 128 tiles, ragged last tiles), 256-multiples take the
+    LDS-DMA plans with one or two column tiles in layer 2 -- all on the 16 x 16 x 32 MFMA layout.  Bar as in
+    test_gemm_engines_vs_fp64: logits within 1e-6 * max(1, |logit|) of the fp64 evaluation."""
+    from humanoid_amp_amd.engine import AmpDiscriminator
+
+    in_dim = 166
+    g = torch.Generator().manual_seed(rows + hidden[0])
+    w = odisc.make_weights(in_dim, seed=9, hidden=hidden)
+    x = torch.randn(rows, in_dim, generator=g) * 1.5
+    mean = torch.randn(in_dim, generator=g, dtype=torch.float64) * 0.2
+    var = torch.rand(in_dim, generator=g, dtype=torch.float64) + 0.1
+    d = AmpDiscriminator([(p.cuda(), q.cuda()) for p, q in w], "cuda:0", running_mean=mean, running_variance=var)
+    out = d.style_reward(x.cuda(), want_logits=True)
+    sub = torch.cat([torch.arange(0, min(rows, 1024)), torch.arange(max(rows - 1024, 0), rows)]).unique()
+    ref = odisc.forward(w, x[sub], mean, var)
+    with torch.no_grad():
+        lg64 = odisc.logits(w, ref["scaled"], dtype=torch.float64)
+    scale = max(1.0, float(lg64.abs().max()))
+    assert float((out["logits"][sub].cpu().double() - lg64).abs().max()) <= 1e-6 * scale
+    assert float((out["style"][sub].cpu() - ref["style"]).abs().max()) <= 2.5e-6 * scale + 1e-6
+    # ... and a row's logit does not depend on the batch it is scored in
+    part = d.style_reward(x[:min(rows, 700)].cuda(), want_logits=True)["logits"]
+    assert torch.equal(part, out["logits"][:part.shape[0]])
