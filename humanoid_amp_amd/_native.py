@@ -12,14 +12,17 @@ import os
 import torch  # noqa: F401  (must be imported first: its libamdhip64.so.7 is the HIP runtime we bind to)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libamp_engine.so")
-ABI_VERSION = 8
+# AMP_ENGINE_LIB: load another build of the SAME library instead of the in-tree one (A/B variants from tools/build_variant.sh:
+# diagnostic stamps, ablations) -- the in-tree product file is never overwritten by an experiment.  ABI and symbols are checked as usual.
+LIB_PATH = os.environ.get("AMP_ENGINE_LIB") or os.path.join(_HERE, "csrc", "libamp_engine.so")
+ABI_VERSION = 9
 
 AMP_DISC_F16X3, AMP_DISC_FP32 = 0, 1
 AMP_DISC_INPUT_F32_ROWS, AMP_DISC_INPUT_F16_BLOCKS = 0, 1
 AMP_PHASE_DONES, AMP_PHASE_REWARD, AMP_PHASE_OBS = 1, 2, 4
 AMP_PHASE_ALL = 7
 AMP_COMMAND_TICK, AMP_COMMAND_RESET = 0, 1
+AMP_RESET_REFERENCE, AMP_RESET_DEFAULT = 0, 1
 TILE_ENVS = 64
 
 
@@ -39,12 +42,13 @@ class AmpMotionDesc(C.Structure):
 class AmpResetArgs(C.Structure):
     _fields_ = [
         ("env_ids", C.c_void_p), ("count", C.c_void_p), ("max_n", C.c_int64), ("seed", C.c_uint64), ("step", C.c_uint64),
-        ("start", C.c_int32), ("K", C.c_int32), ("env_origins", C.c_void_p), ("z_lift", C.c_float), ("reserved", C.c_int32),
+        ("start", C.c_int32), ("K", C.c_int32), ("env_origins", C.c_void_p), ("z_lift", C.c_float), ("mode", C.c_int32),
         ("root_state", C.c_void_p), ("dof_pos", C.c_void_p), ("dof_vel", C.c_void_p), ("amp_obs_buffer", C.c_void_p),
         ("motion_ids", C.c_void_p), ("motion_times", C.c_void_p),
         ("env_motion_ids", C.c_void_p), ("env_motion_start_times", C.c_void_p), ("env_offset", C.c_int64),
         ("episode_length", C.c_void_p), ("last_actions", C.c_void_p), ("just_reset", C.c_void_p), ("n_actions", C.c_int32),
         ("reserved2", C.c_int32), ("step_dev", C.c_void_p),
+        ("default_root_state", C.c_void_p), ("default_joint_pos", C.c_void_p), ("default_joint_vel", C.c_void_p),
     ]
 
 
@@ -221,6 +225,7 @@ SIGNATURES = {
     "amp_disc_style_reward_prescaled_compact": (C.c_int, [_vp, _vp, _i64, _f32, _vp, _f32, _f32, _vp, _vp, _vp, _vp,
                                                           C.POINTER(AmpCompactArgs), _vp]),
     "amp_hot_step": (C.c_int, [C.POINTER(AmpHotStepArgs), _vp]),
+    "amp_disc_train_tt_plan": (C.c_int, [_i32, _i32, _i64, _i64, _i64, _i64, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "amp_disc_style_reward": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 

@@ -51,21 +51,15 @@ __global__ __launch_bounds__(kBlock) void command_kernel(AmpCommandArgs a, int64
 // (g1_amp_env.py:142-167) and _apply_action (:169-173) do with five ATen launches + the command-timer launch:
 //   actions[e] = actions_in[e]; last_actions[e] = actions_in[e]; target[e] = offset[j] + scale[j] * actions_in[e]   (mul, add:
 //   the reference's `self.action_offset + self.action_scale * self.actions`, bit for bit)   + the timers' tick for env < N.
-// A thread owns one (env, joint) element; the threads with joint 0 also tick their env's command timer.
-__global__ __launch_bounds__(kBlock) void pre_physics_kernel(AmpPrePhysicsArgs a, AmpCommandArgs c, int has_tick) {
-  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const int64_t total = a.num_envs * a.n_actions;
-  if (e >= total) return;
-  const int64_t env = e / a.n_actions;
-  const int j = (int)(e - env * a.n_actions);
-  const float v = a.actions_in[e];
-  if (a.actions) a.actions[e] = v;
-  if (a.last_actions) a.last_actions[e] = v;
-  if (a.target) {
-    const float s = a.scale ? a.scale[j] * v : v;
-    a.target[e] = a.offset ? a.offset[j] + s : s;
-  }
-  if (j == 0 && has_tick) {
+// A pure streaming kernel (one 16-B load, up to three 16-B stores per lane: 30 MB at 65 536 envs): the first `copy_blocks`
+// workgroups own four consecutive elements per lane (`vec`: every array 16-B aligned; else one element per lane), the
+// workgroups behind them tick one env's command timer per lane -- the Philox draw of an expired timer diverges only there.
+// (Round 3's body owned one element per lane and ticked from the joint-0 lanes: 10.7 us at 65 536 envs, 2.8 TB/s.)
+__global__ __launch_bounds__(kBlock) void pre_physics_kernel(AmpPrePhysicsArgs a, AmpCommandArgs c, unsigned copy_blocks, int vec) {
+  typedef float pf4 __attribute__((ext_vector_type(4)));
+  if (blockIdx.x >= copy_blocks) {
+    const int64_t env = (int64_t)(blockIdx.x - copy_blocks) * kBlock + threadIdx.x;
+    if (env >= a.num_envs) return;
     const float left = c.time_left[env] - c.step_dt;  // command_time_left -= step_dt (command_kernel's TICK branch)
     if (left <= 0.0f && c.vel_span > 0.0f) {
       float cx, cy, tl;
@@ -76,6 +70,45 @@ __global__ __launch_bounds__(kBlock) void pre_physics_kernel(AmpPrePhysicsArgs a
     } else {
       c.time_left[env] = left;
     }
+    return;
+  }
+  const int64_t total = a.num_envs * a.n_actions;
+  const int n = a.n_actions;
+  const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  auto one = [&](const int64_t e, const int j, const float v) {
+    if (a.actions) a.actions[e] = v;
+    if (a.last_actions) a.last_actions[e] = v;
+    if (a.target) {
+      const float sv = a.scale ? a.scale[j] * v : v;
+      a.target[e] = a.offset ? a.offset[j] + sv : sv;
+    }
+  };
+  if (!vec) {
+    if (q < total) one(q, (int)(q % n), a.actions_in[q]);
+    return;
+  }
+  const int64_t e = 4 * q;
+  if (e >= total) return;
+  int j = (int)(e % n);
+  if (e + 4 > total) {  // the last, partial quad
+    for (int64_t i = e; i < total; ++i) {
+      one(i, j, a.actions_in[i]);
+      if (++j >= n) j = 0;
+    }
+    return;
+  }
+  const pf4 v = *reinterpret_cast<const pf4*>(a.actions_in + e);
+  if (a.actions) *reinterpret_cast<pf4*>(a.actions + e) = v;
+  if (a.last_actions) *reinterpret_cast<pf4*>(a.last_actions + e) = v;
+  if (a.target) {
+    pf4 t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float sv = a.scale ? a.scale[j] * v[i] : v[i];
+      t[i] = a.offset ? a.offset[j] + sv : sv;
+      if (++j >= n) j = 0;
+    }
+    *reinterpret_cast<pf4*>(a.target + e) = t;
   }
 }
 
@@ -146,8 +179,14 @@ int amp_pre_physics_step(const AmpPrePhysicsArgs* a, const AmpCommandArgs* tick,
   AMP_REQUIRE(!tick || !(tick->vel_span > 0.0f) || tick->t_span >= 0.0f, "amp_pre_physics_step: negative resampling-time span");
   hipStream_t st = (hipStream_t)stream;
   const int64_t total = a->num_envs * a->n_actions;
+  const uintptr_t bits = reinterpret_cast<uintptr_t>(a->actions_in) | reinterpret_cast<uintptr_t>(a->actions) |
+                         reinterpret_cast<uintptr_t>(a->last_actions) | reinterpret_cast<uintptr_t>(a->target);
+  const int vec = (bits & 15) == 0;  // (null pointers are aligned)
+  const int64_t lanes = vec ? (total + 3) / 4 : total;
+  const unsigned copy_blocks = (unsigned)((lanes + kBlock - 1) / kBlock);
+  const unsigned tick_blocks = tick ? (unsigned)((a->num_envs + kBlock - 1) / kBlock) : 0u;
   { amp::TraceScope trace__("pre_physics_kernel", st);
-    pre_physics_kernel<<<(unsigned)((total + kBlock - 1) / kBlock), kBlock, 0, st>>>(*a, tick ? *tick : AmpCommandArgs{}, tick ? 1 : 0);
+    pre_physics_kernel<<<copy_blocks + tick_blocks, kBlock, 0, st>>>(*a, tick ? *tick : AmpCommandArgs{}, copy_blocks, vec);
   }
   return launch_status("pre_physics_kernel");
 }

@@ -477,10 +477,10 @@ static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* a
       // with three stages, 28.2 with four; 6 144 rows 29.9 -> 26.8, engine tracer) -- what helps is the extra fill cover: the same
       // schedule on TWO stages measured 31.8 us; with more tiles than CUs two 64-KB workgroups per CU win (12 000 rows: 45.9 vs
       // 49.3 us).  Same accumulation order: bit-identical either way.
-      const bool one_round = (m + 127) / 128 * (h->h2 / 128) <= 256;
+      const bool one_round = (m + 127) / 128 * (h->h2 / 128) <= dma_cu_count();
       if (plan == kPlanDmaSmall) rc = one_round ? launch_dma<1, 2, 1, 4>(g2, m, h->h2, "disc_gemm_f16_dma_kernel<1>", st)
                                                 : launch_dma<1, 2, 1>(g2, m, h->h2, "disc_gemm_f16_dma_kernel<1>", st);
-      else if (plan == kPlanDmaTiny) rc = (m + 63) / 64 * (h->h2 / 128) <= 256 ? launch_dma<1, 1, 1, 4>(g2, m, h->h2, "disc_gemm_f16_dma_kernel<1>", st)
+      else if (plan == kPlanDmaTiny) rc = (m + 63) / 64 * (h->h2 / 128) <= dma_cu_count() ? launch_dma<1, 1, 1, 4>(g2, m, h->h2, "disc_gemm_f16_dma_kernel<1>", st)
                                                                               : launch_dma<1, 1, 1>(g2, m, h->h2, "disc_gemm_f16_dma_kernel<1>", st);
       else if (plan == kPlanDmaMid) rc = launch_dma<1, 4, 1>(g2, m, h->h2, "disc_gemm_f16_dma_kernel<1>", st);
       else rc = launch_dma<1, 4, 2>(g2, m, h->h2, "disc_gemm_f16_dma_kernel<1>", st);

@@ -680,26 +680,53 @@ int gemm_nt(hipStream_t st, const float* A, int64_t lda, int64_t M, const float*
 }
 
 // C[M, N] (ld = ldc) (+)= A^T W with A [K, M] (row pitch lda) and W [K, N] (row pitch ldw): the weight-gradient products
-// dW = dY^T X straight on the row-major batch tensors (disc_gemm_tt_kernel: no transposed copies).  M and N are multiples
-// of 64, the row pitches multiples of 4; split-K as gemm_nt.
+// dW = dY^T X straight on the row-major batch tensors (disc_gemm_tt_kernel: no transposed copies); split-K as gemm_nt.
 // `defer`: the weight-gradient products of a weight come in pairs (prediction loss, gradient penalty): *defer == 0 on entry ->
 // this call writes its k-slices into `split` and returns their number in *defer WITHOUT summing them; *defer > 0 on entry -> this
 // call ACCUMULATES into the first min(*defer, own) slices, then the slices are summed once into C (one sum_slices launch and one
 // pass over the slices per weight instead of two).
+//
+// Shape admission (tt_plan; also exported as amp_disc_train_tt_plan so that it is testable without a GPU).  The kernel has NO
+// row / column guards on its tile -- its loads take BM_ / BN_ consecutive floats of every operand row and its epilogue stores BN_
+// consecutive floats of BM_ rows of C -- so the host admits only shapes the chosen tile covers EXACTLY:
+//   M % BM == 0 and N % BN == 0 for the tile that is launched (round 3 checked `% 64` whatever the tile: a 128-wide tile on
+//   N = kN = 192 / 832 would have read and stored 64 columns past every row, profiles/r04_tt_kernel_abort.md),
+//   lda >= M, ldw >= N, ldc >= N (the rows hold the tile), 16-B aligned rows (pitches % 4), K in int32.
+// Tile choice: 128 x 128 (one LDS read per MFMA instead of two) or 128 x 64 where the shape divides AND tiles x k-slices still
+// give every CU two workgroups (>= 512); 64 x 64 otherwise.  The element arithmetic (k ascending within a slice, slices summed in
+// order) depends on the slice count only, not on the tile.
+struct TtPlan { int bm, bn, slices; };
+static int tt_slices(const int tiles, const int64_t K, const bool split) {
+  const int nk = (int)((K + 15) / 16);
+  int slices = 1;
+  if (split)
+    while (slices < 16 && tiles * slices < 1024 && nk / (slices * 2) >= 16) slices *= 2;
+  return slices;
+}
+static int tt_plan(int M, int N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc, bool split, TtPlan* out) {
+  if (M <= 0 || N <= 0 || K <= 0 || K > INT32_MAX) return kShapeNotSupported;
+  if (M % 64 != 0 || N % 64 != 0 || lda % 4 != 0 || ldw % 4 != 0 || ldc % 4 != 0) return kShapeNotSupported;
+  if (lda < M || ldw < N || ldc < N) return kShapeNotSupported;
+  // the slice count is the 64 x 64 plan's whatever tile runs: a row of C is then the same sum on every tile shape (bit-identical)
+  const int slices = tt_slices((M / 64) * (N / 64), K, split);
+  TtPlan p{64, 64, slices};
+  if (M % 128 == 0 && N % 128 == 0 && (M / 128) * (N / 128) * slices >= 512) p = TtPlan{128, 128, slices};
+  else if (M % 128 == 0 && (M / 128) * (N / 64) * slices >= 512) p = TtPlan{128, 64, slices};
+  if (M % p.bm != 0 || N % p.bn != 0) return kShapeNotSupported;  // (cannot happen by construction; the kernel's precondition)
+  *out = p;
+  return AMP_OK;
+}
+
 int gemm_tt(hipStream_t st, const float* A, int64_t lda, int M, const float* W, int64_t ldw, int N, int64_t K, float* C, int64_t ldc,
             int accumulate, float* split, int* defer = nullptr) {
-  if (M % 64 != 0 || N % 64 != 0 || lda % 4 != 0 || ldw % 4 != 0 || K > INT32_MAX) return kShapeNotSupported;
+  TtPlan plan;
+  if (tt_plan(M, N, K, lda, ldw, ldc, split != nullptr, &plan) != AMP_OK) return kShapeNotSupported;
   GemmArgs g{};
   g.A = A; g.lda = lda; g.M = M; g.K = (int32_t)K; g.W = W; g.Kp = (int32_t)ldw; g.N = N; g.C = C; g.ldc = ldc;
   g.accumulate = accumulate;
-  // 64 x 64 tiles (wave tile 32 x 32).  128 x 128 / 128 x 64 tiles (one LDS read per MFMA instead of two) were measured SLOWER at
-  // 3 x 4096 rows (0.909 vs 0.873 ms per step: with 16 k-slices there are too few of them for 256 CUs) and are not instantiated.
-  g.n_tiles = N / 64; g.m_tiles = M / 64;
-  const int tiles = g.m_tiles * g.n_tiles, nk = (int)((K + 15) / 16);
-  int slices = 1;
-  if (split) {
-    while (slices < 16 && tiles * slices < 1024 && nk / (slices * 2) >= 16) slices *= 2;
-  }
+  g.n_tiles = N / plan.bn; g.m_tiles = M / plan.bm;
+  const int tiles = g.m_tiles * g.n_tiles;
+  int slices = plan.slices;
   const int first = defer ? *defer : 0;  // slices the first product of the pair left in `split`
   if (first > 0 && slices > first) slices = first;
   const bool deferred = defer && slices > 1;
@@ -712,7 +739,9 @@ int gemm_tt(hipStream_t st, const float* A, int64_t lda, int M, const float* W, 
   const unsigned grid = (unsigned)(((int64_t)tiles * slices + 7) / 8 * 8);
   {
     amp::TraceScope trace__("disc_gemm_tt_kernel", st);
-    disc_gemm_tt_kernel<64, 64, 16, 4><<<grid, kBlock, 0, st>>>(g);
+    if (plan.bm == 128 && plan.bn == 128) disc_gemm_tt_kernel<128, 128, 16, 4><<<grid, kBlock, 0, st>>>(g);
+    else if (plan.bm == 128) disc_gemm_tt_kernel<128, 64, 16, 4><<<grid, kBlock, 0, st>>>(g);
+    else disc_gemm_tt_kernel<64, 64, 16, 4><<<grid, kBlock, 0, st>>>(g);
   }
   int rc = launch_status("disc_gemm_tt_kernel");
   if (rc != AMP_OK) return rc;
@@ -1080,6 +1109,17 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
   rc = launch_status("adam_multi_kernel");
   if (rc != AMP_OK) return rc;
   return (c.apply_update && !c.defer_refresh) ? disc_refresh_derived(t->disc, st) : AMP_OK;
+}
+
+int amp_disc_train_tt_plan(int32_t M, int32_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t split, int32_t* bm,
+                           int32_t* bn, int32_t* slices) {
+  AMP_REQUIRE(bm && bn && slices, "amp_disc_train_tt_plan: null output");
+  TtPlan p;
+  if (tt_plan(M, N, K, lda, ldw, ldc, split != 0, &p) != AMP_OK)
+    return amp::fail(AMP_ERR_INVALID, "amp_disc_train_tt_plan: shape not admitted (M = %d, N = %d, K = %lld, pitches %lld / %lld / %lld)", M, N,
+                     (long long)K, (long long)lda, (long long)ldw, (long long)ldc);
+  *bm = p.bm; *bn = p.bn; *slices = p.slices;
+  return AMP_OK;
 }
 
 int amp_disc_trainer_refresh(AmpDiscTrainer* t, amp_stream_t stream) {

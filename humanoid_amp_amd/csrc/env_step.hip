@@ -353,12 +353,15 @@ __host__ __device__ inline int env_dma_lds_floats(int T, int KD, int nd, bool pe
 }
 
 #ifdef AMP_ENV_TIMELINE  // diagnostic builds only (tools/env_timeline.py): per-workgroup phase stamps, 100 MHz wall clock
-__device__ unsigned long long* g_env_timeline;  // [workgroups][8]
+__device__ unsigned long long* g_env_timeline;  // [g_env_timeline_rows][8]
+__device__ unsigned g_env_timeline_rows;        // capacity in workgroups: workgroups past it are not stamped
 #define AMP_ENV_STAMP(slot)                                                                                              \
   do {                                                                                                                   \
-    if (g_env_timeline && threadIdx.x == 0) g_env_timeline[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+    if (g_env_timeline && threadIdx.x == 0 && blockIdx.x < g_env_timeline_rows)                                         \
+      g_env_timeline[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime();                              \
   } while (0)
-extern "C" int amp_debug_env_timeline(unsigned long long* buf) {
+extern "C" int amp_debug_env_timeline(unsigned long long* buf, unsigned rows) {
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_env_timeline_rows), &rows, sizeof(rows)) != hipSuccess) return -2;
   return hipMemcpyToSymbol(HIP_SYMBOL(g_env_timeline), &buf, sizeof(buf)) == hipSuccess ? 0 : -2;
 }
 #else

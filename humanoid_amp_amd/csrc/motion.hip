@@ -427,6 +427,38 @@ __global__ __launch_bounds__(kBlock) void reset_compact_apply_kernel(MotionView 
     cnt += s_wcnt[w];
   }
   if (cnt == 0) return;  // uniform: nothing to reset among this workgroup's envs
+  if (a.mode == AMP_RESET_DEFAULT) {
+    // reset_strategy "default" (g1_amp_env.py:338-339, 362-369): default root state (+ env origin) and default joint state for
+    // the provider's write, the per-env clears of _reset_idx (:352-358); no draw, no expert frames, no command resample
+    if (slot >= 0) {
+      const int li = wbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+      s_env[li] = env;
+      s_slot[li] = slot;
+      if (a.episode_length) a.episode_length[env] = 0;
+      if (a.just_reset) a.just_reset[env] = 1;
+    }
+    __syncthreads();
+    const int nd = v.n_dof, width = 13 + 2 * nd;
+    for (int e = tid; e < cnt * width; e += kBlock) {
+      const int li = e / width, j = e - li * width;
+      const int64_t en = s_env[li], sl = s_slot[li];
+      if (j < 13) {
+        float x = a.default_root_state[en * 13 + j];
+        if (j < 3 && a.env_origins) x += a.env_origins[en * 3 + j];
+        if (a.root_state) a.root_state[sl * 13 + j] = x;
+      } else if (j < 13 + nd) {
+        if (a.dof_pos) a.dof_pos[sl * nd + (j - 13)] = a.default_joint_pos[en * nd + (j - 13)];
+      } else {
+        if (a.dof_vel) a.dof_vel[sl * nd + (j - 13 - nd)] = a.default_joint_vel[en * nd + (j - 13 - nd)];
+      }
+    }
+    if (a.last_actions)
+      for (int e = tid; e < cnt * a.n_actions; e += kBlock) {
+        const int li = e / a.n_actions;
+        a.last_actions[s_env[li] * a.n_actions + (e - li * a.n_actions)] = 0.0f;
+      }
+    return;
+  }
   if (slot >= 0) {
     const int li = wbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
     int64_t clip;
@@ -661,6 +693,7 @@ int amp_reset_apply(const AmpMotion* h, const AmpResetArgs* a, amp_stream_t stre
   AMP_REQUIRE(h->has_layout, "amp_reset_apply: call amp_motion_set_obs_layout first");
   AMP_REQUIRE(a->max_n >= 0 && a->K >= 1, "amp_reset_apply: need max_n >= 0 and K >= 1");
   if (a->max_n == 0) return AMP_OK;
+  AMP_REQUIRE(a->mode == AMP_RESET_REFERENCE, "amp_reset_apply: only the reference-motion reset (mode 0); the default strategy is served by amp_reset_compact_apply");
   AMP_REQUIRE(a->env_ids && a->count && a->motion_ids && a->motion_times, "amp_reset_apply: null buffer");
   AMP_REQUIRE(!a->last_actions || a->n_actions >= 1, "amp_reset_apply: last_actions needs n_actions >= 1");
   hipStream_t st = (hipStream_t)stream;
@@ -706,7 +739,14 @@ int amp_reset_compact_apply(const AmpMotion* h, const AmpCompactArgs* c, const A
               "amp_reset_compact_apply: tile_envs must be 8, 16, 32 or 64");
   AMP_REQUIRE(a->env_ids == c->ids && a->count == c->count && a->max_n >= N,
               "amp_reset_compact_apply: the reset arguments must consume the compaction's ids / count (max_n >= num_envs)");
-  AMP_REQUIRE(a->motion_ids && a->motion_times && a->amp_obs_buffer, "amp_reset_compact_apply: null buffer (motion_ids / motion_times / amp_obs_buffer)");
+  AMP_REQUIRE(a->mode == AMP_RESET_REFERENCE || a->mode == AMP_RESET_DEFAULT, "amp_reset_compact_apply: unknown reset mode %d", a->mode);
+  if (a->mode == AMP_RESET_DEFAULT) {
+    AMP_REQUIRE(a->default_root_state && a->default_joint_pos && a->default_joint_vel,
+                "amp_reset_compact_apply: AMP_RESET_DEFAULT needs default_root_state / default_joint_pos / default_joint_vel");
+    AMP_REQUIRE(!cmd, "amp_reset_compact_apply: the default reset strategy does not resample commands (g1_amp_env.py:362-369)");
+  } else {
+    AMP_REQUIRE(a->motion_ids && a->motion_times && a->amp_obs_buffer, "amp_reset_compact_apply: null buffer (motion_ids / motion_times / amp_obs_buffer)");
+  }
   AMP_REQUIRE(!lg || (lg->reward_terms && lg->means && lg->n_terms >= 1 && lg->n_terms <= 64),
               "amp_reset_compact_apply: the reward-log arguments need reward_terms, means and 1..64 terms");
   AMP_REQUIRE(!a->last_actions || a->n_actions >= 1, "amp_reset_compact_apply: last_actions needs n_actions >= 1");

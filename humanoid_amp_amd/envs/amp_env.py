@@ -73,7 +73,7 @@ class _AmpEnv(DirectRLEnv):
             env_offset = dist.get_rank() * int(cfg.scene.num_envs) if dist.is_available() and dist.is_initialized() else 0
         self.env_offset = int(env_offset)
         self._bound, self._reward_fresh, self._reset_args, self._tick_args = {}, False, None, None
-        self._pending_means, self._log_args = None, nat.AmpRewardLogArgs()
+        self._pending_means, self._pending_log, self._log_args = None, None, nat.AmpRewardLogArgs()
         super().__init__(cfg, render_mode, robot=robot, **kwargs)
         nat.require_gpu(self.device)
         data = self.robot.data
@@ -173,6 +173,8 @@ class _AmpEnv(DirectRLEnv):
     def _track_log(self, log):
         agent = getattr(self, "_skrl_agent", None)
         if agent is not None:  # the reference records to TensorBoard every step when an agent is attached (:307-315)
+            if torch.cuda.is_current_stream_capturing():
+                return  # reading the means is a host sync: never while a step is being recorded (_after_replay tracks the replays)
             try:
                 for k, v in log.items():
                     agent.track_data(f"Reward / {k}", v)
@@ -262,8 +264,10 @@ class _AmpEnv(DirectRLEnv):
         (``amp_reset_compact_apply``: reset-id compaction, clip / time draw, reference root / DoF state, K expert frames
         into ``amp_observation_buffer``, episode-length / last-action / just-reset clears, command resample) + the state
         provider's ``write_reset_compact``.  Ids and count never leave the device."""
-        if not self.cfg.reset_strategy.startswith("random"):
-            raise ValueError("device_reset supports the random / random-start strategies")
+        strategy = self.cfg.reset_strategy
+        default = strategy == "default"
+        if not default and not strategy.startswith("random"):
+            raise ValueError(f"Unknown reset strategy: {strategy}")
         k = self._kernel
         key = (self.episode_length_buf.data_ptr(), self.last_actions.data_ptr(), self.command_target_speed.data_ptr(),
                self.command_time_left.data_ptr(), self.amp_observation_buffer.data_ptr())
@@ -283,12 +287,19 @@ class _AmpEnv(DirectRLEnv):
             a.motion_ids, a.motion_times = o["motion_ids"].data_ptr(), o["motion_times"].data_ptr()
             a.env_motion_ids, a.env_motion_start_times = self.motion_ids.data_ptr(), self.motion_start_times.data_ptr()
             a.env_offset = self.env_offset
+            if default:
+                # reset_strategy "default" (g1_amp_env.py:338-339, 362-369): default root / joint state, AMP buffer and commands untouched
+                d = self.robot.data
+                a.mode = nat.AMP_RESET_DEFAULT
+                self._reset_defaults = tuple(t.to(torch.float32).contiguous() for t in
+                                             (d.default_root_state, d.default_joint_pos, d.default_joint_vel))  # kept alive here
+                a.default_root_state, a.default_joint_pos, a.default_joint_vel = (t.data_ptr() for t in self._reset_defaults)
             a.episode_length = self.episode_length_buf.data_ptr()
             if self.IS_G1:
                 a.last_actions, a.n_actions = self.last_actions.data_ptr(), int(self.last_actions.shape[1])
                 if getattr(self.cfg, "num_actor_observations", 1) > 1:
                     a.just_reset = self._just_reset_mask.data_ptr()
-            cmd = self._command_args() if self.IS_G1 else None
+            cmd = self._command_args() if self.IS_G1 and not default else None
             self._reset_args = (key, c, a, cmd, nat.load().amp_reset_compact_apply, self._motion_loader._need_handle())
         _, c, a, cmd, fn, handle = self._reset_args
         a.seed = self._reset_seed & (2**64 - 1)
@@ -305,6 +316,9 @@ class _AmpEnv(DirectRLEnv):
                          C.byref(lg) if lg is not None else None, nat.stream_ptr()), "amp_reset_compact_apply")
         o = self._reset_out
         self.robot.write_reset_compact(k.reset_ids, k.reset_count, o["root_state"], o["dof_pos"], o["dof_vel"])
+        log, self._pending_log = self._pending_log, None
+        if log is not None:  # the means this step's _get_rewards deferred are enqueued now: the agent may look
+            self._track_log(log)
 
     def _reset_strategy_default(self, env_ids):
         d = self.robot.data
@@ -389,12 +403,15 @@ class G1AmpEnv(_AmpEnv):
             drop = () if self.cfg.rew_track_vel > 0.0 else ("rew_track_vel", "error_track_vel")
             if self.device_reset and self._in_step:
                 # inside step() the means ride on the reset launch that follows (amp_reset_compact_apply, one launch fewer)
+                # -- so the agent's tracking waits for that launch too (_reset_on_device): until then the tensor is unwritten
                 means = self._pending_means = torch.empty(len(REWARD_TERMS), dtype=torch.float32, device=self.device)
+                log = self._pending_log = LazyRewardLog(REWARD_TERMS, means, drop)
+                self.extras["log"] = log
             else:
                 means = reward_log_means(self._kernel.reward_terms)
-            log = LazyRewardLog(REWARD_TERMS, means, drop)
-            self.extras["log"] = log
-            self._track_log(log)
+                log = LazyRewardLog(REWARD_TERMS, means, drop)
+                self.extras["log"] = log
+                self._track_log(log)
         return self._kernel.reward
 
     def _after_reset(self, env_ids):

@@ -82,6 +82,8 @@ class DirectRLEnv:
             np.random.seed(seed)
             torch.manual_seed(seed)
             if hasattr(self, "_reset_seed"):  # the engine's counter-based draws follow the run seed as torch.rand does
+                if self._graph is not None and int(seed) != self._reset_seed:
+                    self._graph = None  # a captured step has the old key baked into its launches: back to eager (capture again)
                 self._reset_seed = int(seed)
         self._reset_idx(None)
         return self._get_observations(), self.extras
@@ -97,7 +99,13 @@ class DirectRLEnv:
         the whole step -- hooks, state-provider writes and (synthetic) physics included -- is one graph; what changes from
         step to step lives on the device (the counter-based draws read a device-side step counter that the graph itself
         increments).  Needs ``device_reset=True``.  The returned observation / reward / done tensors are static buffers,
-        overwritten by the next step (as ``extras["amp_obs"]`` always is)."""
+        overwritten by the next step (as ``extras["amp_obs"]`` always is).
+
+        Side effects to know about: the ``warmup`` passes are REAL steps of this env on zero actions (episode lengths,
+        resets, draw counters and physics advance by ``warmup`` steps; the recording pass itself executes nothing).  The
+        graph bakes every pointer and the draw key of the moment: ``reset(seed=...)`` with a new seed drops the graph (the
+        env steps eagerly until ``capture_step`` is called again), and tensors the hooks read must keep their addresses
+        (the env's own buffers do; a state provider that re-allocates its arrays needs a new capture)."""
         if not getattr(self, "device_reset", False):
             raise ValueError("capture_step needs device_reset=True (the host-driven reset reads the reset count back)")
         n_act = int(self.cfg.action_space)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define AMP_ABI_VERSION 8
+#define AMP_ABI_VERSION 9
 
 typedef void* amp_stream_t; /* hipStream_t */
 typedef void* amp_event_t;  /* hipEvent_t  */
@@ -149,7 +149,7 @@ typedef struct {
   int32_t K;
   const float* env_origins; /* dev [num_envs, 3] or NULL */
   float z_lift;
-  int32_t reserved;
+  int32_t mode;             /* AMP_RESET_REFERENCE (0) or AMP_RESET_DEFAULT (1), see below */
   float* root_state;        /* dev [max_n, 13] compact, may be NULL */
   float* dof_pos;           /* dev [max_n, n_dof] compact, may be NULL */
   float* dof_vel;
@@ -170,7 +170,16 @@ typedef struct {
   /* optional device-side step counter: the draws use step + *step_dev.  Lets a captured hipGraph of the env step advance
    * the counter-based streams from one replay to the next (the caller increments *step_dev inside the graph). */
   const uint64_t* step_dev;
+  /* mode == AMP_RESET_DEFAULT -- reset_strategy "default" (g1_amp_env.py:338-339, 362-369): rows i < *count of
+   * root_state / dof_pos / dof_vel get default_root_state[env] (+ env_origins[env] on x, y, z) / default_joint_pos[env] /
+   * default_joint_vel[env]; the per-env clears run; NOTHING else is touched (no clip / time draw, amp_obs_buffer and the
+   * command stay as they are, exactly as in the reference).  All three are required in that mode, ignored otherwise. */
+  const float* default_root_state;  /* dev [num_envs, 13] */
+  const float* default_joint_pos;   /* dev [num_envs, n_dof] */
+  const float* default_joint_vel;   /* dev [num_envs, n_dof] */
 } AmpResetArgs;
+#define AMP_RESET_REFERENCE 0
+#define AMP_RESET_DEFAULT 1
 int amp_reset_apply(const AmpMotion* h, const AmpResetArgs* args, amp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -535,6 +544,13 @@ int amp_disc_trainer_create(AmpDisc* disc, const AmpDiscTrainCfg* cfg, const dou
                             const double* running_variance_dev, double current_count, amp_stream_t stream,
                             AmpDiscTrainer** out);
 int amp_disc_trainer_destroy(AmpDiscTrainer* t);
+/* Shape admission and tile plan of the step's weight-gradient products dW = dY^T X (the "TT" GEMM: C[M, N] (+)= A^T W, A [K, M]
+ * pitch lda, W [K, N] pitch ldw, C pitch ldc; `split` != 0: split-K scratch available).  Pure host arithmetic, no GPU needed:
+ * AMP_OK + the (bm x bn) tile and the k-slice count the step would launch, or AMP_ERR_INVALID when the shape is refused -- the
+ * kernel has no row / column guards, so only shapes its tile covers exactly (M % bm == 0, N % bn == 0, pitches >= widths) pass.
+ * (skrl's AMP._update is third-party; shapes: agents/skrl_g1_walk_amp_cfg.yaml:31-39, discriminator_batch_size :91.) */
+int amp_disc_train_tt_plan(int32_t M, int32_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t split, int32_t* bm,
+                           int32_t* bn, int32_t* slices);
 /* With cfg.defer_refresh: bring the attached AmpDisc's inference-side derived data up to date with the trained weights / scaler. */
 int amp_disc_trainer_refresh(AmpDiscTrainer* t, amp_stream_t stream);
 /* Copies the running statistics (fp64 [in_dim]) into caller-owned device buffers; *count (host) = samples seen. */

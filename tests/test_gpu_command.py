@@ -225,3 +225,24 @@ def test_pre_physics_step_equals_the_separate_launches():
     with torch.cuda.device("cuda:0"):
         nat.check(nat.load().amp_pre_physics_step(C.byref(a2), None, nat.stream_ptr()), "amp_pre_physics_step")
     assert torch.equal(target, acts) and torch.equal(cmd_a, cmd_b)
+    # arrays that are not 16-B aligned take the one-element-per-lane body: same results
+    n3 = 301
+    pool = torch.zeros(3 * n3 * A + 8, device="cuda")
+    src = pool[1 : 1 + n3 * A].view(n3, A)
+    src.copy_(acts[:n3])
+    dst_t, dst_l = pool[n3 * A + 3 : 2 * n3 * A + 3].view(n3, A), pool[2 * n3 * A + 6 : 3 * n3 * A + 6].view(n3, A)
+    a3 = nat.AmpPrePhysicsArgs()
+    a3.actions_in, a3.target, a3.last_actions = src.data_ptr(), dst_t.data_ptr(), dst_l.data_ptr()
+    a3.offset, a3.scale, a3.num_envs, a3.n_actions = off.data_ptr(), scale.data_ptr(), n3, A
+    with torch.cuda.device("cuda:0"):
+        nat.check(nat.load().amp_pre_physics_step(C.byref(a3), None, nat.stream_ptr()), "amp_pre_physics_step")
+    assert torch.equal(dst_t, want_target[:n3]) and torch.equal(dst_l, acts[:n3])
+    # fewer actions than a quad (the joint index wraps inside one lane's four elements)
+    a_s = (torch.randn(64, 3, generator=gen)).cuda()
+    o_s, s_s = torch.randn(3, generator=gen).cuda(), torch.randn(3, generator=gen).cuda()
+    t_s = torch.zeros_like(a_s)
+    a4 = nat.AmpPrePhysicsArgs()
+    a4.actions_in, a4.target, a4.offset, a4.scale, a4.num_envs, a4.n_actions = a_s.data_ptr(), t_s.data_ptr(), o_s.data_ptr(), s_s.data_ptr(), 64, 3
+    with torch.cuda.device("cuda:0"):
+        nat.check(nat.load().amp_pre_physics_step(C.byref(a4), None, nat.stream_ptr()), "amp_pre_physics_step")
+    assert torch.equal(t_s, o_s + s_s * a_s)

@@ -240,3 +240,96 @@ def test_scatter_rows_equals_index_assignment():
                     dict(dst=dst["wide"][:, :29], src=src_a)], ids, count)()
         for k in dst:
             assert torch.equal(dst[k], want[k]), (n_valid, k)
+
+
+def test_default_strategy_on_the_device_equals_the_host_driven_reset():
+    """reset_strategy = "default" (g1_amp_env.py:338-339, 362-369) with device_reset=True (AmpResetArgs.mode =
+    AMP_RESET_DEFAULT inside amp_reset_compact_apply) against the host-driven path (nonzero-style id list ->
+    _reset_strategy_default -> write_*_to_sim) over 30 steps with deaths and time-outs: default root / joint state for the
+    reset envs, amp_observation_buffer and the commands NOT touched by the reset, everything torch.equal."""
+    from humanoid_amp_amd.envs import G1AmpEnv, G1AmpWalkEnvCfg
+
+    def make(device_reset):
+        cfg = G1AmpWalkEnvCfg(reset_strategy="default")
+        cfg.scene.num_envs = 900
+        cfg.episode_length_s = 0.4
+        env = G1AmpEnv(cfg, device_reset=device_reset, reset_seed=4)
+        _deterministic_physics(env.robot)
+        d = env.robot.data   # per-env defaults, so that a row landing on the wrong env would show
+        gen = torch.Generator().manual_seed(3)
+        d.default_joint_pos.copy_(torch.randn(900, 29, generator=gen) * 0.2)
+        d.default_joint_vel.copy_(torch.randn(900, 29, generator=gen) * 0.1)
+        d.default_root_state[:, 7:].copy_(torch.randn(900, 6, generator=gen) * 0.1)
+        d.default_root_state[:, 2] = 0.8 + 0.1 * torch.rand(900, generator=gen).cuda()
+        env.reset(seed=3)
+        env.episode_length_buf.copy_(torch.randint(0, env.max_episode_length, (900,), generator=torch.Generator().manual_seed(1)).cuda())
+        return env
+
+    host, dev = make(False), make(True)
+    gen = torch.Generator().manual_seed(2)
+    n_reset = 0
+    for step in range(30):
+        a = (torch.randn(900, 29, generator=gen) * 0.3).cuda()
+        if step == 10:  # drop a third of the envs below the termination height: deaths on top of the time-outs
+            for e in (host, dev):
+                e.robot.data.body_pos_w[::3, :, 2] = 0.2
+        with torch.cuda.device("cuda:0"):
+            oh, rh, th, toh, xh = host.step(a)
+            torch.cuda.set_sync_debug_mode("error")   # the device path never waits for the GPU inside step()
+            try:
+                od, rd, td, tod, xd = dev.step(a)
+            finally:
+                torch.cuda.set_sync_debug_mode("default")
+        assert torch.equal(th, td) and torch.equal(toh, tod) and torch.equal(rh, rd) and torch.equal(oh["policy"], od["policy"])
+        assert torch.equal(xh["amp_obs"], xd["amp_obs"])
+        for k in ("joint_pos", "joint_vel", "joint_acc", "body_pos_w", "body_quat_w", "body_lin_vel_w", "body_ang_vel_w"):
+            assert torch.equal(getattr(host.robot.data, k), getattr(dev.robot.data, k)), (step, k)
+        assert torch.equal(host.episode_length_buf, dev.episode_length_buf) and torch.equal(host.last_actions, dev.last_actions)
+        assert torch.equal(host.command_target_speed, dev.command_target_speed)
+        assert torch.equal(host.command_time_left, dev.command_time_left)
+        ids = (th | toh).nonzero().squeeze(-1)
+        n_reset += len(ids)
+        if len(ids):
+            d = dev.robot.data
+            assert torch.equal(d.joint_pos[ids], d.default_joint_pos[ids]) and int(dev.episode_length_buf[ids].max()) == 0
+    assert n_reset > 600
+
+
+def test_reward_log_reaches_an_attached_agent_after_the_reset_launch():
+    """with device_reset=True the step's reward-log means are written by the reset launch that FOLLOWS
+    _get_rewards; an attached skrl agent (g1_amp_env.py:307-315) must be handed those means, not the unwritten tensor --
+    eager, and across a captured step (no tracking while recording, every replay tracked)."""
+    from humanoid_amp_amd.engine import REWARD_TERMS
+    from humanoid_amp_amd.envs import G1AmpEnv, G1AmpWalkEnvCfg
+
+    class Agent:
+        def __init__(self):
+            self.seen = []
+
+        def track_data(self, tag, value):
+            self.seen.append((tag, value))
+
+    cfg = G1AmpWalkEnvCfg()
+    cfg.scene.num_envs = 512
+    env = G1AmpEnv(cfg, device_reset=True, reset_seed=1)
+    _deterministic_physics(env.robot)
+    env.reset(seed=1)
+    agent = env._skrl_agent = Agent()
+    gen = torch.Generator().manual_seed(0)
+    names = [n for n in REWARD_TERMS if cfg.rew_track_vel > 0.0 or n not in ("rew_track_vel", "error_track_vel")]
+
+    def check(n_steps):
+        for _ in range(n_steps):
+            agent.seen.clear()
+            _, _, _, _, extras = env.step((torch.randn(512, 29, generator=gen) * 0.3).cuda())
+            want = env._kernel.reward_terms.double().mean(dim=1).cpu()
+            assert [t for t, _ in agent.seen] == [f"Reward / {n}" for n in names]
+            for tag, v in agent.seen:
+                i = REWARD_TERMS.index(tag.split(" / ")[1])
+                assert abs(v - float(want[i])) <= 1e-6 * max(1.0, abs(float(want[i]))), (tag, v, float(want[i]))
+            assert dict(extras["log"]) == {t.split(" / ")[1]: v for t, v in agent.seen}
+
+    check(4)
+    env.capture_step(warmup=2)
+    assert env._graph is not None   # tracking during the recording pass would have been a host sync inside the capture
+    check(4)

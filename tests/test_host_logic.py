@@ -197,3 +197,41 @@ def test_shipped_clips_pass_the_surveys_self_checks():
         assert norm.min() > 1.0 - 1e-6 and norm.max() < 1.0 + 1e-6, (path, norm.min(), norm.max())
         assert len(d["dof_names"]) == dofs and len(d["body_names"]) == bodies
     assert seen == want
+
+
+def test_tt_gemm_shape_admission():
+    """The weight-gradient ("TT") GEMM kernel has no row / column guards: the host plan admits only shapes its tile covers
+    exactly.  Round 3 checked `% 64` whatever the tile, so a 128-wide tile on N = kN = 192 (K D = 166) or 832 (K D = 830)
+    would have read and stored 64 columns past every row (profiles/r04_tt_kernel_abort.md).  Host-only call."""
+    import ctypes as C
+
+    from humanoid_amp_amd import _native as nat
+
+    lib = nat.load()
+
+    def plan(M, N, K, lda=None, ldw=None, ldc=None, split=1):
+        bm, bn, sl = C.c_int32(), C.c_int32(), C.c_int32()
+        rc = lib.amp_disc_train_tt_plan(M, N, K, lda or M, ldw or N, ldc or N, split, C.byref(bm), C.byref(bn), C.byref(sl))
+        return None if rc != 0 else (bm.value, bn.value, sl.value)
+
+    # every product of the training step at BASELINE's minibatch (3 x 4096 rows; gradient-penalty products reduce over 4096):
+    # gW2 [512 x 1024], gW1 [1024 x kN] with kN = 192 (K D = 166) / 832 (K D = 830) -- multiples of 64, NOT of 128
+    for (M, N, K) in [(512, 1024, 12288), (1024, 192, 12288), (1024, 832, 12288), (512, 1024, 4096), (1024, 192, 4096),
+                      (1024, 832, 4096), (512, 1024, 2304), (1024, 192, 6), (64, 64, 1)]:
+        p = plan(M, N, K)
+        assert p is not None, (M, N, K)
+        bm, bn, sl = p
+        assert M % bm == 0 and N % bn == 0 and bm in (64, 128) and bn in (64, 128), (M, N, K, p)   # the tile covers the shape exactly
+        assert 1 <= sl <= 16 and (sl & (sl - 1)) == 0
+        assert sl == 1 or (K + 15) // 16 // sl >= 16                                                # >= 16 k-tiles per slice
+    assert plan(1024, 192, 12288)[1] == 64 and plan(1024, 832, 12288)[1] == 64                      # never a 128-wide tile on kN
+    assert plan(1024, 832, 12288)[0] == 128                                                         # (rows do divide: 128 x 64)
+    assert plan(1024, 832, 12288, split=0)[2] == 1
+    # the slice count does not depend on the tile: a row of C is the same sum whatever tile ran it
+    assert plan(1024, 832, 12288)[2] == plan(1024, 832 - 64, 12288)[2] == 8
+    # refused: ragged tiles, rows that do not hold the tile, unaligned pitches, empty / oversized reductions
+    for bad in [dict(M=1000, N=192, K=4096), dict(M=1024, N=166, K=4096), dict(M=1024, N=192, K=0), dict(M=1024, N=192, K=2**31),
+                dict(M=1024, N=192, K=4096, lda=1000), dict(M=1024, N=192, K=4096, ldw=166), dict(M=1024, N=192, K=4096, ldc=128),
+                dict(M=1024, N=192, K=4096, ldw=194), dict(M=0, N=192, K=4096), dict(M=-64, N=192, K=4096)]:
+        assert plan(**bad) is None, bad
+    assert b"not admitted" in lib.amp_last_error()

@@ -1,16 +1,14 @@
 #!/bin/bash
 # A/B of engine-library variants on ONE box: tools/ab_bench.sh <out_dir> <variant.so> [<variant.so> ...]
-# Runs bench.py --no-dropin on the in-tree library and on every variant (copied over it), interleaved, twice; puts the tree's
-# library back at the end.  Variants: tools/build_variant.sh <name> <source.hip> -D...  ->  tools/bin/libamp_<name>.so.
+# Runs bench.py --no-dropin on the in-tree library and on every variant (selected with AMP_ENGINE_LIB), interleaved, twice.  Variants: tools/build_variant.sh <name> <source.hip> -D...  ->  tools/bin/libamp_<name>.so.
 set -u
 out=$1; shift
 mkdir -p "$out"
-L=humanoid_amp_amd/csrc/libamp_engine.so
-cp $L /tmp/ab_base.so
+# variants are selected through AMP_ENGINE_LIB (humanoid_amp_amd/_native.py): the in-tree library is never touched
 for rep in 1 2; do
   for v in base "$@"; do
-    if [ "$v" = base ]; then cp /tmp/ab_base.so $L; n=base; else cp "$v" $L; n=$(basename "$v" .so); fi
-    timeout -k 10 200 python bench.py --no-dropin --steps 100 > "$out/bench_${n}_$rep.json" 2>/dev/null
+    if [ "$v" = base ]; then lib=""; n=base; else lib=$(readlink -f "$v"); n=$(basename "$v" .so); fi
+    AMP_ENGINE_LIB="$lib" timeout -k 10 200 python bench.py --no-dropin --no-configs --steps 100 > "$out/bench_${n}_$rep.json" 2>/dev/null
     python - "$out/bench_${n}_$rep.json" "$n" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
@@ -20,4 +18,3 @@ print(f"{sys.argv[2]:28s} {d['ms_per_step']*1e3:7.1f} us/step  env {k['env_step_
 PY
   done
 done
-cp /tmp/ab_base.so $L

@@ -18,13 +18,13 @@ hot = HotPath(WORKLOADS["g1_walk"], envs, "cuda:0", seed=1)
 for _ in range(8):
     hot.step()
 torch.cuda.synchronize()
-n_wg = 8192
+n_wg = envs // 8 + envs // 16 + 64  # >= env tiles (>= 8 envs each) + expert tiles of any plan: sized from the grid, and bounded in the kernel
 buf = torch.zeros(n_wg * 8, dtype=torch.int64, device="cuda")
-lib.amp_debug_env_timeline.argtypes = [C.c_void_p]
-assert lib.amp_debug_env_timeline(C.c_void_p(buf.data_ptr())) == 0
+lib.amp_debug_env_timeline.argtypes = [C.c_void_p, C.c_uint]
+assert lib.amp_debug_env_timeline(C.c_void_p(buf.data_ptr()), n_wg) == 0
 hot.step()
 torch.cuda.synchronize()
-assert lib.amp_debug_env_timeline(C.c_void_p(0)) == 0
+assert lib.amp_debug_env_timeline(C.c_void_p(0), 0) == 0
 t = buf.view(n_wg, 8).cpu().numpy().astype(np.float64)
 used = (t[:, 0] > 0) & (t[:, 7] > 0)
 t = t[used]
