@@ -37,7 +37,14 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
 # layer 2 of the discriminator: 2*M*1024*512 of the 2*M*(in*1024+1024*512+512) FLOPs
 # tracer labels: the fp16 engine launches disc_gemm_f16_dma_kernel<1> (LDS-DMA tiles) or disc_gemm_f16_kernel<1>
-DOMINANT_FILTER = {"f16x3": "disc_gemm_f16_", "f32": "disc_gemm_kernel<1>"}
+# (round 4: shards of >= 24 576 rows run both layers as ONE launch, disc_mlp_fused_kernel; the tracer filter matches either)
+DOMINANT_FILTER = {"f16x3": "disc_", "f32": "disc_gemm_kernel<1>"}
+FUSED_KERNEL = "disc_mlp_fused_kernel"
+
+
+def is_dominant(name):
+    """Tracer labels of the dominant kernel: the fused two-layer kernel, or a layer-2 GEMM launch."""
+    return name == FUSED_KERNEL or (name.endswith("<1>") and "disc_gemm" in name)
 DOMINANT_KERNEL = {"f16x3": "disc_gemm_f16_dma_kernel<1>", "f32": "disc_gemm_kernel<1>"}
 MFMA_PEAK_TFLOPS = {"f16x3": 16 * 157.3, "f32": 157.3}  # dense fp16 MFMA = 16 x the fp32 MFMA rate (MI355X_MICROARCH.md)
 MFMA_PER_PRODUCT = {"f16x3": 3, "f32": 1}               # the fp16 engine issues three MFMA products per algorithmic one
@@ -419,7 +426,7 @@ def main():
         trace_every = TRACE_EVERY
         with nat.KernelTrace(capacity=8 * (args.steps + args.warmup) + 8, kernel_filter=dominant_filter, every=trace_every) as tr:
             dt = timed_steps(hot, args.steps, args.warmup, world, collective)
-        timing = (f"HIP events around every {trace_every}th discriminator-GEMM launch inside the timed region (layer-2 launches of "
+        timing = (f"HIP events around every {trace_every}th discriminator-GEMM launch inside the timed region (launches of the dominant kernel in "
                   "the timed steps averaged)")
     value = global_envs * args.steps / dt
     n_sets = len(hot.states)
@@ -431,10 +438,11 @@ def main():
     summary_all = tr_all.summary()
     per_kernel = {k: round(t / 16 * 1e3, 2) for k, (c, t) in summary_all.items()}  # us per step (all launches of the kernel)
     # the engine may run a large shard as several row chunks: layer-2 launches per step, from the all-kernel pass
-    allrecs = [r for r in tr.records() if r[0].endswith("<1>")]  # layer 2
+    allrecs = [r for r in tr.records() if is_dominant(r[0])]  # the fused two-layer kernel, or layer 2
     if allrecs:
         dominant = allrecs[-1][0]
-    per_step = max(1, round(sum(c for k, (c, t) in summary_all.items() if k.endswith("<1>") and dominant_filter in k) / 16))
+    fused = dominant == FUSED_KERNEL
+    per_step = max(1, round(sum(c for k, (c, t) in summary_all.items() if is_dominant(k)) / 16))
     if trace_every == 1:
         recs = allrecs[-args.steps * per_step:]                        # small shards: traced pass = warmup + steps
     else:
@@ -442,7 +450,7 @@ def main():
     if not recs:
         # very short runs (--steps 1..2): the sampled tracer may not have met a layer-2 launch of the timed steps; take the
         # warm-up samples too, and failing that the all-kernel pass right after the timed region
-        recs = allrecs or [(k, t / c) for k, (c, t) in summary_all.items() if k.endswith("<1>") and dominant_filter in k]
+        recs = allrecs or [(k, t / c) for k, (c, t) in summary_all.items() if is_dominant(k)]
         timing += " (too few timed launches sampled: warm-up / post-region launches included)"
     gemm2_ms = sum(ms for _, ms in recs) / max(len(recs), 1)
 
@@ -471,13 +479,17 @@ def main():
             tj = {}
         rows = envs // per_step
         # keys are "kernel<template args>@workgroups" of one launch (tools/pmc_summary.py --traffic-json)
-        if args.disc_precision == "f16x3" and rows >= 24576:
+        if fused:
+            traffic = (tj.get(f"{FUSED_KERNEL}<6>@{(rows + 127) // 128}") or {}).get("hbm_bytes")
+        elif args.disc_precision == "f16x3" and rows >= 24576:
             wg = ((rows + 255) // 256 * 2 + 7) // 8 * 8
             traffic = (tj.get(f"disc_gemm_f16_dma_kernel<1, 4, 2, 0>@{wg}") or tj.get(f"disc_gemm_f16_dma_kernel<1, 4, 2>@{wg}") or {}).get("hbm_bytes")
         if spec.K == 2 and envs >= 32768 and envs % 32 == 0:
             wg = envs // 32 + (envs * spec.K + 255) // 256  # 32-env tiles + 256-sample expert tiles of the fused launch
             hbm_traffic = (tj.get(f"env_step_dma_reference_kernel<32>@{wg}") or {}).get("hbm_bytes")
         flops2 = (2.0 * envs * 1024 * 512 + 2.0 * envs * 512) / per_step   # layer 2 + the fused 512 -> 1 dot, per launch
+        if fused:  # both layers in the launch: + layer 1 (ALGORITHMIC K D, not the padded 192)
+            flops2 += 2.0 * envs * spec.K * spec.D * 1024 / per_step
         achieved = flops2 / (gemm2_ms * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS[args.disc_precision]
         nprod = MFMA_PER_PRODUCT[args.disc_precision]

@@ -23,6 +23,7 @@
 #include "disc_gemm.hpp"
 #include "disc_gemm_f16.hpp"
 #include "disc_gemm_f16_dma.hpp"
+#include "disc_mlp_fused.hpp"
 #include "compact_kernels.hpp"
 
 
@@ -395,6 +396,8 @@ static int f16_kernels_init() {
   AMP_HIP((dma_kernel_init<1, 2, 1, 4>()));
   AMP_HIP((dma_kernel_init<1, 1, 1, 4>()));
   AMP_HIP((dma_kernel_init<1, 1, 1>()));
+  AMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_mlp_fused_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              FusedLds<6>::kBytes));
   if (dev >= 0 && dev < 64) done[dev] = true;
   return AMP_OK;
 }
@@ -414,7 +417,22 @@ constexpr int64_t kChunkRows = 32768;
 //   12 288    26.6 / 64.2   31.1 / 40.6  25.4 / 42.8
 //    8 192    24.8 / 62.0   19.1 / 37.9  18.0 / 29.0   18.5 / 34.6, 20.8 / 37.6
 //    4 096    22.7 / 60.2   16.1 / 35.6  12.0 / 25.9   (64 x 64: 12 / 22 inside the step; 64 x 128 LDS-DMA layer 2: 20.4, ~18 on a 4-stage ring)
-enum { kPlanRegister = 0, kPlanDmaSmall = 1, kPlanDmaMid = 2, kPlanDmaLarge = 3, kPlanDmaTiny = 4 };
+enum { kPlanRegister = 0, kPlanDmaSmall = 1, kPlanDmaMid = 2, kPlanDmaLarge = 3, kPlanDmaTiny = 4, kPlanFused = 5 };
+// Fused two-layer kernel (disc_mlp_fused.hpp): one workgroup per 128 rows and all 512 output columns, so it needs at least one
+// workgroup per CU to pay (AMP_DISC_FUSED_MIN_ROWS overrides the threshold, AMP_DISC_FUSED=0 switches the plan off: A/B runs and
+// the plan-independence tests); shapes: h2 = 512 (the accumulator tile), K D padded to 192 (activation fragments in registers).
+static int64_t fused_min_rows() {
+  static int64_t v = -1;
+  if (v < 0) {
+    const char* off = getenv("AMP_DISC_FUSED");
+    const char* mn = getenv("AMP_DISC_FUSED_MIN_ROWS");
+    v = (off && off[0] == '0') ? INT64_MAX : (mn && atoll(mn) >= kFusedRows ? atoll(mn) : 24576);
+  }
+  return v;
+}
+static bool fused_ok(const AmpDisc* h, int64_t rows) {
+  return h->h2 == kFusedN2 && h->k1h == 192 && h->h1 % 32 == 0 && h->h1 <= 1024 && rows >= fused_min_rows() && rows >= kFusedRows;
+}
 static int f16_plan(const AmpDisc* h, int64_t rows) {
   if (h->h1 % kDmaBN != 0 || h->h2 % kDmaBN != 0) return kPlanRegister;   // the LDS-DMA tiles need 256-column multiples
   if ((rows + kDmaBM - 1) / kDmaBM * (h->h2 / kDmaBN) >= 192) return kPlanDmaLarge;  // >= ~1 tile of 256 x 256 per CU
@@ -430,6 +448,7 @@ static int f16_plan(const AmpDisc* h, int64_t rows) {
 }
 static bool f16_use_dma(const AmpDisc* h, int64_t rows) { return f16_plan(h, rows) != kPlanRegister; }
 static int64_t f16_chunk_rows(const AmpDisc* h, int64_t rows) {
+  if (fused_ok(h, rows)) return rows;  // no hidden layer in memory: nothing to keep cache-resident, one launch
   return f16_plan(h, kChunkRows) == kPlanDmaLarge && rows > kChunkRows + kChunkRows / 2 ? kChunkRows : rows;
 }
 static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* amax, int64_t rows, _Float16* H1p, float* partial,
@@ -440,7 +459,20 @@ static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* a
   const int64_t chunk = f16_chunk_rows(h, rows);
   const int n_blocks = h->h2 / 32;  // canonical partial logits: one per (row, 32-column block)
   int rc = AMP_OK;
-  for (int64_t r0 = 0; r0 < rows && rc == AMP_OK; r0 += chunk) {
+  const bool fused = fused_ok(h, rows);
+  if (fused) {
+    FusedArgs f{};
+    f.X = Xp; f.ldx = h->k1h; f.M = rows;
+    f.W1b = h->w1b; f.W2b = h->w2b; f.b1 = h->b1; f.b2 = h->b2; f.w3 = h->w3;
+    f.range = h->range; f.amax = amax; f.h1 = h->h1; f.partial = partial;
+    const unsigned grid = (unsigned)((rows + kFusedRows - 1) / kFusedRows);
+    { amp::TraceScope trace__("disc_mlp_fused_kernel", st);
+      disc_mlp_fused_kernel<6><<<grid, kFusedThreads, FusedLds<6>::kBytes, st>>>(f);
+    }
+    rc = launch_status("disc_mlp_fused_kernel");
+    if (rc != AMP_OK) return rc;
+  }
+  for (int64_t r0 = 0; !fused && r0 < rows && rc == AMP_OK; r0 += chunk) {
     const int64_t m = rows - r0 < chunk ? rows - r0 : chunk;
     const int plan = f16_plan(h, chunk);  // by the chunk size (a short last chunk keeps the hidden layer's layout)
     const bool dma = plan != kPlanRegister;
