@@ -61,7 +61,8 @@ constexpr int kFusedThreads = 512, kFusedRows = 128, kFusedN2 = 512;
 template <int KX>
 struct FusedLds {
   static constexpr int kW1Slot = KX * 4096, kW2Half = 256 * 128;
-  static constexpr int kW1 = 0, kW2 = kW1Slot, kH = kW2 + 3 * kW2Half, kBias = kH + kFusedRows * 128, kBytes = kBias + 4096;
+  // (the small regions first: their addresses are 16-bit immediate offsets off the lane's two chunk registers)
+  static constexpr int kW1 = 0, kH = kW1Slot, kBias = kH + kFusedRows * 128, kW2 = kBias + 4096, kBytes = kW2 + 3 * kW2Half;
 };
 
 template <int KX>
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(kFusedThreads, 2) void disc_mlp_fused_kernel(FusedA
   // rho = 64 wn' + r holds column 128 wn' + 64 hf + r; 32 pieces, wave w issues 4 w .. 4 w + 3.  Lane l of a piece: row
   // 8 j + (l >> 3), stored chunk l & 7 = source chunk (l & 7) ^ ((row >> 1) & 7).
   constexpr int NP1 = (4 * KX + 7) / 8, NP2 = 4;
-  uint32_t off1[NP1], off2[NP2];
+  uint32_t off1[NP1], off2[2];  // off2: pieces t and t + 2 differ by 16 rows (same swizzle): a wave-uniform + 16 pitch2 on the base
   int dst1[NP1];
   const uint32_t pitch1 = KX * 128u, pitch2 = (uint32_t)nq * 128u;  // bytes per weight row (block layout)
 #pragma unroll
@@ -108,8 +109,8 @@ __global__ __launch_bounds__(kFusedThreads, 2) void disc_mlp_fused_kernel(FusedA
     dst1[t] = kbx * 4096 + j * 1024;
   }
 #pragma unroll
-  for (int t = 0; t < NP2; ++t) {
-    const int rho = 8 * (wave * NP2 + t) + (lane >> 3);
+  for (int t = 0; t < 2; ++t) {
+    const int rho = 8 * (wave * NP2 + t) + (lane >> 3);  // rows 32 w .. 32 w + 31 of the half-slot: inside one 64-row column group
     const int col = 128 * (rho >> 6) + (rho & 63);  // + 64 hf
     const int c = (lane & 7) ^ ((rho >> 1) & 7);
     off2[t] = (uint32_t)col * pitch2 + 16u * (uint32_t)c;
@@ -126,7 +127,8 @@ __global__ __launch_bounds__(kFusedThreads, 2) void disc_mlp_fused_kernel(FusedA
     const unsigned char* src = w2g + (int64_t)half * (64 * (int64_t)pitch2) + (int64_t)q * 128;
     unsigned char* dst = lds + L::kW2 + hs * L::kW2Half + wave * (NP2 * 1024);
 #pragma unroll
-    for (int t = 0; t < NP2; ++t) __builtin_amdgcn_global_load_lds((gptr_t)(src + off2[t]), (lptr_t)(dst + t * 1024), 16, 0, 0);
+    for (int t = 0; t < NP2; ++t)
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + (t >> 1) * (16 * (int64_t)pitch2) + off2[t & 1]), (lptr_t)(dst + t * 1024), 16, 0, 0);
   };
   static_assert((4 * KX) % 8 == 0 && NP1 == 3 && NP2 == 4, "the counted vmcnt waits are written for 3 + 4 pieces per wave");
 
@@ -137,15 +139,11 @@ __global__ __launch_bounds__(kFusedThreads, 2) void disc_mlp_fused_kernel(FusedA
   float* const b1s = reinterpret_cast<float*>(lds + L::kBias);
   for (int e = tid; e < g.h1; e += kFusedThreads) b1s[e] = g.b1[e] * s_h;
 
-  // prologue: the steady-state issue order is W1(q + 1), W2b(q + 1), W2a(q + 2) per k-block, preceded by W2a(0)
+  // prologue: W2a(0), W1(0) -- then the steady issue order W2b(q), W2a(q + 1), W1(q + 1) of the interval heads
   fill_w2(0, 0, 0);
   fill_w1(0);
-  fill_w2(0, 1, 1);
-  if (nq > 1) fill_w2(1, 0, 2);
-  // W1(0) has landed: everything older than the youngest 2 NP2 pieces (nq == 1: one half is missing, drain)
-  if (nq > 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();  // W1(0) and the bias are visible to every wave
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // W1(0), W2a(0) and the bias are visible to every wave
 
   fx4 c16[4][8];
 #pragma unroll
@@ -157,75 +155,120 @@ __global__ __launch_bounds__(kFusedThreads, 2) void disc_mlp_fused_kernel(FusedA
   unsigned char* const hrow = lds + L::kH + (16 * wave) * 128 + frag_row;           // the lane's row of the hidden block (writer)
   const unsigned char* const hfrag = lds + L::kH + (64 * wm) * 128 + frag_row;      // ... and of the wave's layer-2 rows (reader)
   const int w2frag = (64 * wn) * 128 + frag_row;
+  h8 hf0[4], hf1[4];  // hidden fragments of the wave's four 16-row blocks (read at the head of B1, used by B1 and B2)
 
-  int hsA = 0, hsB = 1;  // half-slots of W2a(q) / W2b(q): (2 q) % 3, (2 q + 1) % 3
-  for (int q = 0; q < nq; ++q) {
-    const bool steady = q + 2 < nq;  // the fills of k-block q + 2 exist: the counted waits hold; the last two k-blocks drain
-    // ---- A(q): layer 1 for units 32 q .. 32 q + 31 of the wave's 16 rows -> hidden block ---------------------------------------
-    {
-      const unsigned char* s1 = lds + L::kW1 + frag_row;
-      const fv4 bia0 = *reinterpret_cast<const fv4*>(b1s + 32 * q + 8 * kq), bia1 = *reinterpret_cast<const fv4*>(b1s + 32 * q + 8 * kq + 4);
-      fx4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = {0.0f, 0.0f, 0.0f, 0.0f};
+  // A(q): layer 1 for units 32 q .. 32 q + 31 of the wave's 16 rows -> the wave's rows of the hidden block
+  auto phase_a = [&](const int q) {
+    const unsigned char* s1 = lds + L::kW1 + frag_row;
+    const fv4 bia0 = *reinterpret_cast<const fv4*>(b1s + 32 * q + 8 * kq), bia1 = *reinterpret_cast<const fv4*>(b1s + 32 * q + 8 * kq + 4);
+    fx4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-      for (int kb = 0; kb < KX; ++kb) {
-        const h8 w00 = *reinterpret_cast<const h8*>(s1 + kb * 4096 + ch0), w01 = *reinterpret_cast<const h8*>(s1 + kb * 4096 + ch1);
-        const h8 w10 = *reinterpret_cast<const h8*>(s1 + kb * 4096 + 2048 + ch0), w11 = *reinterpret_cast<const h8*>(s1 + kb * 4096 + 2048 + ch1);
-        a0 = mfma16(w00, x[kb][1], a0);
-        a1 = mfma16(w10, x[kb][1], a1);
-        a0 = mfma16(w01, x[kb][0], a0);
-        a1 = mfma16(w11, x[kb][0], a1);
-        a0 = mfma16(w00, x[kb][0], a0);
-        a1 = mfma16(w10, x[kb][0], a1);
-      }
-      h4 p0a, p1a, p0b, p1b;
-      relu_split4(a0, ds, bia0, p0a, p1a);
-      relu_split4(a1, ds, bia1, p0b, p1b);
-      *reinterpret_cast<h8*>(hrow + ch0) = h8{p0a[0], p0a[1], p0a[2], p0a[3], p0b[0], p0b[1], p0b[2], p0b[3]};
-      *reinterpret_cast<h8*>(hrow + ch1) = h8{p1a[0], p1a[1], p1a[2], p1a[3], p1b[0], p1b[1], p1b[2], p1b[3]};
+    for (int kb = 0; kb < KX; ++kb) {
+      const h8 w00 = *reinterpret_cast<const h8*>(s1 + kb * 4096 + ch0), w01 = *reinterpret_cast<const h8*>(s1 + kb * 4096 + ch1);
+      const h8 w10 = *reinterpret_cast<const h8*>(s1 + kb * 4096 + 2048 + ch0), w11 = *reinterpret_cast<const h8*>(s1 + kb * 4096 + 2048 + ch1);
+      a0 = mfma16(w00, x[kb][1], a0);
+      a1 = mfma16(w10, x[kb][1], a1);
+      a0 = mfma16(w01, x[kb][0], a0);
+      a1 = mfma16(w11, x[kb][0], a1);
+      a0 = mfma16(w00, x[kb][0], a0);
+      a1 = mfma16(w10, x[kb][0], a1);
     }
-    // end of A(q): this wave's pieces of W2a(q) have landed; its reads of the W1 slot and its hidden rows are retired / written
-    if (steady) asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (q + 1 < nq) fill_w1(q + 1);
-    // ---- B1(q) / B2(q): layer 2, k-block q, the first / second 64 columns of the wave's 128 -------------------------------------
-    h8 hf0[4], hf1[4];
+    h4 p0a, p1a, p0b, p1b;
+    relu_split4(a0, ds, bia0, p0a, p1a);
+    relu_split4(a1, ds, bia1, p0b, p1b);
+    *reinterpret_cast<h8*>(hrow + ch0) = h8{p0a[0], p0a[1], p0a[2], p0a[3], p0b[0], p0b[1], p0b[2], p0b[3]};
+    *reinterpret_cast<h8*>(hrow + ch1) = h8{p1a[0], p1a[1], p1a[2], p1a[3], p1b[0], p1b[1], p1b[2], p1b[3]};
+  };
+  auto read_h = [&]() {
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       hf0[a] = *reinterpret_cast<const h8*>(hfrag + a * 2048 + ch0);
       hf1[a] = *reinterpret_cast<const h8*>(hfrag + a * 2048 + ch1);
     }
+  };
+  // B1 / B2: layer 2, one k-block, the first / second 64 columns of the wave's 128 from half-slot hs
+  auto phase_b = [&](auto half_c, const int hs) {
+    constexpr int half = decltype(half_c)::value;
+    const unsigned char* s2 = lds + L::kW2 + hs * L::kW2Half + w2frag;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const unsigned char* s2 = lds + L::kW2 + (half ? hsB : hsA) * L::kW2Half + w2frag;
+    for (int cb = 0; cb < 4; ++cb) {
+      const h8 w0 = *reinterpret_cast<const h8*>(s2 + cb * 2048 + ch0), w1 = *reinterpret_cast<const h8*>(s2 + cb * 2048 + ch1);
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb) {
-        const h8 w0 = *reinterpret_cast<const h8*>(s2 + cb * 2048 + ch0), w1 = *reinterpret_cast<const h8*>(s2 + cb * 2048 + ch1);
+      for (int a = 0; a < 4; ++a) c16[a][4 * half + cb] = mfma16(w0, hf1[a], c16[a][4 * half + cb]);
 #pragma unroll
-        for (int a = 0; a < 4; ++a) c16[a][4 * half + cb] = mfma16(w0, hf1[a], c16[a][4 * half + cb]);
+      for (int a = 0; a < 4; ++a) c16[a][4 * half + cb] = mfma16(w1, hf0[a], c16[a][4 * half + cb]);
 #pragma unroll
-        for (int a = 0; a < 4; ++a) c16[a][4 * half + cb] = mfma16(w1, hf0[a], c16[a][4 * half + cb]);
-#pragma unroll
-        for (int a = 0; a < 4; ++a) c16[a][4 * half + cb] = mfma16(w0, hf0[a], c16[a][4 * half + cb]);
-      }
-      if (half == 0) {
-        // end of B1(q): the wave's pieces of W2b(q) have landed; half-slot hsA is free -> W2b(q + 1)
-        if (steady) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (q + 1 < nq) fill_w2(q + 1, 1, hsA);
-      } else {
-        // end of B2(q): the wave's pieces of W1(q + 1) have landed; half-slot hsB is free -> W2a(q + 2)
-        if (steady) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (steady) fill_w2(q + 2, 0, hsB);
-      }
+      for (int a = 0; a < 4; ++a) c16[a][4 * half + cb] = mfma16(w0, hf0[a], c16[a][4 * half + cb]);
     }
-    // half-slots of the next k-block: (2 q + 2) % 3 = the slot after hsB, (2 q + 3) % 3 = hsA
-    const int nA = hsB == 2 ? 0 : hsB + 1;
-    hsB = hsA;
-    hsA = nA;
+  };
+  using half0_t = std::integral_constant<int, 0>;
+  using half1_t = std::integral_constant<int, 1>;
+  auto next3 = [](const int v) { return v == 2 ? 0 : v + 1; };
+
+  // Two wave groups, one wave of each per SIMD, run the phase sequence A B1 B2 one interval apart (group 1 = waves 4-7 = the
+  // tile's rows 64-127 in BOTH layers: a group's hidden rows are written and read by the group itself), so that a SIMD always
+  // pairs two DIFFERENT phases -- layer 1's dependent epilogue (VALU, LDS write) runs under the partner's layer-2 MFMAs instead
+  // of under its own copy of the same epilogue.  Interval I0(q): G0 A(q) | G1 B2(q - 1);  I1(q): G0 B1(q) | G1 A(q);
+  // I2(q): G0 B2(q) | G1 B1(q); one workgroup barrier per interval.  A stage is read in two consecutive intervals (G0, then G1)
+  // and refilled at the head of the interval after them, by every wave:
+  //   head of I0(q): W2b(q)     -> half-slot (2 q + 1) % 3   (last readers: W2a(q - 1) in I1 / I2 of q - 1)
+  //   head of I1(q): W2a(q + 1) -> half-slot (2 q + 2) % 3   (W2b(q - 1): I2(q - 1), I0(q))
+  //   head of I2(q): W1(q + 1)  -> the W1 slot               (W1(q): I0(q), I1(q))
+  // and awaited in front of the barrier that ends the interval BEFORE the first use: end of I0(q): W2a(q) (7 younger pieces stay
+  // in flight), end of I1(q): W2b(q) (4), end of I2(q): W1(q + 1) (0).
+  // The loop body is the same for every k-block (no first / last special cases: a peeled or unswitched copy of 264 MFMAs costs
+  // registers and instruction cache): group 1's B2(-1) of the first interval runs on ZERO hidden fragments over the landed W2a(0)
+  // (adds exact zeros), and the last k-block's look-ahead fills re-fetch k-block nq - 1 into slots nobody reads again.
+#pragma unroll
+  for (int a = 0; a < 4; ++a) hf0[a] = hf1[a] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+  // (Two loops, one per group -- the group is wave-uniform, and in ONE loop with a branch per interval the compiler has to keep
+  //  hf0 / hf1 alive through the other group's phase A: 420 B of scratch.  Both loops execute the same barriers.)
+  auto end_interval = [&](auto younger_c) {
+    constexpr int Y = decltype(younger_c)::value;
+    if constexpr (Y == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+    else if constexpr (Y == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  using y7 = std::integral_constant<int, 7>;
+  using y4 = std::integral_constant<int, 4>;
+  using y0 = std::integral_constant<int, 0>;
+  int m3 = 0;  // (2 q) % 3
+  if (wm == 0) {
+#pragma clang loop unroll(disable)
+    for (int q = 0; q < nq; ++q) {
+      const int qn = q + 1 < nq ? q + 1 : q;              // the look-ahead k-block (clamped at the end)
+      const int sA = m3, sB = next3(m3), sC = next3(sB);  // half-slots of W2a(q), W2b(q), and of W2b(q - 1) = W2a(q + 1)
+      fill_w2(q, 1, sB);   // I0(q)
+      phase_a(q);
+      end_interval(y7{});
+      fill_w2(qn, 0, sC);  // I1(q)
+      read_h();
+      phase_b(half0_t{}, sA);
+      end_interval(y4{});
+      fill_w1(qn);         // I2(q)
+      phase_b(half1_t{}, sB);
+      end_interval(y0{});
+      m3 = sC;
+    }
+  } else {
+#pragma clang loop unroll(disable)
+    for (int q = 0; q < nq; ++q) {
+      const int qn = q + 1 < nq ? q + 1 : q;
+      const int sA = m3, sB = next3(m3), sC = next3(sB);
+      fill_w2(q, 1, sB);   // I0(q)
+      phase_b(half1_t{}, q > 0 ? sC : sA);
+      end_interval(y7{});
+      fill_w2(qn, 0, sC);  // I1(q)
+      phase_a(q);
+      end_interval(y4{});
+      fill_w1(qn);         // I2(q)
+      read_h();
+      phase_b(half0_t{}, sA);
+      end_interval(y0{});
+      m3 = sC;
+    }
+    phase_b(half1_t{}, next3(next3(m3)));  // B2(nq - 1): half-slot (2 nq - 1) % 3
   }
 
   // ---- canonical partial logits: one per (row, 32-column block) = l2_partial16 of its two 16-column blocks.  The wave's 128
