@@ -75,6 +75,8 @@ def parse_args():
     ap.add_argument("--cpu-envs", type=int, default=0, help="envs of the CPU sample (0 = same as the shard)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 8192- / 4096-env secondary measurements")
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in env (G1AmpEnv.step through the hooks) measurements")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the bounded entries for BASELINE.json configs[2] / configs[3] (g1_dance K = 10, humanoid 3-clip)")
     ap.add_argument("--disc-precision", default="f16x3", choices=["f16x3", "f32"],
                     help="GEMM engine of the discriminator (both fp32-class accuracy): fp16-split (default) or fp32 MFMA")
     ap.add_argument("--no-fp32-engine", action="store_true", help="skip the comparison run on the fp32-MFMA GEMM engine")
@@ -253,6 +255,29 @@ def cpu_baseline(spec, n_envs, seed, target_seconds=12.0, probe=True, threads=No
             "ms_per_step": med * 1e3}
 
 
+TRIVIAL_KERNEL_US = 1.5   # what rocprofv3 reports for the one-workgroup command tick used as the bracket probe (profiles/r04_*)
+
+
+def event_pair_overhead_us(device, reps=200):
+    """What a HIP-event bracket of the engine's tracer adds to a launch: the median bracketed time of a ONE-workgroup kernel (the
+    command-timer tick of 64 envs: ~1.5 us under rocprofv3) minus that duration.  The tracer's per-kernel figures of bench.py are
+    reported raw AND with this subtracted, so that they can be read next to a rocprofv3 kernel trace."""
+    from humanoid_amp_amd import _native as nat
+    from humanoid_amp_amd.engine import command_step
+
+    cmd, left = torch.zeros(64, 2, device=device), torch.full((64,), 1e9, device=device)
+    for _ in range(20):
+        command_step(cmd, left, mode=nat.AMP_COMMAND_TICK, step_dt=0.01, vel_range=(0.0, 1.0), time_range=(4.0, 7.0), seed=0, step=0)
+    torch.cuda.synchronize()
+    with nat.KernelTrace(capacity=reps + 8, kernel_filter="command_kernel") as tr:
+        for _ in range(reps):
+            command_step(cmd, left, mode=nat.AMP_COMMAND_TICK, step_dt=0.01, vel_range=(0.0, 1.0), time_range=(4.0, 7.0), seed=0, step=0)
+        torch.cuda.synchronize()
+    ms = sorted(m for _, m in tr.records())
+    floor = ms[len(ms) // 2] * 1e3 if ms else 0.0
+    return max(0.0, floor - TRIVIAL_KERNEL_US), floor
+
+
 def dropin_env_step(spec, envs, device, steps=60, warmup=10):
     """The path skrl would drive: ``env.step(actions)`` of the drop-in env class (G1AmpEnv / HumanoidAmpEnv over the synthetic
     articulation, ``device_reset=True``: command timers -> DONES|REWARD launch -> one-launch device reset -> state-provider
@@ -301,22 +326,34 @@ def dropin_env_step(spec, envs, device, steps=60, warmup=10):
     for i in range(warmup):
         env.step(acts[i & 3])
     eager = min(timed(steps), timed(steps))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     with nat.KernelTrace(capacity=16 * 16) as tr:
         for i in range(16):
             env.step(acts[i & 3])
-    per = {k: round(t / 16 * 1e3, 2) for k, (c, t) in tr.summary().items()}
+        torch.cuda.synchronize()
+    traced = (time.perf_counter() - t0) / 16
+    summ = tr.summary()
+    per = {k: round(t / 16 * 1e3, 2) for k, (c, t) in summ.items()}
+    brackets = sum(c for c, t in summ.values()) / 16.0   # event pairs per step
     env.capture_step()
     for i in range(warmup):
         env.step(acts[i & 3])
     graph = min(timed(steps), timed(steps))
     provider = per.get("scatter_rows_kernel", 0.0)
+    faster = "eager" if eager <= graph else "hipgraph"
     out = {"envs": envs, "env_class": cls.__name__, "K": spec.K,
            "eager": {"us_per_step": eager * 1e6, "env_steps_per_s": envs / eager},
            "hipgraph": {"us_per_step": graph * 1e6, "env_steps_per_s": envs / graph},
+           "recommended": faster,
+           "recommended_note": "a graph replay pays ~8.5 us between replays (profiles/r02_small_shard_gaps.md) + the copy of the actions "
+                               "into its static buffer; it wins where the eager step is HOST-bound (small shards) and loses where the "
+                               "eager launches already queue back to back (GPU-bound: 65 536 envs)",
            "engine_kernel_us_per_step": per, "engine_env_side_us": round(sum(per.values()) - provider, 2),
+           "traced_us_per_step": traced * 1e6, "event_pairs_per_step": brackets,
            "state_provider_reset_write_us": provider, "engine_launches_per_step": len(per) + (1 if "env_step_kernel" in per else 0),
            "note": "device_reset=True, no host sync inside step(); synthetic articulation with its toy physics off; kernel us are "
-                   "HIP-event brackets of an eager traced pass (each carries ~3 us of event overhead)"}
+                   "HIP-event brackets of an eager traced pass (each carries `event_pair_overhead_us` of the top level)"}
     del env
     torch.cuda.empty_cache()
     return out
@@ -468,6 +505,7 @@ def main():
                      "core_clock_mhz_random_operands_16x16x32_two_waves": f16c,
                      "note": "constant / random_operands: bare v_mfma_f32_32x32x16_f16 stream, one wave per SIMD; the dominant kernel "
                              "(layer 2) issues v_mfma_f32_16x16x32_f16 from two waves per SIMD: its ceiling is the 16x16x32 figure"}
+    pair_us, pair_floor = event_pair_overhead_us(device) if rank == 0 else (0.0, 0.0)
     if rank == 0:
         # HBM traffic of the dominant kernel: PMC FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE per launch, collected
         # in separate rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh) and committed: STATIC
@@ -534,6 +572,17 @@ def main():
                              "bytes_per_env_step": algorithmic_bytes_per_env_step(spec), "us": hbm_us,
                              "traffic": hbm_traffic,
                              "traffic_source": "profiles/pmc_traffic.json (static)" if hbm_traffic else None},
+            # the env step + expert sample launch ALONE (the tail launch is latency-bound, not byte-bound); the bracketed time carries
+            # one event pair, whose cost (traced - untraced wall per bracket) is reported and subtracted in `us_corrected`
+            "roofline_hbm_env_launch": (lambda us, pair: {
+                "bound": "hbm", "kernel": "env_step_reference_kernel", "us": us, "event_pair_overhead_us": round(pair, 2),
+                "us_corrected": round(us - pair, 2), "bytes": alg_bytes,
+                "achieved": alg_bytes / ((us - pair) * 1e-6) / 1e9 if us > pair else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (alg_bytes / ((us - pair) * 1e-6) / 1e9 / HBM_PEAK_GBS) if us > pair else None,
+                "traffic": hbm_traffic})(per_kernel.get("env_step_reference_kernel", 0.0), pair_us),
+            "event_pair_overhead_us": round(pair_us, 2), "event_pair_probe_us": round(pair_floor, 2),
+            "event_pair_note": "median HIP-event bracket of a one-workgroup kernel (~1.5 us under rocprofv3) minus 1.5 us: what every "
+                               "bracketed per-kernel figure of this line carries on top of the kernel",
             "kernel_us_per_step": per_kernel,
             "kernel_us_per_step_note": "a separate, fully traced eager pass after the timed region: every launch carries a HIP-event "
                                        "pair (~3-4 us of queue time each), so the sum exceeds ms_per_step of the untraced / sampled region",
@@ -577,13 +626,36 @@ def main():
         entries = []
         for n_env in dict.fromkeys((envs, 8192, 4096)):
             entries.append(dropin_env_step(spec, n_env, device))
+        pair = pair_us  # every bracketed figure of the comparison carries one event pair
+        for e in entries:
+            n_env = e["envs"]
             hp = (per_kernel if n_env == envs else (out.get(f"envs_{n_env}") or {}).get("kernel_us_per_step_eager")) or {}
             hp_env = sum(v for k, v in hp.items() if "env_step" in k)
             if hp_env:
                 # HotPath's env launch also carries the benchmark's N expert rows; the hooks' launches do not
-                entries[-1]["hot_path_env_launch_us"] = hp_env
-                entries[-1]["env_side_vs_hot_path_env_launch"] = entries[-1]["engine_env_side_us"] / hp_env
+                n_side = e["engine_launches_per_step"] - (1 if e["state_provider_reset_write_us"] else 0)
+                e["hot_path_env_launch_us"] = hp_env
+                e["env_side_vs_hot_path_env_launch_raw"] = e["engine_env_side_us"] / hp_env
+                side_c, hp_c = e["engine_env_side_us"] - n_side * pair, hp_env - pair
+                e["engine_env_side_us_corrected"], e["hot_path_env_launch_us_corrected"] = round(side_c, 2), round(hp_c, 2)
+                e["env_side_vs_hot_path_env_launch"] = side_c / hp_c if hp_c > 0 else None
+                e["event_pair_overhead_us_applied"] = pair
         out["dropin_env_step"] = entries
+
+    # ---- BASELINE.json configs[2] / configs[3], bounded (the default line times configs[4] / [1] above) ---------------
+    if world == 1 and not args.no_configs:
+        cfgs = {}
+        for key, wl, n in (("configs[2]: G1-AMP-Dance (K = 10), 8192 envs, 1 GPU", "g1_dance", 8192),
+                           ("configs[3] on ONE GPU: humanoid 3-clip, 32768 envs", "humanoid3", 32768),
+                           ("configs[3] per-GPU shard: humanoid 3-clip, 8192 envs", "humanoid3", 8192)):
+            cfgs[key] = measure_shard(WORKLOADS[wl], n, device, rank, world, 50, args.warmup, args.graph, args.disc_precision,
+                                      args.state_sets)
+            cfgs[key]["workload"] = WORKLOADS[wl].description
+        if not args.no_dropin:
+            # the reference's self-consistent G1 family (Custom / Deploy cfg: K = 10, g1_amp_env_cfg.py:81-141,160-206) through the hooks
+            cfgs["dropin_env_step K = 10 (G1AmpEnvCfg_CUSTOM on G1_dance)"] = [dropin_env_step(WORKLOADS["g1_dance"], n, device)
+                                                                               for n in (8192, 65536)]
+        out["baseline_configs"] = cfgs
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

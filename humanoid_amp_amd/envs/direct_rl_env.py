@@ -129,11 +129,18 @@ class DirectRLEnv:
 
     def _replay_step(self, action: torch.Tensor):
         g, out = self._graph
-        self._graph_actions.copy_(action)
+        if action.data_ptr() != self._graph_actions.data_ptr():  # a policy may write straight into `graph_actions`: no copy then
+            self._graph_actions.copy_(action)
         g.replay()
         self.common_step_counter += 1
         self._after_replay()
         return out[0], out[1], out[2], out[3], self.extras
+
+    @property
+    def graph_actions(self) -> torch.Tensor | None:
+        """The captured step's static action buffer (``None`` before ``capture_step``): ``step(env.graph_actions)`` after
+        writing the actions into it replays without the per-step copy."""
+        return getattr(self, "_graph_actions", None) if self._graph is not None else None
 
     def _after_replay(self):
         """Refresh per-step Python objects (``extras``) after a graph replay; tasks override."""
