@@ -405,7 +405,11 @@ __device__ __forceinline__ void env_step_dma_pass(const EnvPlan& p, const AmpSim
   // (staging the 4-B granular pieces -- history and joint rows -- through registers instead, one column per lane, was
   //  measured equal at K = 2 and 13 % slower at K = 10)
   float* const buf = bf.amp_obs_buffer + tile_base * KD;
+#ifndef AMP_ENV_XP_NO_ROW_DMA   // (diagnostic builds only: upper bound of what fewer row pieces could buy; results are wrong)
   if (do_obs || g1) {
+#else
+  if (false) {
+#endif
 #pragma unroll 1
   for (int r = wave; r < T; r += 4) {
     float* row = s_img + r * RP;
