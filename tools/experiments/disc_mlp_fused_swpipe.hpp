@@ -1,0 +1,317 @@
+// Layers 1 and 2 of the fp16-split discriminator forward as ONE kernel: the hidden layer never leaves the CU.
+//
+// Why.  Run as two GEMM launches, a 32 768-row chunk writes its hidden layer (4 B per element: 134 MB) and reads it straight
+// back: 542 of the step's 884 MB of fabric traffic at 65 536 envs (profiles/pmc_traffic.json), and layer 1 -- k-loops + 134 MB
+// of stores that do not overlap on this memory system (profiles/r03_l1_timeline.txt) -- is a third of the step at 0.30 of the
+// fp16 peak.  Here a workgroup owns 128 rows x ALL 512 output columns; per 32 hidden units (one k-block of layer 2) every wave
+//   A   computes the units' pre-activations for ITS 16 rows (layer 1: 2 x KX x 3 MFMAs, activation fragments resident in
+//       registers for the whole tile, weight fragments from an LDS stage),
+//       applies bias + ReLU + the fp16 plane split in registers -- the result IS the B operand of layer 2's MFMAs --
+//   B   and accumulates it into its 16 x 512 slice of layer 2 (32 column blocks x 3 MFMAs, weight fragments from LDS).
+// No hidden-layer stores, no hidden-layer fills, one launch instead of two (and the step's two 32 768-row chunks become one
+// launch: chunking existed only to keep the hidden layer in the Infinity Cache).  Operand intake per workgroup and k-block:
+// 64 KB of W2 + 24 KB of W1, all L2-resident (2.8 MB of planes) -- 21 B per matrix-pipe cycle of the CU, what the 256 x 256
+// tiles take.
+//
+// Bit-identical to the two-kernel plans (tests/test_gpu_shard_equivalence.py, test_gemm_engines_vs_fp64 over every plan):
+//   * layer 1: per accumulator the products (w0, x1), (w1, x0), (w0, x0) per k-block, k-blocks ascending -- the order of every
+//     f16 kernel; the MFMA's own reduction depends on the k-slot alone, not on which row / lane of the tile an element sits in;
+//   * the epilogue is relu_split4's arithmetic (fma, max, rn16, rn16 of the exact residual);
+//   * the MFMA of layer 1 takes the WEIGHT rows as its A operand in the order unit(m, u) = 8 (m >> 2) + 4 u + (m & 3) (u = 0 / 1:
+//     the two MFMAs of a 32-unit block; a per-lane row offset in the fill, nothing else), so that lane (i, kq) ends up with
+//     units 8 kq .. 8 kq + 7 of activation row i in NATURAL order: exactly the B fragment of v_mfma_f32_16x16x32_f16 for layer 2;
+//   * layer 2: (w0, h1), (w1, h0), (w0, h0) per k-block and accumulator, then the canonical partial logits (l2_partial16).
+//
+// Geometry: 512 threads = 8 waves.  Layer 1: wave w owns rows 16 w .. 16 w + 15 of the tile (48 registers of activation
+// fragments: KX = 6 k-blocks x 2 planes) and hands its 16 x 32 slice of the hidden block to the workgroup through a 16-KB LDS
+// tile in block layout (two ds_write_b128 per lane).  Layer 2: waves as 2 (rows) x 4 (columns), wave (wm, wn) owns rows
+// 64 wm .. + 63 and columns 128 wn .. + 127: c16[4][8] = 128 accumulator registers, every weight fragment feeds 4 row blocks and
+// every hidden fragment 8 column blocks (the first version gave every wave 16 rows x all 512 columns with the hidden block in
+// registers: no LDS hand-over, but 88 KB of fragment reads per wave and k-block -- 170 B/clk of the LDS's 256 while the pipes
+// run -- and the pipes were 55 % busy: 231 us per 65 536 rows; this layout reads 48 KB).  One workgroup per CU (140 KB of LDS).
+// LDS: W1 slot KX x 4 KB | W2 half-slots (256 columns x 128 B = 32 KB) x 3 | hidden block 128 rows x 128 B | bias of layer 1 4 KB.
+// A W2 half-slot holds, for every column group wn, 64 of its 128 columns (half 0: columns 128 wn .. + 63, half 1: the rest), so
+// that every wave computes in every phase.
+// A k-block q runs as three phases separated by one barrier each: A(q) (layer 1 -> hidden block), B1(q) on half-slot (2 q) % 3,
+// B2(q) on half-slot (2 q + 1) % 3.  Fill schedule (every wave issues its share: 3 pieces of W1, 4 of a W2 half):
+//   behind the barrier that ends A(q)  : W1(q + 1)  into the W1 slot (A(q) was its last reader)
+//   behind the barrier that ends B1(q) : W2b(q + 1) into the half-slot B1(q) just left
+//   behind the barrier that ends B2(q) : W2a(q + 2) into the half-slot B2(q) just left
+// and in front of the barrier that ends A(q) / B1(q) / B2(q) a wave waits (counted vmcnt: 11 / 7 / 4 younger pieces stay in
+// flight) for ITS pieces of W2a(q) / W2b(q) / W1(q + 1) -- the data of the NEXT phase: the LDS-DMA visibility rule
+// (MI355X_MICROARCH.md: the issuing wave's vmcnt + a barrier the reader has passed); every refill is issued behind a barrier
+// that follows the lgkmcnt(0) of the slot's last reads, and the hidden block is rewritten by A(q + 1) behind the barrier that
+// ends B2(q) (its fragments are read once, at the head of B1(q), and stay in registers).
+#pragma once
+#include "disc_gemm_f16_dma.hpp"
+
+namespace amp {
+
+struct FusedArgs {
+  const _Float16* X; int64_t ldx; int64_t M;   // scaled input, block layout: row pitch 2 * ldx halves (ldx = 32 KX)
+  const _Float16* W1b;                         // [h1][KX][2][32] planes of s_w1 W1
+  const _Float16* W2b;                         // [512][h1 / 32][2][32] planes of s_w2 W2
+  const float* b1; const float* b2; const float* w3;
+  const DiscRange* range; const float* amax;
+  int32_t h1;                                  // hidden units (multiple of 32, <= 1024)
+  float* partial;                              // [M, 16] canonical partial logits
+};
+
+constexpr int kFusedThreads = 512, kFusedRows = 128, kFusedN2 = 512;
+template <int KX>
+struct FusedLds {
+  static constexpr int kW1Slot = KX * 4096, kW2Half = 256 * 128;
+  // (the small regions first: their addresses are 16-bit immediate offsets off the lane's two chunk registers)
+  static constexpr int kW1 = 0, kH = kW1Slot, kBias = kH + kFusedRows * 128, kW2 = kBias + 4096, kBytes = kW2 + 3 * kW2Half;
+};
+
+template <int KX>
+__global__ __launch_bounds__(kFusedThreads, 2) void disc_mlp_fused_kernel(FusedArgs g) {
+  using L = FusedLds<KX>;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int i16 = lane & 15, kq = lane >> 4, swz16 = (i16 >> 1) & 7;
+  const int nq = g.h1 >> 5;  // k-blocks of layer 2 = 32-unit blocks of layer 1
+  // the last row tile of a ragged M is moved up to end at M (its overlap with the tile above is computed twice from the same
+  // operands: the same bits land twice); M >= 128 is the launcher's precondition
+  int64_t m0 = (int64_t)blockIdx.x * kFusedRows;
+  if (m0 + kFusedRows > g.M) m0 = g.M - kFusedRows;
+
+  // ---- activation fragments of the wave's 16 layer-1 rows: B operand, lane (i, kq) = row i, k = 32 kbx + 8 kq .. + 7 ----------
+  h8 x[KX][2];
+  {
+    const _Float16* xr = g.X + (m0 + 16 * wave + i16) * (2 * g.ldx) + 8 * kq;
+#pragma unroll
+    for (int kb = 0; kb < KX; ++kb) {
+      x[kb][0] = *reinterpret_cast<const h8*>(xr + kb * 64);
+      x[kb][1] = *reinterpret_cast<const h8*>(xr + kb * 64 + 32);
+    }
+  }
+  // ---- fill plan ------------------------------------------------------------------------------------------------------------
+  // W1(q): LDS sub-stage kbx = 32 rows x 128 B, LDS row rho = 16 u + i holds unit 32 q + 8 (i >> 2) + 4 u + (i & 3); 4 pieces of
+  // 8 rows per kbx, 4 KX pieces per k-block: wave w issues pieces 3 w .. 3 w + 2 (KX = 6).  W2 half hf (256 LDS rows): LDS row
+  // rho = 64 wn' + r holds column 128 wn' + 64 hf + r; 32 pieces, wave w issues 4 w .. 4 w + 3.  Lane l of a piece: row
+  // 8 j + (l >> 3), stored chunk l & 7 = source chunk (l & 7) ^ ((row >> 1) & 7).
+  constexpr int NP1 = (4 * KX + 7) / 8, NP2 = 4;
+  const uint32_t pitch1 = KX * 128u, pitch2 = (uint32_t)nq * 128u;  // bytes per weight row (block layout, multiples of 128)
+  // The lane's source offset of a piece = a wave-uniform part (scalar registers) + ONE per-lane register per operand:
+  //   W1 piece p = 4 kbx + j (8 LDS rows 8 j .. 8 j + 7 of sub-stage kbx):  rho = 8 j + (l >> 3), u = j >> 1,
+  //     unit = 16 (j & 1) + 4 u + 8 (l >> 5) + ((l >> 3) & 3),  chunk = (l & 7) ^ ((l >> 4) | 4 (j & 1))
+  //   W2 piece t of the wave (rows 32 w + 8 t ..):  col = 128 (w >> 1) + 32 (w & 1) + 8 t + (l >> 3),  chunk = (l & 7) ^ ((l >> 4) | 4 (t & 1))
+  // the "| 4" flips bit 6 of the byte offset (rows are multiples of 128 B): an XOR with 64 on the lane register.
+  const uint32_t lane_c16 = 16u * (uint32_t)((lane & 7) ^ (lane >> 4));
+  const uint32_t lane1 = (uint32_t)(8 * (lane >> 5) + ((lane >> 3) & 3)) * pitch1 + lane_c16;
+  const uint32_t lane2 = (uint32_t)(lane >> 3) * pitch2 + lane_c16;
+  const unsigned char* const w1g = reinterpret_cast<const unsigned char*>(g.W1b);
+  const unsigned char* const w2g = reinterpret_cast<const unsigned char*>(g.W2b);
+  auto fill_w1 = [&](const int q) {  // units 32 q .. 32 q + 31
+    const unsigned char* src = w1g + (int64_t)q * (32 * (int64_t)pitch1);
+    unsigned char* dst = lds + L::kW1;
+#pragma unroll
+    for (int t = 0; t < NP1; ++t) {
+      const int p = wave * NP1 + t, kbx = p >> 2, j = p & 3;   // wave-uniform
+      const uint32_t uni = (uint32_t)(16 * (j & 1) + 4 * (j >> 1)) * pitch1 + (uint32_t)kbx * 128u;
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + uni + (lane1 ^ ((j & 1) ? 64u : 0u))), (lptr_t)(dst + kbx * 4096 + j * 1024), 16, 0, 0);
+    }
+  };
+  auto fill_w2 = [&](const int q, const int half, const int hs) {  // k-block q of the half's columns -> half-slot hs
+    const unsigned char* src = w2g + (int64_t)half * (64 * (int64_t)pitch2) + (int64_t)q * 128 +
+                               (int64_t)(128 * (wave >> 1) + 32 * (wave & 1)) * pitch2;
+    unsigned char* dst = lds + L::kW2 + hs * L::kW2Half + wave * (NP2 * 1024);
+#pragma unroll
+    for (int t = 0; t < NP2; ++t)
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + (int64_t)(8 * t) * pitch2 + (lane2 ^ ((t & 1) ? 64u : 0u))), (lptr_t)(dst + t * 1024), 16, 0, 0);
+  };
+  static_assert((4 * KX) % 8 == 0 && NP1 == 3 && NP2 == 4, "the counted vmcnt waits are written for 3 + 4 pieces per wave");
+
+  const LayerScales sc1 = layer_scales(g.range, g.amax, 1);
+  const float s_h = sc1.s_out, ds = sc1.descale * s_h;
+  const float descale2 = layer_scales(g.range, g.amax, 2).descale;
+  // layer 1's bias, scaled, in LDS: lane (i, kq) needs the eight units 32 q + 8 kq .. + 7 per k-block
+  float* const b1s = reinterpret_cast<float*>(lds + L::kBias);
+  for (int e = tid; e < g.h1; e += kFusedThreads) b1s[e] = g.b1[e] * s_h;
+
+  // prologue: W2a(0), W1(0) -- then the steady issue order W2b(q), W2a(q + 1), W1(q + 1) of the interval heads
+  fill_w2(0, 0, 0);
+  fill_w1(0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // W1(0), W2a(0) and the bias are visible to every wave
+
+  fx4 c16[4][8];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) c16[a][b] = fx4{0.0f, 0.0f, 0.0f, 0.0f};
+  const int ch0 = (kq ^ swz16) * 16, ch1 = ((4 + kq) ^ swz16) * 16;  // plane 0 / 1 chunk of the lane inside a 128-B row
+  // Every fragment address = one of TWO lane registers (the lane's row inside a 16-row block + its plane-0 / plane-1 chunk) + a
+  // wave-uniform offset.  The uniform parts are re-derived inside each phase from an OPAQUE copy of the wave index: left to
+  // itself hipcc hoists eight precomputed address registers out of the k-loop, and the loop does not have them to spare.
+  unsigned char* const fr0 = lds + i16 * 128 + ch0;
+  unsigned char* const fr1 = lds + i16 * 128 + ch1;
+  auto opaque = [](int v) { asm volatile("" : "+s"(v)); return v; };
+  h8 hf0[4], hf1[4];  // hidden fragments of the wave's four 16-row blocks (read at the head of B1, used by B1 and B2)
+
+  // A(q): layer 1 for units 32 q .. 32 q + 31 of the wave's 16 rows -> the wave's rows of the hidden block
+  // Fragment reads are software-pipelined BY HAND in both phases: the next block's weight fragments are issued before the
+  // current block's MFMAs (pinned with sched_barrier; hipcc otherwise emits read -> lgkmcnt(0) -> MFMAs -> read ..., and the
+  // two waves of a SIMD, running that same shape, fall into step: both read, both wait, the pipe idles ~40 % of the phase).
+  auto phase_a = [&](const int q) {
+    const unsigned char* const s10 = fr0 + L::kW1;
+    const unsigned char* const s11 = fr1 + L::kW1;
+    fx4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    // units of three MFMAs (one accumulator, one k-block): the next unit's two fragments are in flight under the current unit
+    h8 nw0 = *reinterpret_cast<const h8*>(s10), nw1 = *reinterpret_cast<const h8*>(s11);
+#pragma unroll
+    for (int un = 0; un < 2 * KX; ++un) {
+      const int kb = un >> 1, u = un & 1;
+      const h8 w0 = nw0, w1 = nw1;
+      if (un + 1 < 2 * KX) {
+        const int nb = (un + 1) >> 1, nu = (un + 1) & 1;
+        nw0 = *reinterpret_cast<const h8*>(s10 + nb * 4096 + nu * 2048);
+        nw1 = *reinterpret_cast<const h8*>(s11 + nb * 4096 + nu * 2048);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      fx4& acc = u ? a1 : a0;
+      acc = mfma16(w0, x[kb][1], acc);
+      acc = mfma16(w1, x[kb][0], acc);
+      acc = mfma16(w0, x[kb][0], acc);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // (the bias is read behind the MFMAs: eight registers that are not live next to the fragment double buffer)
+    const fv4 bia0 = *reinterpret_cast<const fv4*>(b1s + 32 * q + 8 * kq), bia1 = *reinterpret_cast<const fv4*>(b1s + 32 * q + 8 * kq + 4);
+    h4 p0a, p1a, p0b, p1b;
+    relu_split4(a0, ds, bia0, p0a, p1a);
+    relu_split4(a1, ds, bia1, p0b, p1b);
+    const int hw = L::kH + opaque(wave) * (16 * 128);   // the wave's 16 rows of the hidden block
+    *reinterpret_cast<h8*>(fr0 + hw) = h8{p0a[0], p0a[1], p0a[2], p0a[3], p0b[0], p0b[1], p0b[2], p0b[3]};
+    *reinterpret_cast<h8*>(fr1 + hw) = h8{p1a[0], p1a[1], p1a[2], p1a[3], p1b[0], p1b[1], p1b[2], p1b[3]};
+  };
+  auto read_h = [&]() {
+    const int hr = L::kH + (opaque(wave) >> 2) * (64 * 128);   // the 64 rows of the wave's layer-2 tile
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      hf0[a] = *reinterpret_cast<const h8*>(fr0 + hr + a * 2048);
+      hf1[a] = *reinterpret_cast<const h8*>(fr1 + hr + a * 2048);
+    }
+  };
+  // B1 / B2: layer 2, one k-block, the first / second 64 columns of the wave's 128 from half-slot hs
+  auto phase_b = [&](auto half_c, const int hs) {
+    constexpr int half = decltype(half_c)::value;
+    const int so = L::kW2 + hs * L::kW2Half + (opaque(wave) & 3) * (64 * 128);   // the wave's 64 columns of the half-slot
+    const unsigned char* const s20 = fr0 + so;
+    const unsigned char* const s21 = fr1 + so;
+    h8 n0 = *reinterpret_cast<const h8*>(s20), n1 = *reinterpret_cast<const h8*>(s21);
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const h8 w0 = n0, w1 = n1;
+      if (cb + 1 < 4) {
+        n0 = *reinterpret_cast<const h8*>(s20 + (cb + 1) * 2048);
+        n1 = *reinterpret_cast<const h8*>(s21 + (cb + 1) * 2048);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) c16[a][4 * half + cb] = mfma16(w0, hf1[a], c16[a][4 * half + cb]);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) c16[a][4 * half + cb] = mfma16(w1, hf0[a], c16[a][4 * half + cb]);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) c16[a][4 * half + cb] = mfma16(w0, hf0[a], c16[a][4 * half + cb]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  using half0_t = std::integral_constant<int, 0>;
+  using half1_t = std::integral_constant<int, 1>;
+  auto next3 = [](const int v) { return v == 2 ? 0 : v + 1; };
+
+  // Two wave groups, one wave of each per SIMD, run the phase sequence A B1 B2 one interval apart (group 1 = waves 4-7 = the
+  // tile's rows 64-127 in BOTH layers: a group's hidden rows are written and read by the group itself), so that a SIMD always
+  // pairs two DIFFERENT phases -- layer 1's dependent epilogue (VALU, LDS write) runs under the partner's layer-2 MFMAs instead
+  // of under its own copy of the same epilogue.  Interval I0(q): G0 A(q) | G1 B2(q - 1);  I1(q): G0 B1(q) | G1 A(q);
+  // I2(q): G0 B2(q) | G1 B1(q); one workgroup barrier per interval.  A stage is read in two consecutive intervals (G0, then G1)
+  // and refilled at the head of the interval after them, by every wave:
+  //   head of I0(q): W2b(q)     -> half-slot (2 q + 1) % 3   (last readers: W2a(q - 1) in I1 / I2 of q - 1)
+  //   head of I1(q): W2a(q + 1) -> half-slot (2 q + 2) % 3   (W2b(q - 1): I2(q - 1), I0(q))
+  //   head of I2(q): W1(q + 1)  -> the W1 slot               (W1(q): I0(q), I1(q))
+  // and awaited in front of the barrier that ends the interval BEFORE the first use: end of I0(q): W2a(q) (7 younger pieces stay
+  // in flight), end of I1(q): W2b(q) (4), end of I2(q): W1(q + 1) (0).
+  // The loop body is the same for every k-block (no first / last special cases: a peeled or unswitched copy of 264 MFMAs costs
+  // registers and instruction cache): group 1's B2(-1) of the first interval runs on ZERO hidden fragments over the landed W2a(0)
+  // (adds exact zeros), and the last k-block's look-ahead fills re-fetch k-block nq - 1 into slots nobody reads again.
+#pragma unroll
+  for (int a = 0; a < 4; ++a) hf0[a] = hf1[a] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+  // (Two loops, one per group -- the group is wave-uniform, and in ONE loop with a branch per interval the compiler has to keep
+  //  hf0 / hf1 alive through the other group's phase A: 420 B of scratch.  Both loops execute the same barriers.)
+  auto end_interval = [&](auto younger_c) {
+    constexpr int Y = decltype(younger_c)::value;
+#ifdef AMP_FUSED_XP_NO_VMWAIT  // diagnostic builds only: the refills are issued but never awaited (racy, WRONG results): what the fill LATENCY costs
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+    if constexpr (Y == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+    else if constexpr (Y == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+    __builtin_amdgcn_s_barrier();
+  };
+  using y7 = std::integral_constant<int, 7>;
+  using y4 = std::integral_constant<int, 4>;
+  using y0 = std::integral_constant<int, 0>;
+  int m3 = 0;  // (2 q) % 3
+  if (wm == 0) {
+#pragma clang loop unroll(disable)
+    for (int q = 0; q < nq; ++q) {
+      const int qn = q + 1 < nq ? q + 1 : q;              // the look-ahead k-block (clamped at the end)
+      const int sA = m3, sB = next3(m3), sC = next3(sB);  // half-slots of W2a(q), W2b(q), and of W2b(q - 1) = W2a(q + 1)
+      fill_w2(q, 1, sB);   // I0(q)
+      phase_a(q);
+      end_interval(y7{});
+      fill_w2(qn, 0, sC);  // I1(q)
+      read_h();
+      phase_b(half0_t{}, sA);
+      end_interval(y4{});
+      fill_w1(qn);         // I2(q)
+      phase_b(half1_t{}, sB);
+      end_interval(y0{});
+      m3 = sC;
+    }
+  } else {
+#pragma clang loop unroll(disable)
+    for (int q = 0; q < nq; ++q) {
+      const int qn = q + 1 < nq ? q + 1 : q;
+      const int sA = m3, sB = next3(m3), sC = next3(sB);
+      fill_w2(q, 1, sB);   // I0(q)
+      phase_b(half1_t{}, q > 0 ? sC : sA);
+      end_interval(y7{});
+      fill_w2(qn, 0, sC);  // I1(q)
+      phase_a(q);
+      end_interval(y4{});
+      fill_w1(qn);         // I2(q)
+      read_h();
+      phase_b(half0_t{}, sA);
+      end_interval(y0{});
+      m3 = sC;
+    }
+    phase_b(half1_t{}, next3(next3(m3)));  // B2(nq - 1): half-slot (2 nq - 1) % 3
+  }
+
+  // ---- canonical partial logits: one per (row, 32-column block) = l2_partial16 of its two 16-column blocks.  The wave's 128
+  //      columns are the 32-column blocks 4 wn .. 4 wn + 3 (its column blocks 2 t, 2 t + 1); every lane of a row ends up with the
+  //      same four values, the lanes of group kq = 0 store them (one 16-B store per row) -----------------------------------------
+  fv4 bs[8], ws[8];
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    bs[b] = *reinterpret_cast<const fv4*>(g.b2 + 128 * wn + 16 * b + 4 * kq);
+    ws[b] = *reinterpret_cast<const fv4*>(g.w3 + 128 * wn + 16 * b + 4 * kq);
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    fv4 out;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      out[t] = l2_partial16(c16[a][2 * t], descale2, bs[2 * t], ws[2 * t]) + l2_partial16(c16[a][2 * t + 1], descale2, bs[2 * t + 1], ws[2 * t + 1]);
+    const int64_t row = m0 + 64 * wm + 16 * a + i16;
+    if (kq == 0) *reinterpret_cast<fv4*>(g.partial + row * 16 + 4 * wn) = out;
+  }
+}
+
+}  // namespace amp
