@@ -32,12 +32,16 @@ def _kernel_descriptors(tmp_path, source, extra=()):
 
 
 def test_gemm_kernels_use_no_scratch(tmp_path):
-    found = {k: v for k, v in _kernel_descriptors(tmp_path, os.path.join(CSRC, "disc.hip")).items() if "disc_gemm" in k}
+    every = _kernel_descriptors(tmp_path, os.path.join(CSRC, "disc.hip"))
+    found = {k: v for k, v in every.items() if "disc_gemm" in k}
     assert len(found) >= 8, sorted(found)                      # fp32 engine + register-staged + LDS-DMA instantiations
     spilled = {k: v for k, v in found.items() if v[0] != 0}
     assert not spilled, spilled
     dma = {k: v for k, v in found.items() if "disc_gemm_f16_dma_kernel" in k}
     assert len(dma) >= 5 and all(v[1] <= 256 for v in dma.values()), dma   # 8 waves per workgroup: 256 registers each
+    # the fused two-layer kernel (round 4) lives at 254 of 256 registers: one more long-lived address register and it spills
+    fused = {k: v for k, v in every.items() if "disc_mlp_fused_kernel" in k}
+    assert len(fused) >= 1 and all(v[0] == 0 and v[1] <= 256 for v in fused.values()), fused
 
 
 def test_training_step_gemm_kernels_use_no_scratch(tmp_path):
