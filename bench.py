@@ -255,12 +255,13 @@ def cpu_baseline(spec, n_envs, seed, target_seconds=12.0, probe=True, threads=No
             "ms_per_step": med * 1e3}
 
 
-TRIVIAL_KERNEL_US = 1.5   # what rocprofv3 reports for the one-workgroup command tick used as the bracket probe (profiles/r04_*)
+TRIVIAL_KERNEL_US = 3.4   # rocprofv3 duration of the bracketed one-workgroup command tick used as the probe: 3.37 us avg over 220 launches
+                          # (profiles/r04_v_bench_kernel_trace_by_grid.md, command_kernel @ 1 workgroup)
 
 
 def event_pair_overhead_us(device, reps=200):
     """What a HIP-event bracket of the engine's tracer adds to a launch: the median bracketed time of a ONE-workgroup kernel (the
-    command-timer tick of 64 envs: ~1.5 us under rocprofv3) minus that duration.  The tracer's per-kernel figures of bench.py are
+    command-timer tick of 64 envs: 3.4 us under rocprofv3 when bracketed) minus that duration.  The tracer's per-kernel figures of bench.py are
     reported raw AND with this subtracted, so that they can be read next to a rocprofv3 kernel trace."""
     from humanoid_amp_amd import _native as nat
     from humanoid_amp_amd.engine import command_step
@@ -581,7 +582,7 @@ def main():
                 "frac": (alg_bytes / ((us - pair) * 1e-6) / 1e9 / HBM_PEAK_GBS) if us > pair else None,
                 "traffic": hbm_traffic})(per_kernel.get("env_step_reference_kernel", 0.0), pair_us),
             "event_pair_overhead_us": round(pair_us, 2), "event_pair_probe_us": round(pair_floor, 2),
-            "event_pair_note": "median HIP-event bracket of a one-workgroup kernel (~1.5 us under rocprofv3) minus 1.5 us: what every "
+            "event_pair_note": "median HIP-event bracket of a one-workgroup kernel (3.4 us under rocprofv3 when bracketed) minus that: what every "
                                "bracketed per-kernel figure of this line carries on top of the kernel",
             "kernel_us_per_step": per_kernel,
             "kernel_us_per_step_note": "a separate, fully traced eager pass after the timed region: every launch carries a HIP-event "

@@ -360,11 +360,12 @@ def test_a_rows_logit_does_not_depend_on_the_kernel_plan(in_dim):
 
 
 @pytest.mark.parametrize("hidden,rows", [((384, 128), 900), ((640, 384), 7000), ((512, 256), 3500), ((512, 256), 40000),
-                                         ((1024, 256), 9000), ((128, 128), 300)])
+                                         ((1024, 256), 9000), ((128, 128), 300), ((768, 512), 30000), ((256, 512), 25000)])
 def test_other_hidden_widths_vs_fp64(hidden, rows):
     """Hidden widths other than the reference's 1024 / 512 (agents/*.yaml:31-39): multiples of 128 (the engine's granularity) that are not multiples of 256 stay on
     the register-staged kernels at every batch size (their 64 x 64 and 128 x 128 tiles, ragged last tiles), 256-multiples take the
-    LDS-DMA plans with one or two column tiles in layer 2 -- all on the 16 x 16 x 32 MFMA layout.  Bar as in
+    LDS-DMA plans with one or two column tiles in layer 2 -- all on the 16 x 16 x 32 MFMA layout; a 512-wide second layer over another
+    first-layer width (768, 256) at >= 24 576 rows takes the fused two-layer kernel (24 / 8 k-blocks instead of 32).  Bar as in
     test_gemm_engines_vs_fp64: logits within 1e-6 * max(1, |logit|) of the fp64 evaluation."""
     from humanoid_amp_amd.engine import AmpDiscriminator
 

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}/gpurun_out/$TAG
 mkdir -p "$R"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/trace" -- python3 bench.py > "$R/bench_traced.json" 2> "$R/bench_traced.err" || exit 1
-ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-fp32-engine --no-dropin"
+ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-fp32-engine --no-dropin --no-configs"
 export AMP_BENCH_NO_CALIBRATION=1  # the PMC passes need only the step kernels
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE \
   --output-format csv -d "$R/pmc_sq" -- python3 bench.py $ARGS > "$R/pmc_sq.json" 2> "$R/pmc_sq.err" || exit 2
