@@ -479,8 +479,15 @@ def main():
     allrecs = [r for r in tr.records() if is_dominant(r[0])]  # the fused two-layer kernel, or layer 2
     if allrecs:
         dominant = allrecs[-1][0]
-    fused = dominant == FUSED_KERNEL
-    per_step = max(1, round(sum(c for k, (c, t) in summary_all.items() if is_dominant(k)) / 16))
+    fused = FUSED_KERNEL in summary_all
+    fused_rows = envs
+    if fused and any(is_dominant(k) and k != FUSED_KERNEL for k in summary_all):
+        # a shard that is not a whole number of rounds of 128-row tiles: its full rounds run the fused kernel, the rest the
+        # column-split two-kernel plan (disc.hip fused_rows_of); the roofline object describes the fused launch
+        dominant = FUSED_KERNEL
+        allrecs = [r for r in allrecs if r[0] == FUSED_KERNEL]
+        fused_rows = envs // 32768 * 32768
+    per_step = max(1, round(sum(c for k, (c, t) in summary_all.items() if (k == FUSED_KERNEL if fused else is_dominant(k))) / 16))
     if trace_every == 1:
         recs = allrecs[-args.steps * per_step:]                        # small shards: traced pass = warmup + steps
     else:
@@ -516,7 +523,7 @@ def main():
             tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         except Exception:
             tj = {}
-        rows = envs // per_step
+        rows = (fused_rows if fused else envs) // per_step
         # keys are "kernel<template args>@workgroups" of one launch (tools/pmc_summary.py --traffic-json)
         if fused:
             traffic = (tj.get(f"{FUSED_KERNEL}<6>@{(rows + 127) // 128}") or {}).get("hbm_bytes")
@@ -526,9 +533,10 @@ def main():
         if spec.K == 2 and envs >= 32768 and envs % 32 == 0:
             wg = envs // 32 + (envs * spec.K + 255) // 256  # 32-env tiles + 256-sample expert tiles of the fused launch
             hbm_traffic = (tj.get(f"env_step_dma_reference_kernel<32>@{wg}") or {}).get("hbm_bytes")
-        flops2 = (2.0 * envs * 1024 * 512 + 2.0 * envs * 512) / per_step   # layer 2 + the fused 512 -> 1 dot, per launch
+        n_dom = fused_rows if fused else envs
+        flops2 = (2.0 * n_dom * 1024 * 512 + 2.0 * n_dom * 512) / per_step   # layer 2 + the fused 512 -> 1 dot, per launch
         if fused:  # both layers in the launch: + layer 1 (ALGORITHMIC K D, not the padded 192)
-            flops2 += 2.0 * envs * spec.K * spec.D * 1024 / per_step
+            flops2 += 2.0 * n_dom * spec.K * spec.D * 1024 / per_step
         achieved = flops2 / (gemm2_ms * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS[args.disc_precision]
         nprod = MFMA_PER_PRODUCT[args.disc_precision]
@@ -562,7 +570,7 @@ def main():
                          "traffic_source": "profiles/pmc_traffic.json (static: rocprofv3 --pmc passes of the profiled run, not "
                                            "re-measured by this process)" if traffic else None,
                          "avg_launch_ms": gemm2_ms, "launches_timed": len(recs), "launches_per_step": per_step, "timing": timing,
-                         "rows_per_launch": envs // per_step, "flops_per_launch": flops2,
+                         "rows_per_launch": n_dom // per_step, "flops_per_launch": flops2,
                          "mfma_products_per_flop": nprod, "frac_executed": nprod * achieved / peak,
                          "vs_fp32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS,
                          # measured on this device in this process: a bare v_mfma_f32_32x32x16_f16 stream, one wave per SIMD

@@ -430,8 +430,16 @@ static int64_t fused_min_rows() {
   }
   return v;
 }
-static bool fused_ok(const AmpDisc* h, int64_t rows) {
-  return h->h2 == kFusedN2 && h->k1h == 192 && h->h1 % 32 == 0 && h->h1 <= 1024 && rows >= fused_min_rows() && rows >= kFusedRows;
+// Leading rows of a `rows`-row batch that take the fused kernel.  A 128-row tile runs ~100 us whatever the batch, so the launch
+// costs whole ROUNDS of workgroups: every full round (one tile per CU: 32 768 rows on 256 CUs) is fused, and the rest joins it
+// only if it fills a last round to at least the threshold (24 576 rows: three quarters) -- otherwise those rows go through the
+// column-split two-kernel plans, which scale down (measured, us per step fused / split / unfused: 40 960 rows 231.9 / - / 225.3,
+// 49 152 rows 243.6 / - / 241.6 before the split; profiles/r04_fused_mlp_kernel.md).  Any split gives the same bits per row.
+static int64_t fused_rows_of(const AmpDisc* h, int64_t rows) {
+  if (!(h->h2 == kFusedN2 && h->k1h == 192 && h->h1 % 32 == 0 && h->h1 <= 1024) || rows < fused_min_rows() || rows < kFusedRows) return 0;
+  const int64_t per_round = (int64_t)dma_cu_count() * kFusedRows;
+  const int64_t full = rows / per_round * per_round, rem = rows - full;
+  return rem >= fused_min_rows() || rem == 0 ? rows : full;
 }
 static int f16_plan(const AmpDisc* h, int64_t rows) {
   if (h->h1 % kDmaBN != 0 || h->h2 % kDmaBN != 0) return kPlanRegister;   // the LDS-DMA tiles need 256-column multiples
@@ -448,7 +456,6 @@ static int f16_plan(const AmpDisc* h, int64_t rows) {
 }
 static bool f16_use_dma(const AmpDisc* h, int64_t rows) { return f16_plan(h, rows) != kPlanRegister; }
 static int64_t f16_chunk_rows(const AmpDisc* h, int64_t rows) {
-  if (fused_ok(h, rows)) return rows;  // no hidden layer in memory: nothing to keep cache-resident, one launch
   return f16_plan(h, kChunkRows) == kPlanDmaLarge && rows > kChunkRows + kChunkRows / 2 ? kChunkRows : rows;
 }
 static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* amax, int64_t rows, _Float16* H1p, float* partial,
@@ -456,23 +463,23 @@ static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* a
                             float* combined, hipStream_t st, const CompactLaunch* compact = nullptr) {
   // every kernel below accumulates in the same order and emits the same canonical partial logits (one per row and
   // 32-column block), so the choice changes the time, never a bit of the result
-  const int64_t chunk = f16_chunk_rows(h, rows);
+  const int64_t n_fused = fused_rows_of(h, rows);  // leading rows on the fused two-layer kernel (no hidden layer in memory)
+  const int64_t chunk = f16_chunk_rows(h, rows - n_fused);
   const int n_blocks = h->h2 / 32;  // canonical partial logits: one per (row, 32-column block)
   int rc = AMP_OK;
-  const bool fused = fused_ok(h, rows);
-  if (fused) {
+  if (n_fused > 0) {
     FusedArgs f{};
-    f.X = Xp; f.ldx = h->k1h; f.M = rows;
+    f.X = Xp; f.ldx = h->k1h; f.M = n_fused;
     f.W1b = h->w1b; f.W2b = h->w2b; f.b1 = h->b1; f.b2 = h->b2; f.w3 = h->w3;
     f.range = h->range; f.amax = amax; f.h1 = h->h1; f.partial = partial;
-    const unsigned grid = (unsigned)((rows + kFusedRows - 1) / kFusedRows);
+    const unsigned grid = (unsigned)((n_fused + kFusedRows - 1) / kFusedRows);
     { amp::TraceScope trace__("disc_mlp_fused_kernel", st);
       disc_mlp_fused_kernel<6><<<grid, kFusedThreads, FusedLds<6>::kBytes, st>>>(f);
     }
     rc = launch_status("disc_mlp_fused_kernel");
     if (rc != AMP_OK) return rc;
   }
-  for (int64_t r0 = 0; !fused && r0 < rows && rc == AMP_OK; r0 += chunk) {
+  for (int64_t r0 = n_fused; r0 < rows && rc == AMP_OK; r0 += chunk) {
     const int64_t m = rows - r0 < chunk ? rows - r0 : chunk;
     const int plan = f16_plan(h, chunk);  // by the chunk size (a short last chunk keeps the hidden layer's layout)
     const bool dma = plan != kPlanRegister;

@@ -338,7 +338,9 @@ def test_set_weights_in_place():
 def test_a_rows_logit_does_not_depend_on_the_kernel_plan(in_dim):
     """The same 1 500 rows scored inside batches that select every kernel plan of the fp16 engine -- register-staged 64 x 64
     tiles (2 000 rows), LDS-DMA 128 x 128 + 64 x 128 on the four-stage ring (3 500) and on two stages (5 000), 128 x 128 (9 000,
-    20 000), 256 x 256 + 256 x 128 (14 000), 256 x 256 (30 000, ragged last tile moved up) and 32 768-row chunks (70 000) -- give the
+    20 000), 256 x 256 + 256 x 128 (14 000), and at in_dim 166 the fused two-layer kernel: one ragged round (30 000), a full round + a
+    column-split remainder (40 000: 32 768 + 7 232), two rounds (58 000) and two full rounds + a remainder (70 000); at in_dim 830
+    256 x 256 tiles (30 000, ragged last tile moved up) and 32 768-row chunks -- give the
     same logits and style rewards bit for bit: every kernel of a layer issues the same MFMA shape in the same k order and reduces
     the output layer in the same canonical order."""
     from humanoid_amp_amd.engine import AmpDiscriminator
@@ -350,7 +352,7 @@ def test_a_rows_logit_does_not_depend_on_the_kernel_plan(in_dim):
     var = torch.rand(in_dim, generator=g, dtype=torch.float64) + 0.1
     d = AmpDiscriminator([(p.cuda(), q.cuda()) for p, q in w], "cuda:0", running_mean=mean, running_variance=var)
     ref = d.style_reward(x[:2000], want_logits=True)
-    for rows in (3500, 5000, 9000, 14000, 20000, 30000, 70000):
+    for rows in (3500, 5000, 9000, 14000, 20000, 30000, 40000, 58000, 70000):
         out = d.style_reward(x[:rows], want_logits=True)
         assert torch.equal(out["logits"][:1500], ref["logits"][:1500]), rows
         assert torch.equal(out["style"][:1500], ref["style"][:1500]), rows
