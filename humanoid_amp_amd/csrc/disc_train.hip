@@ -648,6 +648,15 @@ int gemm_f16x3(hipStream_t st, AmpDiscTrainer* t, const float* A, int64_t lda, i
 // C[M, N] (ld = ldc) = A W^T, optionally gated / accumulated.  `split` (scratch of k_slices * M * ldc floats) enables
 // split-K for the weight-gradient products whose reduction runs over the 4096..12288 batch rows while the output is
 // only a few hundred tiles: the slices' partial products land in `split` and are summed in slice order.
+// 64 x 64 tiles of the backward NT products with 32-deep k-tiles: a 64 x 64 tile has only 8 MFMAs (512 matrix-pipe cycles) per wave and
+// 16-deep k-tile between its two barriers and its LDS refill; 32-deep k-tiles halve the barriers per MFMA: 257-260 -> 246-248 us for the
+// five products of a step (gpurun_out/r04_t; AMP_TRAIN_BK32=0 switches them off: A/B runs).
+// The TT kernel adds its k-pairs in ascending order whatever the k-tile (bit-identical); the NT kernel's fixed k-permutation inside a
+// k-tile (disc_gemm.hpp) follows the tile depth, i.e. the fp32 summation order changes within the parity bars of the training tests.
+static bool bk32_ok() {
+  static const bool on = !(getenv("AMP_TRAIN_BK32") && getenv("AMP_TRAIN_BK32")[0] == '0');
+  return on;
+}
 int gemm_nt(hipStream_t st, const float* A, int64_t lda, int64_t M, const float* W, int Kp, int N, float* C, int64_t ldc,
             const float* mask, int64_t ldmask, int accumulate, float* split = nullptr) {
   GemmArgs g{};
@@ -670,6 +679,7 @@ int gemm_nt(hipStream_t st, const float* A, int64_t lda, int64_t M, const float*
   {
     amp::TraceScope trace__("disc_gemm_kernel<2>", st);
     if (big) disc_gemm_kernel<128, 128, 16, 1, 2, 4><<<grid, kBlock, 0, st>>>(g);
+    else if (bk32_ok() && Kp % 32 == 0) disc_gemm_kernel<64, 64, 32, 1, 2, 4><<<grid, kBlock, 0, st>>>(g);
     else disc_gemm_kernel<64, 64, 16, 1, 2, 4><<<grid, kBlock, 0, st>>>(g);
   }
   int rc = launch_status("disc_gemm_kernel<2>");
@@ -741,7 +751,7 @@ int gemm_tt(hipStream_t st, const float* A, int64_t lda, int M, const float* W, 
     amp::TraceScope trace__("disc_gemm_tt_kernel", st);
     if (plan.bm == 128 && plan.bn == 128) disc_gemm_tt_kernel<128, 128, 16, 4><<<grid, kBlock, 0, st>>>(g);
     else if (plan.bm == 128) disc_gemm_tt_kernel<128, 64, 16, 4><<<grid, kBlock, 0, st>>>(g);
-    else disc_gemm_tt_kernel<64, 64, 16, 4><<<grid, kBlock, 0, st>>>(g);
+    else disc_gemm_tt_kernel<64, 64, 16, 4><<<grid, kBlock, 0, st>>>(g);  // (32-deep k-tiles: 257.1 vs 255.0 us per step, no gain)
   }
   int rc = launch_status("disc_gemm_tt_kernel");
   if (rc != AMP_OK) return rc;
@@ -762,7 +772,7 @@ int gemm_fwd(hipStream_t st, const float* A, int64_t lda, int64_t M, const float
   const unsigned grid = (unsigned)(((int64_t)g.m_tiles * g.n_tiles + 7) / 8 * 8);
   amp::TraceScope trace__("disc_gemm_kernel<0>", st);
   if (big) disc_gemm_kernel<128, 128, 16, 1, 0, 4><<<grid, kBlock, 0, st>>>(g);
-  else disc_gemm_kernel<64, 64, 16, 1, 0, 8><<<grid, kBlock, 0, st>>>(g);
+  else disc_gemm_kernel<64, 64, 16, 1, 0, 8><<<grid, kBlock, 0, st>>>(g);  // (32-deep k-tiles: 162-166 vs 156-157 us for the two forwards: slower)
   return launch_status("disc_gemm_kernel<0>");
 }
 
