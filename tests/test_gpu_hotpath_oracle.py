@@ -5,7 +5,8 @@ layer 1 / layer 2, fused tail with the reset-id compaction) is run for three ste
 every output of every step is compared with ``oracle/hotpath.py`` -- the composition of oracle/{motion,env,disc}.py --
 which keeps its OWN AMP history across the steps, so drift would show.  Sizes cover the tile plans the benchmark uses:
 32-env tiles are exercised at 20 000 envs (>= 16 384), 16-env tiles at 4 096 / 3 000 (ragged last tile), 8-env tiles with
-K = 10 at 1 000.  Bars as in ``__graft_entry__.smoke()``: done bits and reset ids bit-exact, everything else <= 1e-5
+K = 10 at 1 000; the headline's discriminator plan since round 4 -- the fused two-layer kernel -- at 36 000 envs (one full round
+of 128-row tiles + a 3 232-row remainder on the two-kernel plan) and at 25 000 humanoid envs (one ragged round).  Bars as in ``__graft_entry__.smoke()``: done bits and reset ids bit-exact, everything else <= 1e-5
 (task / combined reward relative to max(1, |reward|); discriminator: skrl absent, parity unpinned).
 """
 
@@ -21,7 +22,8 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
 
-@pytest.mark.parametrize("workload,num_envs", [("g1_walk", 4096), ("g1_walk", 20000), ("g1_dance", 1000), ("humanoid3", 3000)])
+@pytest.mark.parametrize("workload,num_envs", [("g1_walk", 4096), ("g1_walk", 20000), ("g1_dance", 1000), ("humanoid3", 3000),
+                                               ("g1_walk", 36000), ("humanoid3", 25000)])
 def test_hot_step_matches_the_oracle(workload, num_envs):
     from humanoid_amp_amd.motions import MOTIONS_DIR
     from humanoid_amp_amd.robots import G1_JOINT_NAMES, G1_KEY_BODY_NAMES, HUMANOID_KEY_BODY_NAMES
