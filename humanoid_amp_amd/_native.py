@@ -59,7 +59,8 @@ class AmpCompactArgs(C.Structure):
 
 class AmpPrePhysicsArgs(C.Structure):
     _fields_ = [("actions_in", C.c_void_p), ("actions", C.c_void_p), ("last_actions", C.c_void_p), ("target", C.c_void_p),
-                ("offset", C.c_void_p), ("scale", C.c_void_p), ("num_envs", C.c_int64), ("n_actions", C.c_int32), ("reserved", C.c_int32)]
+                ("offset", C.c_void_p), ("scale", C.c_void_p), ("num_envs", C.c_int64), ("n_actions", C.c_int32), ("reserved", C.c_int32),
+                ("episode_length", C.c_void_p)]
 
 
 class AmpRewardLogArgs(C.Structure):

@@ -53,13 +53,17 @@ __global__ __launch_bounds__(kBlock) void command_kernel(AmpCommandArgs a, int64
 //   the reference's `self.action_offset + self.action_scale * self.actions`, bit for bit)   + the timers' tick for env < N.
 // A pure streaming kernel (one 16-B load, up to three 16-B stores per lane: 30 MB at 65 536 envs): the first `copy_blocks`
 // workgroups own four consecutive elements per lane (`vec`: every array 16-B aligned; else one element per lane), the
-// workgroups behind them tick one env's command timer per lane -- the Philox draw of an expired timer diverges only there.
+// workgroups behind them own one env per lane: `episode_length_buf += 1` and the command timer's tick -- the Philox draw of an
+// expired timer diverges only there.
 // (Round 3's body owned one element per lane and ticked from the joint-0 lanes: 10.7 us at 65 536 envs, 2.8 TB/s.)
-__global__ __launch_bounds__(kBlock) void pre_physics_kernel(AmpPrePhysicsArgs a, AmpCommandArgs c, unsigned copy_blocks, int vec) {
+__global__ __launch_bounds__(kBlock) void pre_physics_kernel(AmpPrePhysicsArgs a, AmpCommandArgs c, unsigned copy_blocks, int vec,
+                                                             int has_tick) {
   typedef float pf4 __attribute__((ext_vector_type(4)));
-  if (blockIdx.x >= copy_blocks) {
+  if (blockIdx.x >= copy_blocks) {  // the per-env workgroups: episode-length increment, command timers
     const int64_t env = (int64_t)(blockIdx.x - copy_blocks) * kBlock + threadIdx.x;
     if (env >= a.num_envs) return;
+    if (a.episode_length) a.episode_length[env] += 1;  // DirectRLEnv.step: self.episode_length_buf += 1
+    if (!has_tick) return;
     const float left = c.time_left[env] - c.step_dt;  // command_time_left -= step_dt (command_kernel's TICK branch)
     if (left <= 0.0f && c.vel_span > 0.0f) {
       float cx, cy, tl;
@@ -184,9 +188,9 @@ int amp_pre_physics_step(const AmpPrePhysicsArgs* a, const AmpCommandArgs* tick,
   const int vec = (bits & 15) == 0;  // (null pointers are aligned)
   const int64_t lanes = vec ? (total + 3) / 4 : total;
   const unsigned copy_blocks = (unsigned)((lanes + kBlock - 1) / kBlock);
-  const unsigned tick_blocks = tick ? (unsigned)((a->num_envs + kBlock - 1) / kBlock) : 0u;
+  const unsigned tick_blocks = (tick || a->episode_length) ? (unsigned)((a->num_envs + kBlock - 1) / kBlock) : 0u;
   { amp::TraceScope trace__("pre_physics_kernel", st);
-    pre_physics_kernel<<<copy_blocks + tick_blocks, kBlock, 0, st>>>(*a, tick ? *tick : AmpCommandArgs{}, copy_blocks, vec);
+    pre_physics_kernel<<<copy_blocks + tick_blocks, kBlock, 0, st>>>(*a, tick ? *tick : AmpCommandArgs{}, copy_blocks, vec, tick ? 1 : 0);
   }
   return launch_status("pre_physics_kernel");
 }

@@ -208,7 +208,12 @@ class _AmpEnv(DirectRLEnv):
             a.last_actions = self.last_actions.data_ptr() if self.IS_G1 else None
             a.offset, a.scale = self.action_offset.data_ptr(), self.action_scale.data_ptr()
             a.num_envs, a.n_actions = self.num_envs, int(self.actions.shape[1])
+            # DirectRLEnv.step's `episode_length_buf += 1` rides on this launch (nothing reads the buffer before _get_dones)
+            a.episode_length = self.episode_length_buf.data_ptr()
+            self._pre_physics_counts_steps = True
             p = self._pre_args = (a, nat.load().amp_pre_physics_step)
+        if p[0].episode_length != self.episode_length_buf.data_ptr():  # the buffer was re-assigned: follow it
+            p[0].episode_length = self.episode_length_buf.data_ptr()
         p[0].actions_in = actions.data_ptr()
         with torch.cuda.device(self.device):
             nat.check(p[1](C.byref(p[0]), C.byref(tick) if tick is not None else None, nat.stream_ptr()), "amp_pre_physics_step")

@@ -151,7 +151,8 @@ class DirectRLEnv:
         for _ in range(self.cfg.decimation):
             self._apply_action()
             self.robot.step() if hasattr(self.robot, "step") else None
-        self.episode_length_buf += 1
+        if not getattr(self, "_pre_physics_counts_steps", False):  # (tasks on the engine: done by the pre-physics launch)
+            self.episode_length_buf += 1
         self.common_step_counter += 1
         if self._step_dev is not None:
             self._step_dev += 1

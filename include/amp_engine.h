@@ -322,6 +322,9 @@ typedef struct {
   int64_t num_envs;
   int32_t n_actions;
   int32_t reserved;
+  /* optional: DirectRLEnv.step's `self.episode_length_buf += 1` (Isaac Lab does it between the physics step and _get_dones;
+   * nothing reads the buffer in between, so it may ride on this launch: one ATen launch fewer per env step) */
+  int64_t* episode_length;   /* dev [num_envs] int64, or NULL */
 } AmpPrePhysicsArgs;
 int amp_pre_physics_step(const AmpPrePhysicsArgs* args, const AmpCommandArgs* tick, amp_stream_t stream);
 

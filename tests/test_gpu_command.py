@@ -211,6 +211,9 @@ def test_pre_physics_step_equals_the_separate_launches():
     a = nat.AmpPrePhysicsArgs()
     a.actions_in, a.actions, a.last_actions, a.target = acts.data_ptr(), actions.data_ptr(), last.data_ptr(), target.data_ptr()
     a.offset, a.scale, a.num_envs, a.n_actions = off.data_ptr(), scale.data_ptr(), N, A
+    ep = torch.randint(0, 300, (N,), generator=gen).cuda()   # DirectRLEnv.step's episode_length_buf += 1 rides on the launch
+    ep0 = ep.clone()
+    a.episode_length = ep.data_ptr()
     t = nat.AmpCommandArgs()
     t.command, t.time_left = cmd_b.data_ptr(), left_b.data_ptr()
     t.step_dt, t.vel_lo, t.vel_span, t.t_lo, t.t_span = DT, VEL[0], VEL[1] - VEL[0], TIME[0], TIME[1] - TIME[0]
@@ -218,6 +221,7 @@ def test_pre_physics_step_equals_the_separate_launches():
     with torch.cuda.device("cuda:0"):
         nat.check(nat.load().amp_pre_physics_step(C.byref(a), C.byref(t), nat.stream_ptr()), "amp_pre_physics_step")
     assert torch.equal(actions, acts) and torch.equal(last, acts) and torch.equal(target, want_target)
+    assert torch.equal(ep, ep0 + 1)
     assert torch.equal(cmd_a, cmd_b) and torch.equal(left_a, left_b) and not torch.equal(cmd0, cmd_b)
     # NULL outputs / no tick / no affine map
     a2 = nat.AmpPrePhysicsArgs()
