@@ -235,3 +235,25 @@ def test_tt_gemm_shape_admission():
                 dict(M=1024, N=192, K=4096, ldw=194), dict(M=0, N=192, K=4096), dict(M=-64, N=192, K=4096)]:
         assert plan(**bad) is None, bad
     assert b"not admitted" in lib.amp_last_error()
+
+
+def test_engine_library_can_be_selected_by_environment(tmp_path):
+    """AMP_ENGINE_LIB (A/B variants must not overwrite the in-tree product library): the binding loads the named file,
+    still checks every symbol and the ABI version, and falls back to the in-tree library when the variable is unset or empty."""
+    import shutil
+    import subprocess
+    import sys
+
+    from humanoid_amp_amd import _native as nat
+
+    variant = tmp_path / "libamp_variant.so"
+    shutil.copy(nat.LIB_PATH if not os.environ.get("AMP_ENGINE_LIB") else os.path.join(ROOT, "humanoid_amp_amd", "csrc", "libamp_engine.so"),
+                variant)
+    code = "from humanoid_amp_amd import _native as n; n.load(); print(n.LIB_PATH, n.load().amp_abi_version())"
+    for env_value, want in ((str(variant), str(variant)), ("", os.path.join("csrc", "libamp_engine.so"))):
+        env = dict(os.environ, AMP_ENGINE_LIB=env_value, PYTHONPATH=ROOT)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
+        assert out[0].endswith(want) and int(out[1]) == nat.ABI_VERSION
+    bad = tmp_path / "missing.so"
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, AMP_ENGINE_LIB=str(bad), PYTHONPATH=ROOT), capture_output=True, text=True)
+    assert r.returncode != 0 and "no CPU fallback" in r.stderr
