@@ -65,6 +65,21 @@ struct FusedLds {
   static constexpr int kW1 = 0, kH = kW1Slot, kBias = kH + kFusedRows * 128, kW2 = kBias + 4096, kBytes = kW2 + 3 * kW2Half;
 };
 
+#ifdef AMP_FUSED_TIMELINE  // diagnostic builds only (tools/fused_timeline.py): per-workgroup stamps around the k-loop
+__device__ unsigned long long* g_fused_timeline;  // [workgroups][4]: s_memtime / s_memrealtime at loop start, at loop end
+extern "C" int amp_debug_fused_timeline(unsigned long long* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_fused_timeline), &buf, sizeof(buf)) == hipSuccess ? 0 : -2;
+}
+#define AMP_FUSED_STAMP(slot)                                                                    \
+  do {                                                                                           \
+    if (g_fused_timeline && threadIdx.x == 0) {                                                  \
+      g_fused_timeline[(size_t)blockIdx.x * 4 + 2 * (slot)] = __builtin_amdgcn_s_memtime();      \
+      g_fused_timeline[(size_t)blockIdx.x * 4 + 2 * (slot) + 1] = __builtin_amdgcn_s_memrealtime(); \
+    }                                                                                            \
+  } while (0)
+#else
+#define AMP_FUSED_STAMP(slot) do {} while (0)
+#endif
 template <int KX>
 __global__ __launch_bounds__(kFusedThreads, 2) void disc_mlp_fused_kernel(FusedArgs g) {
   using L = FusedLds<KX>;
@@ -132,16 +147,25 @@ __global__ __launch_bounds__(kFusedThreads, 2) void disc_mlp_fused_kernel(FusedA
   };
   static_assert((4 * KX) % 8 == 0 && NP1 == 3 && NP2 == 4, "the counted vmcnt waits are written for 3 + 4 pieces per wave");
 
+  // prologue: W2a(0), W1(0) -- then the steady issue order W2b(q), W2a(q + 1), W1(q + 1) of the interval heads.  Everything the
+  // first phase needs is REQUESTED before anything is awaited (stages, activation fragments above, the raw bias, the range
+  // record): one memory round trip in front of the first MFMA instead of four dependent ones (range record -> bias -> LDS ->
+  // stages: ~2 us per tile, measured with tools/fused_timeline.py: tiles of the second round used to start 97-103 us after the
+  // first for a 91.5-us k-loop).
+  fill_w2(0, 0, 0);
+  fill_w1(0);
+  float b1raw[2];  // h1 <= 1024: at most two units per lane
+#pragma unroll
+  for (int u = 0; u < 2; ++u) b1raw[u] = tid + u * kFusedThreads < g.h1 ? g.b1[tid + u * kFusedThreads] : 0.0f;
+  __builtin_amdgcn_sched_barrier(0);
   const LayerScales sc1 = layer_scales(g.range, g.amax, 1);
   const float s_h = sc1.s_out, ds = sc1.descale * s_h;
   const float descale2 = layer_scales(g.range, g.amax, 2).descale;
   // layer 1's bias, scaled, in LDS: lane (i, kq) needs the eight units 32 q + 8 kq .. + 7 per k-block
   float* const b1s = reinterpret_cast<float*>(lds + L::kBias);
-  for (int e = tid; e < g.h1; e += kFusedThreads) b1s[e] = g.b1[e] * s_h;
-
-  // prologue: W2a(0), W1(0) -- then the steady issue order W2b(q), W2a(q + 1), W1(q + 1) of the interval heads
-  fill_w2(0, 0, 0);
-  fill_w1(0);
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    if (tid + u * kFusedThreads < g.h1) b1s[tid + u * kFusedThreads] = b1raw[u] * s_h;
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // W1(0), W2a(0) and the bias are visible to every wave
 
@@ -162,6 +186,13 @@ __global__ __launch_bounds__(kFusedThreads, 2) void disc_mlp_fused_kernel(FusedA
     const unsigned char* s1 = lds + L::kW1 + frag_row;
     const fv4 bia0 = *reinterpret_cast<const fv4*>(b1s + 32 * q + 8 * kq), bia1 = *reinterpret_cast<const fv4*>(b1s + 32 * q + 8 * kq + 4);
     fx4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#ifndef AMP_FUSED_NO_PRIO_A
+    // Phase A is a serial path: 36 MFMAs, THEN ~60 VALU operations and two LDS writes that depend on them.  The SIMD's other
+    // wave is in a layer-2 phase (48 independent MFMAs): with equal priority the pipe alternates between the two, this wave's
+    // MFMAs finish when the partner has a dozen left, and the epilogue runs beside an idle pipe.  Raised priority for the MFMA part
+    // puts this wave's 36 first; its epilogue then runs under the partner's remaining MFMAs.
+    __builtin_amdgcn_s_setprio(2);
+#endif
 #pragma unroll
     for (int kb = 0; kb < KX; ++kb) {
       const h8 w00 = *reinterpret_cast<const h8*>(s1 + kb * 4096 + ch0), w01 = *reinterpret_cast<const h8*>(s1 + kb * 4096 + ch1);
@@ -173,6 +204,11 @@ __global__ __launch_bounds__(kFusedThreads, 2) void disc_mlp_fused_kernel(FusedA
       a0 = mfma16(w00, x[kb][0], a0);
       a1 = mfma16(w10, x[kb][0], a1);
     }
+#ifndef AMP_FUSED_NO_PRIO_A
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    // (the same arithmetic in ~40 instead of ~70 instructions -- v_cvt_f16_f32 + v_fma_mixhi_f16 + v_perm packing -- was measured
+    //  equal once the phase's MFMAs run at raised priority: 203.4 us either way)
     h4 p0a, p1a, p0b, p1b;
     relu_split4(a0, ds, bia0, p0a, p1a);
     relu_split4(a1, ds, bia1, p0b, p1b);
@@ -234,13 +270,19 @@ __global__ __launch_bounds__(kFusedThreads, 2) void disc_mlp_fused_kernel(FusedA
   using y4 = std::integral_constant<int, 4>;
   using y0 = std::integral_constant<int, 0>;
   int m3 = 0;  // (2 q) % 3
+  AMP_FUSED_STAMP(0);
   if (wm == 0) {
 #pragma clang loop unroll(disable)
     for (int q = 0; q < nq; ++q) {
       const int qn = q + 1 < nq ? q + 1 : q;              // the look-ahead k-block (clamped at the end)
       const int sA = m3, sB = next3(m3), sC = next3(sB);  // half-slots of W2a(q), W2b(q), and of W2b(q - 1) = W2a(q + 1)
+#ifdef AMP_FUSED_FILL_FIRST
       fill_w2(q, 1, sB);   // I0(q)
       phase_a(q);
+#else
+      phase_a(q);          // I0(q): the serial phase starts right behind the barrier; its share of the refill goes out at its end
+      fill_w2(q, 1, sB);
+#endif
       end_interval(y7{});
       fill_w2(qn, 0, sC);  // I1(q)
       read_h();
@@ -259,8 +301,13 @@ __global__ __launch_bounds__(kFusedThreads, 2) void disc_mlp_fused_kernel(FusedA
       fill_w2(q, 1, sB);   // I0(q)
       phase_b(half1_t{}, q > 0 ? sC : sA);
       end_interval(y7{});
+#ifdef AMP_FUSED_FILL_FIRST
       fill_w2(qn, 0, sC);  // I1(q)
       phase_a(q);
+#else
+      phase_a(q);          // I1(q)
+      fill_w2(qn, 0, sC);
+#endif
       end_interval(y4{});
       fill_w1(qn);         // I2(q)
       read_h();
@@ -271,6 +318,7 @@ __global__ __launch_bounds__(kFusedThreads, 2) void disc_mlp_fused_kernel(FusedA
     phase_b(half1_t{}, next3(next3(m3)));  // B2(nq - 1): half-slot (2 nq - 1) % 3
   }
 
+  AMP_FUSED_STAMP(1);
   // ---- canonical partial logits: one per (row, 32-column block) = l2_partial16 of its two 16-column blocks.  The wave's 128
   //      columns are the 32-column blocks 4 wn .. 4 wn + 3 (its column blocks 2 t, 2 t + 1); every lane of a row ends up with the
   //      same four values, the lanes of group kq = 0 store them (one 16-B store per row) -----------------------------------------
