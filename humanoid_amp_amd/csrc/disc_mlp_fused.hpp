@@ -223,7 +223,10 @@ __global__ __launch_bounds__(kFusedThreads, 2) void disc_mlp_fused_kernel(FusedA
     }
   };
   // B1 / B2: layer 2, one k-block, the first / second 64 columns of the wave's 128 from half-slot hs
-  auto phase_b = [&](auto half_c, const int hs) {
+  // `refill()` issues the wave's share of the interval's refill: behind the FIRST column block's MFMAs, not at the head of the
+  // interval -- in I2 both waves of a SIMD are in a layer-2 phase, and with the pieces in front (address arithmetic + ~100
+  // cycles of issue each) neither reached its first MFMA for ~600 cycles behind the barrier.
+  auto phase_b = [&](auto half_c, const int hs, auto&& refill) {
     constexpr int half = decltype(half_c)::value;
     const unsigned char* s2 = lds + L::kW2 + hs * L::kW2Half + w2frag;
 #pragma unroll
@@ -235,8 +238,14 @@ __global__ __launch_bounds__(kFusedThreads, 2) void disc_mlp_fused_kernel(FusedA
       for (int a = 0; a < 4; ++a) c16[a][4 * half + cb] = mfma16(w1, hf0[a], c16[a][4 * half + cb]);
 #pragma unroll
       for (int a = 0; a < 4; ++a) c16[a][4 * half + cb] = mfma16(w0, hf0[a], c16[a][4 * half + cb]);
+      if (cb == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        refill();
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
+  auto no_refill = []() {};
   using half0_t = std::integral_constant<int, 0>;
   using half1_t = std::integral_constant<int, 1>;
   auto next3 = [](const int v) { return v == 2 ? 0 : v + 1; };
@@ -284,12 +293,10 @@ __global__ __launch_bounds__(kFusedThreads, 2) void disc_mlp_fused_kernel(FusedA
       fill_w2(q, 1, sB);
 #endif
       end_interval(y7{});
-      fill_w2(qn, 0, sC);  // I1(q)
-      read_h();
-      phase_b(half0_t{}, sA);
+      read_h();            // I1(q)
+      phase_b(half0_t{}, sA, [&]() { fill_w2(qn, 0, sC); });
       end_interval(y4{});
-      fill_w1(qn);         // I2(q)
-      phase_b(half1_t{}, sB);
+      phase_b(half1_t{}, sB, [&]() { fill_w1(qn); });   // I2(q)
       end_interval(y0{});
       m3 = sC;
     }
@@ -298,8 +305,7 @@ __global__ __launch_bounds__(kFusedThreads, 2) void disc_mlp_fused_kernel(FusedA
     for (int q = 0; q < nq; ++q) {
       const int qn = q + 1 < nq ? q + 1 : q;
       const int sA = m3, sB = next3(m3), sC = next3(sB);
-      fill_w2(q, 1, sB);   // I0(q)
-      phase_b(half1_t{}, q > 0 ? sC : sA);
+      phase_b(half1_t{}, q > 0 ? sC : sA, [&]() { fill_w2(q, 1, sB); });   // I0(q)
       end_interval(y7{});
 #ifdef AMP_FUSED_FILL_FIRST
       fill_w2(qn, 0, sC);  // I1(q)
@@ -309,13 +315,12 @@ __global__ __launch_bounds__(kFusedThreads, 2) void disc_mlp_fused_kernel(FusedA
       fill_w2(qn, 0, sC);
 #endif
       end_interval(y4{});
-      fill_w1(qn);         // I2(q)
-      read_h();
-      phase_b(half0_t{}, sA);
+      read_h();            // I2(q)
+      phase_b(half0_t{}, sA, [&]() { fill_w1(qn); });
       end_interval(y0{});
       m3 = sC;
     }
-    phase_b(half1_t{}, next3(next3(m3)));  // B2(nq - 1): half-slot (2 nq - 1) % 3
+    phase_b(half1_t{}, next3(next3(m3)), no_refill);  // B2(nq - 1): half-slot (2 nq - 1) % 3
   }
 
   AMP_FUSED_STAMP(1);
