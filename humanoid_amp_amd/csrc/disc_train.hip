@@ -242,11 +242,18 @@ __global__ __launch_bounds__(kBlock) void sumsq_part_kernel(float* __restrict__ 
 // Adam; the L2-type regularisers enter as grad += reg2 * p  (reg2 = 2 * loss_scale * coefficient).
 // The six parameter tensors in ONE launch (they are 4-6 us each alone, launch-bound): segment s covers the flat indices
 // [start[s], start[s + 1]).
+// A segment's gradient may still be in pieces when Adam runs (the forked step): `slices[s]` split-K slices `slice_stride[s]` floats
+// apart, summed here in slice order (what sum_slices_kernel did in a launch of its own), and, for segment 4 (w3), the
+// gradient-penalty chain's column-sum partials `colpart[chunk * cols + c]` (colsum_final_kernel's accumulate).
 struct AdamSegs {
   float* p[6]; const float* g[6]; float* m[6]; float* v[6];
   int64_t ld_p[6], ld_g[6], start[7];
+  int64_t slice_stride[6];
   int32_t cols[6];
+  int32_t slices[6];
   float reg2[6];
+  const float* colpart;
+  int32_t colpart_chunks;
 };
 // What changes from step to step besides the tensors lives on the DEVICE, so that a captured hipGraph of the training step
 // advances it by itself: state[0] = samples the running scaler has seen (double), state[1] = Adam step (int64 bits),
@@ -284,7 +291,15 @@ __global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamSegs a, float lr
   if (s == 0) sq[0] = pv * pv;
   if (s == 2) sq[1] = pv * pv;
   if (s == 4) sq[2] = pv * pv;
-  const float gr = a.g[s][r * a.ld_g[s] + c] + a.reg2[s] * pv;
+  const float* gp = a.g[s] + r * a.ld_g[s] + c;
+  float gsum = gp[0];
+  for (int k = 1; k < a.slices[s]; ++k) gsum += gp[(int64_t)k * a.slice_stride[s]];
+  if (s == 4 && a.colpart != nullptr) {
+    float cs = 0.0f;
+    for (int ch = 0; ch < a.colpart_chunks; ++ch) cs += a.colpart[(int64_t)ch * a.cols[4] + c];
+    gsum = gsum + cs;
+  }
+  const float gr = gsum + a.reg2[s] * pv;
   if (grad_out) grad_out[e] = gr;  // parameter order, logical shapes: the segments are laid out that way
   const float mi = b1 * a.m[s][i] + (1.0f - b1) * gr;
   const float vi = b2 * a.v[s][i] + (1.0f - b2) * gr * gr;
@@ -313,7 +328,7 @@ constexpr int kFinalBlock = 1024;
 __global__ __launch_bounds__(kFinalBlock) void reg_final_kernel(const float* __restrict__ part, int n, float logit_reg,
                                                                 float weight_decay, float loss_scale,
                                                                 const float* __restrict__ bce_part, int n_bce, float n_fake,
-                                                                float n_real, float* __restrict__ loss) {
+                                                                float n_real, float* __restrict__ loss, float* __restrict__ loss_out) {
   __shared__ float red[5][kFinalBlock];
   float s[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
   for (int i = threadIdx.x; i < n; i += kFinalBlock) {
@@ -337,10 +352,14 @@ __global__ __launch_bounds__(kFinalBlock) void reg_final_kernel(const float* __r
     const float l0 = 0.5f * (red[3][0] / n_fake + red[4][0] / n_real);
     const float l2 = logit_reg * red[2][0];
     const float l3 = ((weight_decay * red[0][0]) + weight_decay * red[1][0]) + weight_decay * red[2][0];
+    const float l1 = loss[1], l4 = loss_scale * (((l0 + l1) + l2) + l3);
     loss[0] = l0;
     loss[2] = l2;
     loss[3] = l3;
-    loss[4] = loss_scale * (((l0 + loss[1]) + l2) + l3);
+    loss[4] = l4;
+    if (loss_out) {   // the caller's copy (was a 4.6-us device-to-device copy behind this kernel)
+      loss_out[0] = l0; loss_out[1] = l1; loss_out[2] = l2; loss_out[3] = l3; loss_out[4] = l4;
+    }
   }
 }
 
@@ -543,6 +562,10 @@ struct AmpDiscTrainer {
   int64_t plane_halves;          // capacity of each
   float* amax;                   // [kAmaxSlots]
   int amax_next;
+  // the gradient-penalty chain (six GEMMs over the motion rows, grids that do not fill the chip) runs beside the prediction
+  // loss's backward on a stream of the trainer's own: fork / join through these events (capturable: the side stream joins back)
+  hipStream_t side;
+  hipEvent_t ev[4];              // step start | W^T copies written | forward done | penalty chain done
 };
 
 namespace {
@@ -653,6 +676,11 @@ int gemm_f16x3(hipStream_t st, AmpDiscTrainer* t, const float* A, int64_t lda, i
 // five products of a step (gpurun_out/r04_t; AMP_TRAIN_BK32=0 switches them off: A/B runs).
 // The TT kernel adds its k-pairs in ascending order whatever the k-tile (bit-identical); the NT kernel's fixed k-permutation inside a
 // k-tile (disc_gemm.hpp) follows the tile depth, i.e. the fp32 summation order changes within the parity bars of the training tests.
+// AMP_TRAIN_FORK=0 keeps the whole step on the caller's stream (read per step: the tests compare the two in one process)
+static bool fork_ok() {
+  const char* e = getenv("AMP_TRAIN_FORK");
+  return !(e && e[0] == '0');
+}
 static bool bk32_ok() {
   static const bool on = !(getenv("AMP_TRAIN_BK32") && getenv("AMP_TRAIN_BK32")[0] == '0');
   return on;
@@ -720,6 +748,8 @@ static int tt_plan(int M, int N, int64_t K, int64_t lda, int64_t ldw, int64_t ld
   // the slice count is the 64 x 64 plan's whatever tile runs: a row of C is then the same sum on every tile shape (bit-identical)
   const int slices = tt_slices((M / 64) * (N / 64), K, split);
   TtPlan p{64, 64, slices};
+  // (the 512 re-measured under the forked step, where a second stream fills the chip: admitting the large tiles from 256 or 128
+  //  workgroups made the step slower, 0.703-0.705 vs 0.680-0.687 ms, gpurun_out/r04_al)
   if (M % 128 == 0 && N % 128 == 0 && (M / 128) * (N / 128) * slices >= 512) p = TtPlan{128, 128, slices};
   else if (M % 128 == 0 && (M / 128) * (N / 64) * slices >= 512) p = TtPlan{128, 64, slices};
   if (M % p.bm != 0 || N % p.bn != 0) return kShapeNotSupported;  // (cannot happen by construction; the kernel's precondition)
@@ -727,10 +757,28 @@ static int tt_plan(int M, int N, int64_t K, int64_t lda, int64_t ldw, int64_t ld
   return AMP_OK;
 }
 
+//
+// `raw`: write this product's k-slices (even a single one) to `split` and return their number in *raw without summing -- the
+// forked step's two products of a weight run on two streams, each into its own slice region, and one sum follows the join.
 int gemm_tt(hipStream_t st, const float* A, int64_t lda, int M, const float* W, int64_t ldw, int N, int64_t K, float* C, int64_t ldc,
-            int accumulate, float* split, int* defer = nullptr) {
+            int accumulate, float* split, int* defer = nullptr, int* raw = nullptr) {
   TtPlan plan;
   if (tt_plan(M, N, K, lda, ldw, ldc, split != nullptr, &plan) != AMP_OK) return kShapeNotSupported;
+  if (raw) {
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.M = M; g.K = (int32_t)K; g.W = W; g.Kp = (int32_t)ldw; g.N = N; g.C = split; g.ldc = ldc;
+    g.n_tiles = N / plan.bn; g.m_tiles = M / plan.bm;
+    g.k_slices = plan.slices; g.slice_stride = (int64_t)M * ldc;
+    const unsigned grid = (unsigned)(((int64_t)g.m_tiles * g.n_tiles * plan.slices + 7) / 8 * 8);
+    {
+      amp::TraceScope trace__("disc_gemm_tt_kernel", st);
+      if (plan.bm == 128 && plan.bn == 128) disc_gemm_tt_kernel<128, 128, 16, 4><<<grid, kBlock, 0, st>>>(g);
+      else if (plan.bm == 128) disc_gemm_tt_kernel<128, 64, 16, 4><<<grid, kBlock, 0, st>>>(g);
+      else disc_gemm_tt_kernel<64, 64, 16, 4><<<grid, kBlock, 0, st>>>(g);
+    }
+    *raw = plan.slices;
+    return launch_status("disc_gemm_tt_kernel");
+  }
   GemmArgs g{};
   g.A = A; g.lda = lda; g.M = M; g.K = (int32_t)K; g.W = W; g.Kp = (int32_t)ldw; g.N = N; g.C = C; g.ldc = ldc;
   g.accumulate = accumulate;
@@ -800,6 +848,9 @@ int amp_disc_trainer_destroy(AmpDiscTrainer* t) {
   (void)hipFree(t->planes[0]);
   (void)hipFree(t->planes[1]);
   (void)hipFree(t->amax);
+  for (hipEvent_t e : t->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (t->side) (void)hipStreamDestroy(t->side);
   delete t;
   return AMP_OK;
 }
@@ -848,7 +899,10 @@ int amp_disc_trainer_create(AmpDisc* disc, const AmpDiscTrainCfg* cfg, const dou
                     (int64_t)p.h1 * t->kN + p.h1 + (int64_t)p.h2 * p.h1 + p.h2 + p.h2 + 1 + 64;    // grads + loss
   t->ws_floats = f + (int64_t)16 * p.h2 * p.h1 + (int64_t)16 * p.h1 * t->kN + 64 + 2 * ((M + 3) / 4) + 16 + (int64_t)kChunks * 1024 + 1024 + 3 * (up((int64_t)kChunks * p.in_dim * 2, 8) * 2) + 16 +
                  16 * 40 + 6 * up(p.k1p, 16) + M * (t->kN - p.k1p) + 2 * (int64_t)kChunks * 1024;
+  t->ws_floats += (int64_t)16 * p.h2 * p.h1 + (int64_t)16 * p.h1 * t->kN + (int64_t)3 * kChunks * 1024 + 1024 + 64;  // the side stream's slices + partials
   if (e == hipSuccess) e = hipMalloc(&t->ws, sizeof(float) * t->ws_floats);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking);
+  for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&t->ev[i], hipEventDisableTiming);
   if (e == hipSuccess && cfg->gemm_f16x3) {
     // fp16-split GEMM path: planes of the largest operand ([3B (padded), max(h1, h2)] or its transpose), twice
     const int64_t rows = up(Mp, 32), cols = up(std::max<int64_t>(std::max(p.h1, p.h2), up(t->kN, 32)), 32);
@@ -933,9 +987,10 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
   float* gw3 = take(H2n);
   float* gb3 = take(1);
   float* loss = take(16);  // [0] prediction, [1] gradient penalty, [2] logit reg, [3] weight decay
-  float* split = take((int64_t)16 * H2n * H1n);                  // split-K partial products (largest: gW2)
-  float* split1 = take((int64_t)16 * H1n * kN);                  // ... of gW1 (both weights' slices are alive at once: deferred sums)
+  float* split = take((int64_t)32 * H2n * H1n);                  // split-K partial products of gW2: <= 16 slices per product, two products
+  float* split1 = take((int64_t)32 * H1n * kN);                  // ... of gW1 (both weights' slices are alive at once: deferred sums)
   float* part = take((int64_t)3 * kChunks * 1024 + 1024);      // column-sum / scalar partials (three planes: dh2_colsum_kernel)
+  float* part_side = take((int64_t)3 * kChunks * 1024 + 1024); // ... of the gradient-penalty chain when it runs on the side stream
   const int64_t dpart_stride = up((int64_t)kChunks * p.in_dim * 2, 8);                 // doubles per batch
   double* dpart = reinterpret_cast<double*>(take(3 * dpart_stride * 2 + 16));
   const int vec_stride = (int)up(k1p, 16);
@@ -948,10 +1003,11 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
     colsum_part_kernel<<<dim3((cols_ + 63) / 64, kChunks), kBlock, 0, st>>>(A, rows_, cols_, lda_, rowscale, mask, ldm, part);
     colsum_final_kernel<<<(cols_ + kBlock - 1) / kBlock, kBlock, 0, st>>>(part, cols_, out, accumulate);
   };
-  auto sumsq = [&](float* x, int64_t rows_, int cols_, int64_t ld_, float coef, int in_place, float scale, int slot, int accumulate) {
+  auto sumsq = [&](hipStream_t s_, float* part_, float* x, int64_t rows_, int cols_, int64_t ld_, float coef, int in_place, float scale,
+                   int slot, int accumulate) {
     const int nb = 256;
-    sumsq_part_kernel<<<nb, kBlock, 0, st>>>(x, rows_, cols_, ld_, coef, in_place, part);
-    scalar_final_kernel<<<1, 256, 0, st>>>(part, nb, scale, loss, slot, accumulate);
+    sumsq_part_kernel<<<nb, kBlock, 0, s_>>>(x, rows_, cols_, ld_, coef, in_place, part_);
+    scalar_final_kernel<<<1, 256, 0, s_>>>(part_, nb, scale, loss, slot, accumulate);
   };
   int rc;
   // layer 1's bias gradient = colsum(dH1) comes out of the TT product dH1^T Xs when Xs carries a column of ones in its padding
@@ -969,14 +1025,42 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
     AMP_HIP(hipMemsetAsync(t->amax, 0, sizeof(float) * kAmaxSlots, st));
   }
   const int64_t split_floats = (int64_t)16 * H2n * H1n;
-  auto nt = [&](const float* A, int64_t lda, int64_t Mr, const float* W, int Kp, int N, float* C, int64_t ldc, const float* mask,
-                int64_t ldmask, int accumulate, float* split_ws = nullptr) -> int {
+  auto nt_on = [&](hipStream_t s_, const float* A, int64_t lda, int64_t Mr, const float* W, int Kp, int N, float* C, int64_t ldc,
+                   const float* mask, int64_t ldmask, int accumulate, float* split_ws = nullptr) -> int {
     if (f16) {
-      const int r = gemm_f16x3(st, t, A, lda, Mr, W, Kp, N, Kp, nullptr, 0, C, ldc, mask, ldmask, accumulate, split_ws, split_floats);
+      const int r = gemm_f16x3(s_, t, A, lda, Mr, W, Kp, N, Kp, nullptr, 0, C, ldc, mask, ldmask, accumulate, split_ws, split_floats);
       if (r != kShapeNotSupported) return r;
     }
-    return gemm_nt(st, A, lda, Mr, W, Kp, N, C, ldc, mask, ldmask, accumulate, split_ws);
+    return gemm_nt(s_, A, lda, Mr, W, Kp, N, C, ldc, mask, ldmask, accumulate, split_ws);
   };
+  auto nt = [&](const float* A, int64_t lda, int64_t Mr, const float* W, int Kp, int N, float* C, int64_t ldc, const float* mask,
+                int64_t ldmask, int accumulate, float* split_ws = nullptr) -> int {
+    return nt_on(st, A, lda, Mr, W, Kp, N, C, ldc, mask, ldmask, accumulate, split_ws);
+  };
+  // ---- fork: the gradient-penalty chain on the trainer's side stream when all four weight-gradient products take the TT kernel
+  const bool pair = c.grad_penalty_scale != 0.0f;
+  int sl_w2[2] = {0, 0}, sl_w1[2] = {0, 0};   // k-slices of (prediction, penalty) product of gW2 / gW1
+  bool fork = pair && !f16 && fork_ok() && t->side != nullptr;
+  if (fork) {
+    TtPlan q;
+    fork = tt_plan(H2n, H1n, M, H2n, H1n, H1n, true, &q) == AMP_OK;
+    sl_w2[0] = q.slices;
+    fork = fork && tt_plan(H1n, kN, M, H1n, kN, kN, true, &q) == AMP_OK;
+    sl_w1[0] = q.slices;
+    fork = fork && tt_plan(H1n, kN, B, H1n, kN, kN, true, &q) == AMP_OK;
+    sl_w1[1] = q.slices;
+    fork = fork && tt_plan(H2n, H1n, B, H2n, H1n, H1n, true, &q) == AMP_OK;
+    sl_w2[1] = q.slices;
+  }
+  hipStream_t side = fork ? t->side : st;
+  if (fork) {
+    // the side stream starts with the two W^T copies (they only need last step's Adam), under the scaler passes
+    AMP_HIP(hipEventRecord(t->ev[0], st));
+    AMP_HIP(hipStreamWaitEvent(side, t->ev[0], 0));
+    transpose(side, p.w2, H2n, H1n, H1n, t->w2t, H2n, H1n);               // W2^T [h1, h2]
+    transpose(side, p.w1p, H1n, k1p, k1p, t->w1t, H1n, kN);               // W1^T [kN, h1] (zero rows >= k1p)
+    AMP_HIP(hipEventRecord(t->ev[1], side));
+  }
   // ---- 1. scaler (train=True): update the running statistics with each batch, then scale it --------------------
   const float* mean32 = nullptr;
   const float* den32 = nullptr;
@@ -1004,7 +1088,8 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
     scale_rows3_kernel<<<dim3(blocks(B * kN), 3), kBlock, 0, st>>>(b3, row_stride, B, p.in_dim, kN, mean32, den32, vstride, clip, Xs,
                                                                    ones_col);
   }
-  if (c.use_scaler && c.update_scaler && !c.defer_refresh) {
+  const bool scaler_to_handle = c.use_scaler && c.update_scaler && !c.defer_refresh;
+  if (scaler_to_handle && !fork) {
     // the discriminator handle serves inference with the statistics after the third batch
     rc = amp_disc_set_scaler(t->disc, t->mean64, t->var64, c.scaler_epsilon, c.scaler_clip, stream);
     if (rc != AMP_OK) return rc;
@@ -1018,79 +1103,127 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
   rc = gemm_fwd(st, H1, H1n, M, p.w2, H1n, H2n, p.b2, H2);
   if (rc != AMP_OK) return rc;
   const unsigned n_bce = (unsigned)((M + 3) / 4);
+  if (fork) AMP_HIP(hipEventRecord(t->ev[2], st));   // H1 / H2 are complete: the penalty chain may start
   rowdot_bce_kernel<<<n_bce, kBlock, 0, st>>>(H2, M, H2n, H2n, p.w3, p.b3, 2 * B, c.loss_scale, logit, dlogit, bce_part);
 
-  // ---- 3. backward of the prediction loss ----------------------------------------------------------------------
-  // dH2 = dlogit (x) w3 * (H2 > 0), gw3 = H2^T dlogit, gb2 = colsum(dH2), gb3 = sum(dlogit): one pass over H2
-  dh2_colsum_kernel<<<dim3((H2n + 63) / 64, kChunks), kBlock, 0, st>>>(dlogit, p.w3, H2, M, H2n, dH2, part);
-  dh2_colsum_final_kernel<<<(H2n + kBlock - 1) / kBlock, kBlock, 0, st>>>(part, H2n, gw3, gb2, gb3);
-  transpose(st, p.w2, H2n, H1n, H1n, t->w2t, H2n, H1n);               // W2^T [h1, h2]
-  transpose(st, p.w1p, H1n, k1p, k1p, t->w1t, H1n, kN);               // W1^T [kN, h1] (zero rows >= k1p)
-  rc = nt(dH2, H2n, M, t->w2t, H2n, H1n, dH1, H1n, H1, H1n, 0);   // dH1 = (dH2 W2) * (H1 > 0)
-  if (rc != AMP_OK) return rc;
-  if (ones_col < 0) colsum(dH1, M, H1n, H1n, nullptr, nullptr, 0, gb1, 0);
-  // the weight gradients reduce over the batch: the TT kernel takes both operands as the kernels above left them (rows = batch)
-  // (the fp16-split option keeps its transposed-copy route: its kernel is k-contiguous by construction)
-  // each weight's two products (prediction loss, gradient penalty) share one slice sum: the first defers, the second accumulates
-  const bool pair = c.grad_penalty_scale != 0.0f;
+  // ---- 4. gradient penalty on the motion rows (on the side stream when forked; else in line after section 3) ----
   int def_w1 = 0, def_w2 = 0;
   auto tt = [&](const float* A, int64_t lda, int Mo, const float* W, int64_t ldw, int No, int64_t Kr, float* C, int64_t ldc, int acc,
                 float* sp, int* defer) -> int {
     return f16 ? kShapeNotSupported : gemm_tt(st, A, lda, Mo, W, ldw, No, Kr, C, ldc, acc, sp, pair ? defer : nullptr);
   };
-  rc = tt(dH2, H2n, H2n, H1, H1n, H1n, M, gW2, H1n, 0, split, &def_w2);       // gW2 = dH2^T H1
-  if (rc == kShapeNotSupported) {
-    transpose(st, dH2, M, H2n, H2n, dH2T, Mp, H2n);
-    transpose(st, H1, M, H1n, H1n, H1T, Mp, H1n);
-    rc = nt(dH2T, Mp, H2n, H1T, (int)Mp, H1n, gW2, H1n, nullptr, 0, 0, split);
-  }
-  if (rc != AMP_OK) return rc;
-  rc = tt(dH1, H1n, H1n, Xs, kN, kN, M, gW1, kN, 0, split1, &def_w1);          // gW1 = dH1^T Xs (+ gb1 in column ones_col)
-  if (rc == kShapeNotSupported) {
-    transpose(st, dH1, M, H1n, H1n, dH1T, Mp, H1n);
-    transpose(st, Xs, M, k1p, kN, XsT, Mp, kN);
-    rc = nt(dH1T, Mp, H1n, XsT, (int)Mp, kN, gW1, kN, nullptr, 0, 0, split);
-  }
-  if (rc != AMP_OK) return rc;
-
-  // ---- 4. gradient penalty on the motion rows ------------------------------------------------------------------
-  if (c.grad_penalty_scale != 0.0f) {
+  const int64_t n_w2 = (int64_t)H2n * H1n, n_w1 = (int64_t)H1n * kN;
+  auto penalty = [&]() -> int {
+    hipStream_t s_ = side;
+    float* part_ = fork ? part_side : part;
     const float* H1m = H1 + 2 * B * H1n;
     const float* H2m = H2 + 2 * B * H2n;
-    a2_kernel<<<blocks(B * H2n), kBlock, 0, st>>>(p.w3, H2m, B, H2n, a2);
-    rc = nt(a2, H2n, B, t->w2t, H2n, H1n, a1, H1n, H1m, H1n, 0);        // a1 = (a2 W2) * m1
-    if (rc != AMP_OK) return rc;
-    rc = nt(a1, H1n, B, t->w1t, H1n, kN, g, kN, nullptr, 0, 0);         // g = a1 W1      [B, kN]
-    if (rc != AMP_OK) return rc;
+    int r;
+    a2_kernel<<<blocks(B * H2n), kBlock, 0, s_>>>(p.w3, H2m, B, H2n, a2);
+    r = nt_on(s_, a2, H2n, B, t->w2t, H2n, H1n, a1, H1n, H1m, H1n, 0);        // a1 = (a2 W2) * m1
+    if (r != AMP_OK) return r;
+    r = nt_on(s_, a1, H1n, B, t->w1t, H1n, kN, g, kN, nullptr, 0, 0);         // g = a1 W1      [B, kN]
+    if (r != AMP_OK) return r;
     // loss[1] = gp_scale * mean_rows |g|^2 ;  g <- dL/dg = (2 gp_scale loss_scale / B) g
-    sumsq(g, B, p.in_dim, kN, 2.0f * c.grad_penalty_scale * c.loss_scale / (float)B, 1, c.grad_penalty_scale / (float)B, 1, 0);
-    rc = tt(a1, H1n, H1n, g, kN, kN, B, gW1, kN, 1, split1, &def_w1);        // gW1 += a1^T dg
-    if (rc == kShapeNotSupported) {
-      transpose(st, a1, B, H1n, H1n, a1T, Bp, H1n);
-      transpose(st, g, B, kN, kN, dgT, Bp, kN);
-      rc = nt(a1T, Bp, H1n, dgT, (int)Bp, kN, gW1, kN, nullptr, 0, 1, split);
+    sumsq(s_, part_, g, B, p.in_dim, kN, 2.0f * c.grad_penalty_scale * c.loss_scale / (float)B, 1, c.grad_penalty_scale / (float)B, 1, 0);
+    if (fork) {
+      int n = 0;
+      r = gemm_tt(s_, a1, H1n, H1n, g, kN, kN, B, nullptr, kN, 0, split1 + sl_w1[0] * n_w1, nullptr, &n);   // gW1's penalty slices
+    } else {
+      r = tt(a1, H1n, H1n, g, kN, kN, B, gW1, kN, 1, split1, &def_w1);        // gW1 += a1^T dg
+      if (r == kShapeNotSupported) {
+        transpose(st, a1, B, H1n, H1n, a1T, Bp, H1n);
+        transpose(st, g, B, kN, kN, dgT, Bp, kN);
+        r = nt(a1T, Bp, H1n, dgT, (int)Bp, kN, gW1, kN, nullptr, 0, 1, split);
+      }
     }
-    if (rc != AMP_OK) return rc;
-    rc = nt(g, kN, B, p.w1p, k1p, H1n, e1, H1n, H1m, H1n, 0);           // e1 = (dg W1^T) * m1   (K = k1p <= kN)
-    if (rc != AMP_OK) return rc;
-    rc = tt(a2, H2n, H2n, e1, H1n, H1n, B, gW2, H1n, 1, split, &def_w2);    // gW2 += a2^T e1
-    if (rc == kShapeNotSupported) {
-      transpose(st, a2, B, H2n, H2n, a2T, Bp, H2n);
-      transpose(st, e1, B, H1n, H1n, e1T, Bp, H1n);
-      rc = nt(a2T, Bp, H2n, e1T, (int)Bp, H1n, gW2, H1n, nullptr, 0, 1, split);
+    if (r != AMP_OK) return r;
+    r = nt_on(s_, g, kN, B, p.w1p, k1p, H1n, e1, H1n, H1m, H1n, 0);           // e1 = (dg W1^T) * m1   (K = k1p <= kN)
+    if (r != AMP_OK) return r;
+    if (fork) {
+      int n = 0;
+      r = gemm_tt(s_, a2, H2n, H2n, e1, H1n, H1n, B, nullptr, H1n, 0, split + sl_w2[0] * n_w2, nullptr, &n);  // gW2's penalty slices
+    } else {
+      r = tt(a2, H2n, H2n, e1, H1n, H1n, B, gW2, H1n, 1, split, &def_w2);    // gW2 += a2^T e1
+      if (r == kShapeNotSupported) {
+        transpose(st, a2, B, H2n, H2n, a2T, Bp, H2n);
+        transpose(st, e1, B, H1n, H1n, e1T, Bp, H1n);
+        r = nt(a2T, Bp, H2n, e1T, (int)Bp, H1n, gW2, H1n, nullptr, 0, 1, split);
+      }
     }
+    if (r != AMP_OK) return r;
+    r = nt_on(s_, e1, H1n, B, p.w2, H1n, H2n, da2, H2n, nullptr, 0, 0);       // da2 = e1 W2^T
+    if (r != AMP_OK) return r;
+    // gw3 += colsum(m2 * da2): the partial sums here, the accumulation into gw3 after the join when forked
+    colsum_part_kernel<<<dim3((H2n + 63) / 64, kChunks), kBlock, 0, s_>>>(da2, B, H2n, H2n, nullptr, H2m, H2n, part_);
+    if (!fork) colsum_final_kernel<<<(H2n + kBlock - 1) / kBlock, kBlock, 0, s_>>>(part_, H2n, gw3, 1);
+    return launch_status("colsum_part_kernel");
+  };
+  if (fork) {
+    AMP_HIP(hipStreamWaitEvent(side, t->ev[2], 0));
+    // advance the device-side state here (the scaler's merge, which reads the count, is behind ev[2]; Adam, which reads the bias
+    // corrections, is behind the join): off the step's critical path
+    train_state_kernel<<<1, 1, 0, side>>>(t->state, c.update_scaler ? 3.0 * (double)B : 0.0, (double)c.beta1, (double)c.beta2);
+    if (scaler_to_handle) {   // the handle's copy of the statistics (read by inference only, which is behind the join)
+      rc = amp_disc_set_scaler(t->disc, t->mean64, t->var64, c.scaler_epsilon, c.scaler_clip, (amp_stream_t)side);
+      if (rc != AMP_OK) return rc;
+    }
+    rc = penalty();
     if (rc != AMP_OK) return rc;
-    rc = nt(e1, H1n, B, p.w2, H1n, H2n, da2, H2n, nullptr, 0, 0);       // da2 = e1 W2^T
-    if (rc != AMP_OK) return rc;
-    colsum(da2, B, H2n, H2n, nullptr, H2m, H2n, gw3, 1);  // gw3 += colsum(m2 * da2)
+    AMP_HIP(hipEventRecord(t->ev[3], side));
+  }
+
+  // ---- 3. backward of the prediction loss ----------------------------------------------------------------------
+  // dH2 = dlogit (x) w3 * (H2 > 0), gw3 = H2^T dlogit, gb2 = colsum(dH2), gb3 = sum(dlogit): one pass over H2
+  dh2_colsum_kernel<<<dim3((H2n + 63) / 64, kChunks), kBlock, 0, st>>>(dlogit, p.w3, H2, M, H2n, dH2, part);
+  dh2_colsum_final_kernel<<<(H2n + kBlock - 1) / kBlock, kBlock, 0, st>>>(part, H2n, gw3, gb2, gb3);
+  if (fork) {
+    AMP_HIP(hipStreamWaitEvent(st, t->ev[1], 0));
   } else {
-    AMP_HIP(hipMemsetAsync(loss + 1, 0, sizeof(float), st));
+    transpose(st, p.w2, H2n, H1n, H1n, t->w2t, H2n, H1n);               // W2^T [h1, h2]
+    transpose(st, p.w1p, H1n, k1p, k1p, t->w1t, H1n, kN);               // W1^T [kN, h1] (zero rows >= k1p)
+  }
+  rc = nt(dH2, H2n, M, t->w2t, H2n, H1n, dH1, H1n, H1, H1n, 0);   // dH1 = (dH2 W2) * (H1 > 0)
+  if (rc != AMP_OK) return rc;
+  if (ones_col < 0) colsum(dH1, M, H1n, H1n, nullptr, nullptr, 0, gb1, 0);
+  // the weight gradients reduce over the batch: the TT kernel takes both operands as the kernels above left them (rows = batch)
+  // (the fp16-split option keeps its transposed-copy route: its kernel is k-contiguous by construction)
+  // each weight's two products (prediction loss, gradient penalty) share one slice sum: in line the first defers and the second
+  // accumulates into its slices; forked, the two write slice regions of their own and one sum follows the join
+  if (fork) {
+    int n = 0;
+    rc = gemm_tt(st, dH2, H2n, H2n, H1, H1n, H1n, M, nullptr, H1n, 0, split, nullptr, &n);        // gW2 = dH2^T H1
+    if (rc != AMP_OK) return rc;
+    rc = gemm_tt(st, dH1, H1n, H1n, Xs, kN, kN, M, nullptr, kN, 0, split1, nullptr, &n);          // gW1 = dH1^T Xs (+ gb1 in column ones_col)
+    if (rc != AMP_OK) return rc;
+    AMP_HIP(hipStreamWaitEvent(st, t->ev[3], 0));   // join; Adam sums the slices and the penalty's w3 column partials itself
+  } else {
+    rc = tt(dH2, H2n, H2n, H1, H1n, H1n, M, gW2, H1n, 0, split, &def_w2);       // gW2 = dH2^T H1
+    if (rc == kShapeNotSupported) {
+      transpose(st, dH2, M, H2n, H2n, dH2T, Mp, H2n);
+      transpose(st, H1, M, H1n, H1n, H1T, Mp, H1n);
+      rc = nt(dH2T, Mp, H2n, H1T, (int)Mp, H1n, gW2, H1n, nullptr, 0, 0, split);
+    }
+    if (rc != AMP_OK) return rc;
+    rc = tt(dH1, H1n, H1n, Xs, kN, kN, M, gW1, kN, 0, split1, &def_w1);          // gW1 = dH1^T Xs (+ gb1 in column ones_col)
+    if (rc == kShapeNotSupported) {
+      transpose(st, dH1, M, H1n, H1n, dH1T, Mp, H1n);
+      transpose(st, Xs, M, k1p, kN, XsT, Mp, kN);
+      rc = nt(dH1T, Mp, H1n, XsT, (int)Mp, kN, gW1, kN, nullptr, 0, 0, split);
+    }
+    if (rc != AMP_OK) return rc;
+    if (pair) {
+      rc = penalty();
+      if (rc != AMP_OK) return rc;
+    } else {
+      AMP_HIP(hipMemsetAsync(loss + 1, 0, sizeof(float), st));
+    }
   }
 
   // ---- 5 + 6. Adam; the regularisers' values for the report come out of the same pass over the parameters (their gradients
   //              are folded into the update) ------------------------------------------------------------------------
   // advance the device-side state: scaler count += the batches merged above, Adam step += 1, bias corrections of this step
-  train_state_kernel<<<1, 1, 0, st>>>(t->state, c.update_scaler ? 3.0 * (double)B : 0.0, (double)c.beta1, (double)c.beta2);
+  if (!fork) train_state_kernel<<<1, 1, 0, st>>>(t->state, c.update_scaler ? 3.0 * (double)B : 0.0, (double)c.beta1, (double)c.beta2);
   const float wd2 = 2.0f * c.loss_scale * c.weight_decay_scale, lr2 = 2.0f * c.loss_scale * c.logit_reg_scale;
   const float lr = c.apply_update ? c.learning_rate : 0.0f;
   {
@@ -1098,7 +1231,13 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
     float* ps[6] = {p.w1p, p.b1, p.w2, p.b2, p.w3, p.b3};
     // b1's gradient: gb1, or column ones_col of gW1 (one element per row of gW1)
     const bool col = ones_col >= 0;
-    const float* gs[6] = {gW1, col ? gW1 + ones_col : gb1, gW2, gb2, gw3, gb3};
+    // forked: W1 / W2 (and b1 in W1's column of ones) are still k-slices in `split1` / `split`
+    const float* gw1_src = fork ? split1 : gW1;
+    const float* gs[6] = {gw1_src, col ? gw1_src + ones_col : gb1, fork ? split : gW2, gb2, gw3, gb3};
+    const int nsl[6] = {fork ? sl_w1[0] + sl_w1[1] : 1, (fork && col) ? sl_w1[0] + sl_w1[1] : 1, fork ? sl_w2[0] + sl_w2[1] : 1, 1, 1, 1};
+    const int64_t sst[6] = {n_w1, n_w1, n_w2, 0, 0, 0};
+    a.colpart = fork ? part_side : nullptr;
+    a.colpart_chunks = kChunks;
     const int64_t ldp[6] = {k1p, col ? 1 : H1n, H1n, H2n, H2n, 1}, ldg[6] = {kN, col ? kN : H1n, H1n, H2n, H2n, 1};
     const int64_t rows_[6] = {H1n, col ? H1n : 1, H2n, 1, 1, 1};
     const int cols_[6] = {p.in_dim, col ? 1 : H1n, H1n, H2n, H2n, 1};
@@ -1107,14 +1246,14 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
     for (int k = 0; k < 6; ++k) {
       a.p[k] = ps[k]; a.g[k] = gs[k]; a.m[k] = t->mom[k]; a.v[k] = t->vel[k];
       a.ld_p[k] = ldp[k]; a.ld_g[k] = ldg[k]; a.cols[k] = cols_[k]; a.reg2[k] = reg[k];
+      a.slices[k] = nsl[k]; a.slice_stride[k] = sst[k];
       a.start[k + 1] = a.start[k] + rows_[k] * cols_[k];
     }
     const unsigned nb = blocks(a.start[6]);
     AMP_REQUIRE((int64_t)3 * nb <= (int64_t)3 * kChunks * 1024 + 1024, "amp_disc_train_step: too many Adam blocks for the partials buffer");
     adam_multi_kernel<<<nb, kBlock, 0, st>>>(a, lr, c.beta1, c.beta2, c.adam_epsilon, t->state, grads_dev, part);
     reg_final_kernel<<<1, kFinalBlock, 0, st>>>(part, (int)nb, c.logit_reg_scale, c.weight_decay_scale, c.loss_scale, bce_part, (int)n_bce,
-                                        (float)(2 * B), (float)B, loss);
-    if (loss_dev) AMP_HIP(hipMemcpyAsync(loss_dev, loss, 5 * sizeof(float), hipMemcpyDeviceToDevice, st));
+                                        (float)(2 * B), (float)B, loss, loss_dev);
   }
   rc = launch_status("adam_multi_kernel");
   if (rc != AMP_OK) return rc;

@@ -188,3 +188,43 @@ def test_deferred_refresh_gives_the_same_discriminator():
         outs.append(disc.style_reward(x, want_logits=True))
     assert torch.equal(outs[0]["logits"], outs[1]["logits"]) and torch.equal(outs[0]["style"], outs[1]["style"])
     assert not torch.equal(outs[0]["style"], before)
+
+
+@pytest.mark.parametrize("in_dim,B", [(166, 4096), (830, 1024)])
+def test_forked_penalty_chain_equals_the_in_line_step(in_dim, B, monkeypatch):
+    """The gradient-penalty chain runs on the trainer's side stream beside the prediction loss's backward (fork / join through
+    events).  Against the same step kept on one stream (AMP_TRAIN_FORK=0): loss terms equal, every gradient within 2e-6 of its
+    tensor's scale (the two weight-gradient products of a weight are summed slice after slice instead of pairwise); and the
+    forked step is deterministic -- two identical trainers stay bit-identical over five updating steps (a race between the two
+    streams would show here)."""
+    from humanoid_amp_amd.engine import AmpDiscriminator, AmpDiscriminatorTrainer
+
+    w = odisc.make_weights(in_dim, seed=5)
+    p, r, m = (t.cuda() for t in _batches(in_dim, B, seed=31))
+    outs = {}
+    for fork in ("1", "0"):
+        monkeypatch.setenv("AMP_TRAIN_FORK", fork)
+        disc = AmpDiscriminator([(a.cuda(), b.cuda()) for a, b in w], "cuda:0")
+        tr = AmpDiscriminatorTrainer(disc, batch_size=B, use_scaler=False, update_scaler=False, apply_update=False)
+        outs[fork] = tr.step(p, r, m, want_grads=True)
+        torch.cuda.synchronize()
+    for name in AmpDiscriminatorTrainer.LOSS_TERMS:
+        a, b = float(outs["1"][name]), float(outs["0"][name])
+        assert abs(a - b) <= 1e-6 * max(1.0, abs(b)), (name, a, b)
+    for i, (a, b) in enumerate(zip(_split(outs["1"]["grads"].cpu(), w), _split(outs["0"]["grads"].cpu(), w))):
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), i
+
+    monkeypatch.setenv("AMP_TRAIN_FORK", "1")
+    gen = torch.Generator().manual_seed(8)
+    batches = [[(torch.randn(B, in_dim, generator=gen) * (1.0 + 0.3 * k)).cuda() for k in range(3)] for _ in range(5)]
+    trained = []
+    for _ in range(2):
+        disc = AmpDiscriminator([(a.cuda(), b.cuda()) for a, b in w], "cuda:0")
+        tr = AmpDiscriminatorTrainer(disc, batch_size=B, learning_rate=1e-3)
+        losses = [tr.step(*b) for b in batches]
+        trained.append((tr.weights(), [{k: v.clone() for k, v in l.items() if k in AmpDiscriminatorTrainer.LOSS_TERMS} for l in losses]))
+    for (wa, ba), (wb, bb) in zip(trained[0][0], trained[1][0]):
+        assert torch.equal(wa, wb) and torch.equal(ba, bb)
+    for la, lb in zip(trained[0][1], trained[1][1]):
+        for k in la:
+            assert torch.equal(la[k], lb[k]), k
