@@ -1,7 +1,7 @@
 """Per-workgroup phase stamps of the fused env-step + expert launch (diagnostic build of the engine: env_step.hip compiled with
 -DAMP_ENV_TIMELINE; the product library carries no stamp).  Build here, run on the GPU box:
    tools/build_variant.sh env_tl env_step.hip -DAMP_ENV_TIMELINE
-   gpurun -- 'cp tools/bin/libamp_env_tl.so humanoid_amp_amd/csrc/libamp_engine.so && python tools/env_timeline.py [envs]'"""
+   gpurun -- 'cp tools/bin/libamp_env_tl.so humanoid_amp_amd/csrc/libamp_engine.so && python tools/env_timeline.py [envs] [workload]'"""
 import ctypes as C
 import sys
 
@@ -13,8 +13,9 @@ from humanoid_amp_amd import _native as nat  # noqa: E402
 from humanoid_amp_amd.workloads import WORKLOADS, HotPath  # noqa: E402
 
 envs = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+workload = sys.argv[2] if len(sys.argv) > 2 else "g1_walk"
 lib = nat.load()
-hot = HotPath(WORKLOADS["g1_walk"], envs, "cuda:0", seed=1)
+hot = HotPath(WORKLOADS[workload], envs, "cuda:0", seed=1)
 for _ in range(8):
     hot.step()
 torch.cuda.synchronize()
