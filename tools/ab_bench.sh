@@ -13,8 +13,9 @@ for rep in 1 2; do
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 k = d["kernel_us_per_step"]
-print(f"{sys.argv[2]:28s} {d['ms_per_step']*1e3:7.1f} us/step  env {k['env_step_reference_kernel']:6.1f}  L1 {k['disc_gemm_f16_dma_kernel<0>']:6.1f}  "
-      f"L2 {k['disc_gemm_f16_dma_kernel<1>']:6.1f}  tail {k['step_tail_kernel']:4.1f} | 8192: {d['envs_8192']['ms_per_step']*1e3:5.1f}  4096: {d['envs_4096']['ms_per_step']*1e3:5.1f}")
+gemm = "  ".join(f"{n.replace('disc_', '').replace('_kernel', '')} {v:6.1f}" for n, v in k.items() if n.startswith("disc_"))
+print(f"{sys.argv[2]:28s} {d['ms_per_step']*1e3:7.1f} us/step  env {k['env_step_reference_kernel']:6.1f}  {gemm}  "
+      f"tail {k['step_tail_kernel']:4.1f} | 8192: {d['envs_8192']['ms_per_step']*1e3:5.1f}  4096: {d['envs_4096']['ms_per_step']*1e3:5.1f}")
 PY
   done
 done
