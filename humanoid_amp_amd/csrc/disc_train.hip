@@ -293,10 +293,26 @@ __global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamSegs a, float lr
   if (s == 4) sq[2] = pv * pv;
   const float* gp = a.g[s] + r * a.ld_g[s] + c;
   float gsum = gp[0];
-  for (int k = 1; k < a.slices[s]; ++k) gsum += gp[(int64_t)k * a.slice_stride[s]];
+  {  // the other slices, in slice order, sixteen loads in flight per trip (a wave's life in this kernel is a chain of memory round
+     // trips: one dependent load per slice made it 35 us); a slot past the last slice adds +0.0f
+    const int ns = a.slices[s];
+    const int64_t ss = a.slice_stride[s];
+    for (int k = 1; k < ns; k += 16) {
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = k + j < ns ? gp[(int64_t)(k + j) * ss] : 0.0f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) gsum += v[j];
+    }
+  }
   if (s == 4 && a.colpart != nullptr) {
+    // kChunks (a constant: the loop unrolls, all loads in flight -- as a dynamic-length loop of dependent trips these two
+    // workgroups were the kernel's whole 33 us); colpart_chunks == kChunks by construction
     float cs = 0.0f;
-    for (int ch = 0; ch < a.colpart_chunks; ++ch) cs += a.colpart[(int64_t)ch * a.cols[4] + c];
+    const float* cp = a.colpart + c;
+    const int nc = a.cols[4];
+#pragma unroll
+    for (int ch = 0; ch < kChunks; ++ch) cs += cp[ch * nc];
     gsum = gsum + cs;
   }
   const float gr = gsum + a.reg2[s] * pv;
@@ -902,7 +918,9 @@ int amp_disc_trainer_create(AmpDisc* disc, const AmpDiscTrainCfg* cfg, const dou
   t->ws_floats += (int64_t)16 * p.h2 * p.h1 + (int64_t)16 * p.h1 * t->kN + (int64_t)3 * kChunks * 1024 + 1024 + 64;  // the side stream's slices + partials
   if (e == hipSuccess) e = hipMalloc(&t->ws, sizeof(float) * t->ws_floats);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking);
-  for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&t->ev[i], hipEventDisableTiming);
+  // device-side ordering between two streams of this device only: no timing, no system-scope fence at the record (that fence
+  // delayed the kernel behind a record by ~8 us in the rocprofv3 timeline of the step)
+  for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&t->ev[i], hipEventDisableTiming | hipEventDisableSystemFence);
   if (e == hipSuccess && cfg->gemm_f16x3) {
     // fp16-split GEMM path: planes of the largest operand ([3B (padded), max(h1, h2)] or its transpose), twice
     const int64_t rows = up(Mp, 32), cols = up(std::max<int64_t>(std::max(p.h1, p.h2), up(t->kN, 32)), 32);
@@ -1053,6 +1071,16 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
     sl_w2[1] = q.slices;
   }
   hipStream_t side = fork ? t->side : st;
+  // whatever path leaves this function, the side stream has joined the caller's stream (an error return between fork and join
+  // would otherwise leave a stream capture of the step with unjoined work)
+  struct ForkGuard {
+    hipStream_t st, side; hipEvent_t ev; bool armed;
+    ~ForkGuard() {
+      if (!armed) return;
+      (void)hipEventRecord(ev, side);
+      (void)hipStreamWaitEvent(st, ev, 0);
+    }
+  } fork_guard{st, side, t->ev[3], fork};
   if (fork) {
     // the side stream starts with the two W^T copies (they only need last step's Adam), under the scaler passes
     AMP_HIP(hipEventRecord(t->ev[0], st));
@@ -1197,6 +1225,7 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
     rc = gemm_tt(st, dH1, H1n, H1n, Xs, kN, kN, M, nullptr, kN, 0, split1, nullptr, &n);          // gW1 = dH1^T Xs (+ gb1 in column ones_col)
     if (rc != AMP_OK) return rc;
     AMP_HIP(hipStreamWaitEvent(st, t->ev[3], 0));   // join; Adam sums the slices and the penalty's w3 column partials itself
+    fork_guard.armed = false;
   } else {
     rc = tt(dH2, H2n, H2n, H1, H1n, H1n, M, gW2, H1n, 0, split, &def_w2);       // gW2 = dH2^T H1
     if (rc == kShapeNotSupported) {
