@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # AMP_ENGINE_LIB: load another build of the SAME library instead of the in-tree one (A/B variants from tools/build_variant.sh:
 # diagnostic stamps, ablations) -- the in-tree product file is never overwritten by an experiment.  ABI and symbols are checked as usual.
 LIB_PATH = os.environ.get("AMP_ENGINE_LIB") or os.path.join(_HERE, "csrc", "libamp_engine.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 AMP_DISC_F16X3, AMP_DISC_FP32 = 0, 1
 AMP_DISC_INPUT_F32_ROWS, AMP_DISC_INPUT_F16_BLOCKS = 0, 1
@@ -49,6 +49,7 @@ class AmpResetArgs(C.Structure):
         ("episode_length", C.c_void_p), ("last_actions", C.c_void_p), ("just_reset", C.c_void_p), ("n_actions", C.c_int32),
         ("reserved2", C.c_int32), ("step_dev", C.c_void_p),
         ("default_root_state", C.c_void_p), ("default_joint_pos", C.c_void_p), ("default_joint_vel", C.c_void_p),
+        ("step_dev_out", C.c_void_p),
     ]
 
 
@@ -60,7 +61,7 @@ class AmpCompactArgs(C.Structure):
 class AmpPrePhysicsArgs(C.Structure):
     _fields_ = [("actions_in", C.c_void_p), ("actions", C.c_void_p), ("last_actions", C.c_void_p), ("target", C.c_void_p),
                 ("offset", C.c_void_p), ("scale", C.c_void_p), ("num_envs", C.c_int64), ("n_actions", C.c_int32), ("reserved", C.c_int32),
-                ("episode_length", C.c_void_p)]
+                ("episode_length", C.c_void_p), ("step_in", C.c_void_p), ("step_out", C.c_void_p)]
 
 
 class AmpRewardLogArgs(C.Structure):

@@ -59,6 +59,8 @@ __global__ __launch_bounds__(kBlock) void command_kernel(AmpCommandArgs a, int64
 __global__ __launch_bounds__(kBlock) void pre_physics_kernel(AmpPrePhysicsArgs a, AmpCommandArgs c, unsigned copy_blocks, int vec,
                                                              int has_tick) {
   typedef float pf4 __attribute__((ext_vector_type(4)));
+  // the device-side step counter for the launches behind this one (the tick below draws with *step_in, a different word)
+  if (a.step_out && blockIdx.x == 0 && threadIdx.x == 0) *a.step_out = *a.step_in + 1ull;
   if (blockIdx.x >= copy_blocks) {  // the per-env workgroups: episode-length increment, command timers
     const int64_t env = (int64_t)(blockIdx.x - copy_blocks) * kBlock + threadIdx.x;
     if (env >= a.num_envs) return;
@@ -180,6 +182,9 @@ int amp_pre_physics_step(const AmpPrePhysicsArgs* a, const AmpCommandArgs* tick,
   if (a->num_envs == 0) return AMP_OK;
   AMP_REQUIRE(a->actions_in, "amp_pre_physics_step: actions_in is null");
   AMP_REQUIRE(!tick || (tick->command && tick->time_left), "amp_pre_physics_step: null command buffer");
+  AMP_REQUIRE((a->step_in == nullptr) == (a->step_out == nullptr) && (!a->step_out || a->step_out != a->step_in),
+              "amp_pre_physics_step: step_in / step_out come together and are different words");
+  AMP_REQUIRE(!a->step_out || !tick || tick->step_dev != a->step_out, "amp_pre_physics_step: the tick must not read the word this launch writes");
   AMP_REQUIRE(!tick || !(tick->vel_span > 0.0f) || tick->t_span >= 0.0f, "amp_pre_physics_step: negative resampling-time span");
   hipStream_t st = (hipStream_t)stream;
   const int64_t total = a->num_envs * a->n_actions;

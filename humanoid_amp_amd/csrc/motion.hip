@@ -414,6 +414,9 @@ __global__ __launch_bounds__(kBlock) void reset_compact_apply_kernel(MotionView 
   __shared__ int64_t s_clip[kBlock], s_env[kBlock], s_slot[kBlock];
   __shared__ int s_wcnt[kBlock / kWave];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the step counter's hand-back inside a captured step (AmpPrePhysicsArgs.step_in / step_out): nothing in this launch reads
+  // *step_dev_out, and *step_dev is only read
+  if (a.step_dev_out && blockIdx.x == 0 && tid == 0) *a.step_dev_out = *a.step_dev;
   int64_t env;
   const int64_t slot = compact_rank_body((int64_t)blockIdx.x, c.mask, c.tile_counts, c.num_envs, n_tiles, sub, n_counts, c.ids,
                                          c.count, env);
@@ -694,6 +697,7 @@ int amp_reset_apply(const AmpMotion* h, const AmpResetArgs* a, amp_stream_t stre
   AMP_REQUIRE(a->max_n >= 0 && a->K >= 1, "amp_reset_apply: need max_n >= 0 and K >= 1");
   if (a->max_n == 0) return AMP_OK;
   AMP_REQUIRE(a->mode == AMP_RESET_REFERENCE, "amp_reset_apply: only the reference-motion reset (mode 0); the default strategy is served by amp_reset_compact_apply");
+  AMP_REQUIRE(!a->step_dev_out, "amp_reset_apply: step_dev_out is served by amp_reset_compact_apply only");
   AMP_REQUIRE(a->env_ids && a->count && a->motion_ids && a->motion_times, "amp_reset_apply: null buffer");
   AMP_REQUIRE(!a->last_actions || a->n_actions >= 1, "amp_reset_apply: last_actions needs n_actions >= 1");
   hipStream_t st = (hipStream_t)stream;
@@ -740,6 +744,8 @@ int amp_reset_compact_apply(const AmpMotion* h, const AmpCompactArgs* c, const A
   AMP_REQUIRE(a->env_ids == c->ids && a->count == c->count && a->max_n >= N,
               "amp_reset_compact_apply: the reset arguments must consume the compaction's ids / count (max_n >= num_envs)");
   AMP_REQUIRE(a->mode == AMP_RESET_REFERENCE || a->mode == AMP_RESET_DEFAULT, "amp_reset_compact_apply: unknown reset mode %d", a->mode);
+  AMP_REQUIRE(!a->step_dev_out || (a->step_dev && a->step_dev_out != a->step_dev),
+              "amp_reset_compact_apply: step_dev_out needs step_dev, and a different word");
   if (a->mode == AMP_RESET_DEFAULT) {
     AMP_REQUIRE(a->default_root_state && a->default_joint_pos && a->default_joint_vel,
                 "amp_reset_compact_apply: AMP_RESET_DEFAULT needs default_root_state / default_joint_pos / default_joint_vel");

@@ -181,11 +181,13 @@ class _AmpEnv(DirectRLEnv):
             except Exception:
                 pass
 
-    def _step_args(self):
+    def _step_args(self, behind: bool = False):
         """(step, step_dev) of the counter-based draws: the host counter, or -- once ``capture_step`` made the step a
         hipGraph -- its device-side mirror (the graph increments it; a baked host value would repeat every replay)."""
         if self._step_dev is not None:
-            return 0, self._step_dev.data_ptr()
+            # the word the launch reads: [0] in front of DirectRLEnv.step's `common_step_counter += 1` (the pre-physics tick),
+            # [1] = [0] + 1 behind it (the reset), written by the pre-physics launch; the reset launch copies [1] back to [0]
+            return 0, self._step_dev.data_ptr() + (8 if behind and getattr(self, "_step_dev_in_launches", False) else 0)
         return self.common_step_counter & (2**64 - 1), None
 
     def _after_replay(self):
@@ -214,6 +216,12 @@ class _AmpEnv(DirectRLEnv):
             p = self._pre_args = (a, nat.load().amp_pre_physics_step)
         if p[0].episode_length != self.episode_length_buf.data_ptr():  # the buffer was re-assigned: follow it
             p[0].episode_length = self.episode_length_buf.data_ptr()
+        # a captured step keeps its step counter on the device: with the one-launch device reset behind it, this launch and the
+        # reset launch advance it themselves (AmpPrePhysicsArgs.step_in / step_out, AmpResetArgs.step_dev_out)
+        fold = self._step_dev is not None and getattr(self, "device_reset", False)
+        self._step_dev_in_launches = fold
+        p[0].step_in = self._step_dev.data_ptr() if fold else None
+        p[0].step_out = self._step_dev.data_ptr() + 8 if fold else None
         p[0].actions_in = actions.data_ptr()
         with torch.cuda.device(self.device):
             nat.check(p[1](C.byref(p[0]), C.byref(tick) if tick is not None else None, nat.stream_ptr()), "amp_pre_physics_step")
@@ -308,7 +316,8 @@ class _AmpEnv(DirectRLEnv):
             self._reset_args = (key, c, a, cmd, nat.load().amp_reset_compact_apply, self._motion_loader._need_handle())
         _, c, a, cmd, fn, handle = self._reset_args
         a.seed = self._reset_seed & (2**64 - 1)
-        a.step, a.step_dev = self._step_args()
+        a.step, a.step_dev = self._step_args(behind=True)
+        a.step_dev_out = self._step_dev.data_ptr() if getattr(self, "_step_dev_in_launches", False) and a.step_dev else None
         if cmd is not None:
             cmd.seed, cmd.step, cmd.step_dev = a.seed, a.step, a.step_dev
         lg, means = None, self._pending_means

@@ -110,7 +110,8 @@ class DirectRLEnv:
             raise ValueError("capture_step needs device_reset=True (the host-driven reset reads the reset count back)")
         n_act = int(self.cfg.action_space)
         self._graph_actions = torch.zeros((self.num_envs, n_act), dtype=torch.float32, device=self.device)
-        self._step_dev = torch.full((1,), self.common_step_counter, dtype=torch.int64, device=self.device)
+        # [0] the counter the step starts with, [1] the word a task's launches hand it over through (see _step_dev_in_launches)
+        self._step_dev = torch.full((2,), self.common_step_counter, dtype=torch.int64, device=self.device)
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
@@ -154,8 +155,8 @@ class DirectRLEnv:
         if not getattr(self, "_pre_physics_counts_steps", False):  # (tasks on the engine: done by the pre-physics launch)
             self.episode_length_buf += 1
         self.common_step_counter += 1
-        if self._step_dev is not None:
-            self._step_dev += 1
+        if self._step_dev is not None and not getattr(self, "_step_dev_in_launches", False):
+            self._step_dev[:1] += 1   # (tasks on the engine advance it inside their pre-physics and reset launches: no launch of its own)
         self.reset_terminated, self.reset_time_outs = self._get_dones()
         self.reset_buf = self._reset_buf()
         self.reward_buf = self._get_rewards()

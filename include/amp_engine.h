@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define AMP_ABI_VERSION 9
+#define AMP_ABI_VERSION 10
 
 typedef void* amp_stream_t; /* hipStream_t */
 typedef void* amp_event_t;  /* hipEvent_t  */
@@ -177,6 +177,9 @@ typedef struct {
   const float* default_root_state;  /* dev [num_envs, 13] */
   const float* default_joint_pos;   /* dev [num_envs, n_dof] */
   const float* default_joint_vel;   /* dev [num_envs, n_dof] */
+  /* optional (amp_reset_compact_apply only; needs step_dev): *step_dev_out = *step_dev, written by one thread -- the other half
+   * of AmpPrePhysicsArgs.step_in / step_out.  Must not alias step_dev. */
+  uint64_t* step_dev_out;
 } AmpResetArgs;
 #define AMP_RESET_REFERENCE 0
 #define AMP_RESET_DEFAULT 1
@@ -325,6 +328,13 @@ typedef struct {
   /* optional: DirectRLEnv.step's `self.episode_length_buf += 1` (Isaac Lab does it between the physics step and _get_dones;
    * nothing reads the buffer in between, so it may ride on this launch: one ATen launch fewer per env step) */
   int64_t* episode_length;   /* dev [num_envs] int64, or NULL */
+  /* optional: the device-side step counter's hand-over inside a captured env step (DirectRLEnv.step's
+   * `common_step_counter += 1` sits between this launch and the reset): *step_out = *step_in + 1, written by one thread.  The
+   * tick of THIS launch draws with *step_in (its AmpCommandArgs.step_dev); the reset launch reads *step_out as its step_dev and
+   * copies it back (AmpResetArgs.step_dev_out = step_in), so the next step starts one further -- no increment launch of its
+   * own in the graph.  step_in and step_out must be different words; both NULL = off. */
+  const uint64_t* step_in;
+  uint64_t* step_out;
 } AmpPrePhysicsArgs;
 int amp_pre_physics_step(const AmpPrePhysicsArgs* args, const AmpCommandArgs* tick, amp_stream_t stream);
 

@@ -210,6 +210,9 @@ def test_captured_step_equals_eager(task):
             assert torch.equal(getattr(eager.robot.data, k), getattr(graph.robot.data, k)), k
         n_reset += int((te | oe_t).sum())
     assert n_reset > 100
+    # the device-side step counter is advanced by the step's own launches (pre-physics hands c + 1 to the reset, the reset
+    # hands it back): no increment launch in the graph, and it stays the host counter's mirror
+    assert graph._step_dev_in_launches and int(graph._step_dev[0]) == graph.common_step_counter == eager.common_step_counter
 
 
 def test_scatter_rows_equals_index_assignment():
