@@ -217,18 +217,26 @@ __global__ __launch_bounds__(kBlock) void a2_kernel(const float* __restrict__ w3
   a2[e] = H2[e] > 0.0f ? w3[e % cols] : 0.0f;
 }
 
-// sum of squares of an [rows, cols] view (optionally scaling it in place by coef afterwards) -> per-block partials
+// sum of squares of an [rows, cols] view (optionally scaling it in place by coef afterwards) -> per-block partials.
+// A workgroup walks whole rows (row i of block b: b, b + grid, ...), its lanes the columns: no index division, and the four
+// loads of an unrolled trip are in flight together (the flat-index form -- a 64-bit division and one dependent load per element,
+// 52 elements per lane on 256 workgroups -- took 64 us on the [4096, 832] penalty gradient of K D = 830).
 __global__ __launch_bounds__(kBlock) void sumsq_part_kernel(float* __restrict__ x, int64_t rows, int cols, int64_t ld, float coef,
                                                             int scale_in_place, float* __restrict__ part) {
   __shared__ float red[kBlock];
   float s = 0.0f;
-  const int64_t n = rows * cols;
-  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (int64_t)gridDim.x * kBlock) {
-    const int64_t i = e / cols;
-    const int c = (int)(e - i * cols);
-    const float v = x[i * ld + c];
-    s += v * v;
-    if (scale_in_place) x[i * ld + c] = coef * v;
+  for (int64_t i = blockIdx.x; i < rows; i += gridDim.x) {
+    float* row = x + i * ld;
+    for (int c0 = threadIdx.x; c0 < cols; c0 += 4 * kBlock) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = c0 + j * kBlock < cols ? row[c0 + j * kBlock] : 0.0f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s += v[j] * v[j];
+        if (scale_in_place && c0 + j * kBlock < cols) row[c0 + j * kBlock] = coef * v[j];
+      }
+    }
   }
   red[threadIdx.x] = s;
   __syncthreads();
@@ -389,12 +397,23 @@ __global__ __launch_bounds__(kBlock) void scaler_part_kernel(const float* __rest
   const int64_t per = (rows + kChunks - 1) / kChunks;
   const int64_t lo = (int64_t)blockIdx.y * per, hi = lo + per < rows ? lo + per : rows;
   double s = 0.0, q = 0.0;
-  if (c < cols)
-    for (int64_t i = lo + p; i < hi; i += 4) {
-      const double v = (double)x[i * ld + c];
+  if (c < cols) {
+    // four rows' loads in flight per trip, summed in row order (one dependent load per trip made the kernel latency-bound)
+    const float* px = x + c;
+    int64_t i = lo + p;
+    for (; i + 12 < hi; i += 16) {
+      const float v0 = px[i * ld], v1 = px[(i + 4) * ld], v2 = px[(i + 8) * ld], v3 = px[(i + 12) * ld];
+      s += (double)v0; q += (double)v0 * (double)v0;
+      s += (double)v1; q += (double)v1 * (double)v1;
+      s += (double)v2; q += (double)v2 * (double)v2;
+      s += (double)v3; q += (double)v3 * (double)v3;
+    }
+    for (; i < hi; i += 4) {
+      const double v = (double)px[i * ld];
       s += v;
       q += v * v;
     }
+  }
   red[0][p][threadIdx.x & 63] = s;
   red[1][p][threadIdx.x & 63] = q;
   __syncthreads();
@@ -455,12 +474,23 @@ __global__ __launch_bounds__(kBlock) void scaler_part3_kernel(Batch3 b, int64_t 
   const int64_t per = (rows + kChunks - 1) / kChunks;
   const int64_t lo = (int64_t)blockIdx.y * per, hi = lo + per < rows ? lo + per : rows;
   double s = 0.0, q = 0.0;
-  if (c < cols)
-    for (int64_t i = lo + p; i < hi; i += 4) {
-      const double v = (double)x[i * ld + c];
+  if (c < cols) {
+    // four rows' loads in flight per trip, summed in row order (one dependent load per trip made the kernel latency-bound)
+    const float* px = x + c;
+    int64_t i = lo + p;
+    for (; i + 12 < hi; i += 16) {
+      const float v0 = px[i * ld], v1 = px[(i + 4) * ld], v2 = px[(i + 8) * ld], v3 = px[(i + 12) * ld];
+      s += (double)v0; q += (double)v0 * (double)v0;
+      s += (double)v1; q += (double)v1 * (double)v1;
+      s += (double)v2; q += (double)v2 * (double)v2;
+      s += (double)v3; q += (double)v3 * (double)v3;
+    }
+    for (; i < hi; i += 4) {
+      const double v = (double)px[i * ld];
       s += v;
       q += v * v;
     }
+  }
   red[0][p][threadIdx.x & 63] = s;
   red[1][p][threadIdx.x & 63] = q;
   __syncthreads();
@@ -482,15 +512,23 @@ __global__ __launch_bounds__(kBlock) void scaler_merge3_kernel(const double* __r
   }
   double m = mean[c], v = var[c];
   const double n = (double)rows;
+  // the three batches' sums first (independent of each other and of the merge below: their loads overlap), each in chunk order
+  double sg[3], qg[3];
+#pragma unroll
   for (int g = 0; g < 3; ++g) {
-    const double count = state->count + (double)g * n;
-    const double* pg = part + (int64_t)g * part_stride;
+    const double* pg = part + (int64_t)g * part_stride + (int64_t)c * 2;
     double s = 0.0, q = 0.0;
 #pragma unroll 16
-    for (int ch = 0; ch < kChunks; ++ch) {  // summed in chunk order; unrolled so that the loads are in flight together
-      s += pg[((int64_t)ch * cols + c) * 2 + 0];
-      q += pg[((int64_t)ch * cols + c) * 2 + 1];
+    for (int ch = 0; ch < kChunks; ++ch) {  // unrolled so that the loads are in flight together
+      s += pg[(int64_t)ch * cols * 2 + 0];
+      q += pg[(int64_t)ch * cols * 2 + 1];
     }
+    sg[g] = s; qg[g] = q;
+  }
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    const double count = state->count + (double)g * n;
+    const double s = sg[g], q = qg[g];
     const double bm = s / n;
     const double bv = (q - n * bm * bm) / (n - 1.0);
     const double total = count + n, delta = bm - m;
@@ -511,15 +549,17 @@ __global__ __launch_bounds__(kBlock) void scaler_merge3_kernel(const double* __r
 __global__ __launch_bounds__(kBlock) void scale_rows3_kernel(Batch3 b, int64_t row_stride, int64_t rows, int k, int pitch,
                                                              const float* __restrict__ mean, const float* __restrict__ den,
                                                              int vec_stride, float clip, float* __restrict__ xs, int ones_col) {
-  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (e >= rows * pitch) return;
+  // one element per lane (consecutive lanes = consecutive floats of a row: a quad per lane with one 16-B store was slower, 32 vs
+  // 23 us at K D = 830 -- the four 4-B loads of a lane are 16 B apart across the wave); 32-bit indices (rows * pitch < 2^31: host)
+  const uint32_t e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= (uint32_t)rows * (uint32_t)pitch) return;
   const int z = blockIdx.y;
   const float* __restrict__ x = b.x[z];
-  const int64_t m = e / pitch;
-  const int c = (int)(e - m * pitch);
+  const uint32_t m = e / (uint32_t)pitch;
+  const int c = (int)(e - m * (uint32_t)pitch);
   float v = 0.0f;
   if (c < k) {
-    v = x[m * row_stride + c];
+    v = x[(int64_t)m * row_stride + c];
     if (mean) {
       v = (v - mean[z * vec_stride + c]) / den[z * vec_stride + c];
       v = fminf(fmaxf(v, -clip), clip);
@@ -1023,7 +1063,7 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
   };
   auto sumsq = [&](hipStream_t s_, float* part_, float* x, int64_t rows_, int cols_, int64_t ld_, float coef, int in_place, float scale,
                    int slot, int accumulate) {
-    const int nb = 256;
+    const int nb = (int)std::min<int64_t>(rows_, 1024);
     sumsq_part_kernel<<<nb, kBlock, 0, s_>>>(x, rows_, cols_, ld_, coef, in_place, part_);
     scalar_final_kernel<<<1, 256, 0, s_>>>(part_, nb, scale, loss, slot, accumulate);
   };
@@ -1113,6 +1153,7 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
                                                                           den32w, vec_stride);
       if (c.use_scaler) { mean32 = mean32w; den32 = den32w; clip = c.scaler_clip; vstride = vec_stride; }
     }
+    AMP_REQUIRE(B * kN < (int64_t)1 << 31, "amp_disc_train_step: batch too large for the scaling pass's 32-bit indices");
     scale_rows3_kernel<<<dim3(blocks(B * kN), 3), kBlock, 0, st>>>(b3, row_stride, B, p.in_dim, kN, mean32, den32, vstride, clip, Xs,
                                                                    ones_col);
   }
