@@ -810,12 +810,17 @@ class AmpDiscriminatorUpdate:
     (``humanoid_amp_amd.distributed.ReplayAllGather``)."""
 
     def __init__(self, trainer: AmpDiscriminatorTrainer, replay: AmpReplayBuffer, motion_dataset: AmpReplayBuffer, *,
-                 learning_epochs: int = 6, mini_batches: int = 2, seed: int = 0, record_batches: bool = False):
+                 learning_epochs: int = 6, mini_batches: int = 2, seed: int = 0, record_batches: bool = False, prefetch: bool = True):
+        """``prefetch`` (default): the three batches of training step k + 1 (shuffle, row gather, two ring draws: ~45 us of
+        sort / gather launches) are produced on a side stream while step k trains, into two alternating sets of static
+        buffers; the same draws in the same order, so the rows are identical to the in-line flow (``prefetch=False``)."""
         self.trainer, self.replay, self.motion_dataset = trainer, replay, motion_dataset
         self.learning_epochs, self.mini_batches = int(learning_epochs), int(mini_batches)
         self.gen = torch.Generator(device=trainer.device).manual_seed(seed)
         self.record_batches = bool(record_batches)
         self.batches = []  # (policy, replay, motion) of every trainer step of the last update, when recording
+        self.prefetch = bool(prefetch)
+        self._side, self._bufs = None, None
 
     def update(self, rollout_amp_states: torch.Tensor):
         rows = rollout_amp_states.reshape(-1, rollout_amp_states.shape[-1])
@@ -826,6 +831,8 @@ class AmpDiscriminatorUpdate:
             raise nat.AmpEngineError("the motion dataset is empty: fill it with collect_reference rows first")
         losses, self.batches = [], []
         per = rows.shape[0] // self.mini_batches
+        if self.prefetch:
+            return self._update_prefetched(rows, per, bs)
         for _ in range(self.learning_epochs):
             perm = torch.randperm(rows.shape[0], generator=self.gen, device=rows.device)
             for mb in range(self.mini_batches):
@@ -835,7 +842,60 @@ class AmpDiscriminatorUpdate:
                 losses.append(self.trainer.step(policy, replay, motion)["loss"])
                 if self.record_batches:
                     self.batches.append((policy.clone(), replay.clone(), motion.clone()))
+        return self._finish(rows, losses)
+
+    def _finish(self, rows, losses):
         self.replay.add_samples(rows)
         if getattr(self.trainer, "defer_refresh", False):
             self.trainer.refresh()  # the rollouts that follow score with the trained weights
         return losses
+
+    def _update_prefetched(self, rows, per, bs):
+        """The same flow with the batches of step k + 1 produced on a side stream under step k.  Two static buffer sets:
+        the side stream refills a set only behind the training step that last read it (an event recorded on the main
+        stream), the main stream trains on a set only behind its refill (an event recorded on the side stream).  The
+        shuffles and the ring draws consume their generators / counters in the in-line order."""
+        dev = rows.device
+        main = torch.cuda.current_stream(dev)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        if self._bufs is None or self._bufs[0][0].shape != (bs, rows.shape[1]):
+            self._bufs = [[torch.empty((bs, rows.shape[1]), device=dev) for _ in range(3)] for _ in range(2)]
+        side, bufs = self._side, self._bufs
+        n = self.learning_epochs * self.mini_batches
+        ready, done = [None, None], [None, None]
+        have_replay = len(self.replay) > 0
+        state = {"perm": None}
+        side.wait_stream(main)  # the rollout rows (and whatever used the buffer sets before) are complete
+
+        def produce(k):
+            st, mb = k & 1, k % self.mini_batches
+            with torch.cuda.stream(side):
+                if done[st] is not None:
+                    side.wait_event(done[st])
+                if mb == 0:
+                    state["perm"] = torch.randperm(rows.shape[0], generator=self.gen, device=dev)
+                policy, replay, motion = bufs[st]
+                torch.index_select(rows, 0, state["perm"][mb * per: mb * per + bs], out=policy)
+                if have_replay:
+                    self.replay.sample(bs, out=replay)
+                else:
+                    replay.copy_(policy)
+                self.motion_dataset.sample(bs, out=motion)
+                ready[st] = torch.cuda.Event()
+                ready[st].record(side)
+
+        losses = []
+        produce(0)
+        for k in range(n):
+            if k + 1 < n:
+                produce(k + 1)
+            st = k & 1
+            main.wait_event(ready[st])
+            policy, replay, motion = bufs[st]
+            losses.append(self.trainer.step(policy, replay, motion)["loss"])
+            if self.record_batches:
+                self.batches.append((policy.clone(), replay.clone(), motion.clone()))
+            done[st] = torch.cuda.Event()
+            done[st].record(main)
+        return self._finish(rows, losses)

@@ -60,3 +60,37 @@ def test_update_feeds_the_trainer_what_the_oracle_flow_selects():
     disc.set_scaler(mean, var)
     out = disc.style_reward(x.cuda(), want_logits=True)
     assert float((out["logits"].cpu() - ref["logits"]).abs().max()) <= 1e-5
+
+
+def test_prefetched_update_equals_the_in_line_flow():
+    """AmpDiscriminatorUpdate(prefetch=True) produces the batches of step k + 1 on a side stream under step k, into two
+    alternating static buffer sets: over three updates (empty replay buffer first, then wrapped draws) every batch of every
+    step, every loss, the trained weights and the replay ring are bit-identical to the in-line flow."""
+    from humanoid_amp_amd.engine import AmpDiscriminator, AmpDiscriminatorTrainer, AmpDiscriminatorUpdate, AmpReplayBuffer
+
+    C, bs, epochs, mbs = 166, 512, 3, 2
+    w = odisc.make_weights(C, seed=4)
+    gen = torch.Generator().manual_seed(1)
+    expert = torch.randn(3000, C, generator=gen).cuda()
+    rollouts = [torch.randn(8, 256, C, generator=gen).cuda() for _ in range(3)]
+    runs = []
+    for prefetch in (False, True):
+        disc = AmpDiscriminator([(a.cuda(), b.cuda()) for a, b in w], "cuda:0")
+        trainer = AmpDiscriminatorTrainer(disc, batch_size=bs, defer_refresh=True)
+        replay, motion = AmpReplayBuffer(5000, C, "cuda:0", seed=5), AmpReplayBuffer(2500, C, "cuda:0", seed=6)
+        motion.add_samples(expert)
+        upd = AmpDiscriminatorUpdate(trainer, replay, motion, learning_epochs=epochs, mini_batches=mbs, seed=9, record_batches=True,
+                                     prefetch=prefetch)
+        batches, losses = [], []
+        for r in rollouts:
+            losses += [l.clone() for l in upd.update(r)]
+            batches += upd.batches
+        torch.cuda.synchronize()
+        runs.append((batches, losses, [t.clone() for pair in trainer.weights() for t in pair], replay.sample(4096), len(replay)))
+    (b0, l0, w0, r0, n0), (b1, l1, w1, r1, n1) = runs
+    assert len(b0) == len(b1) == 3 * epochs * mbs and n0 == n1
+    for (p0, q0, m0), (p1, q1, m1) in zip(b0, b1):
+        assert torch.equal(p0, p1) and torch.equal(q0, q1) and torch.equal(m0, m1)
+    assert all(torch.equal(a, b) for a, b in zip(l0, l1))
+    assert all(torch.equal(a, b) for a, b in zip(w0, w1))
+    assert torch.equal(r0, r1)
