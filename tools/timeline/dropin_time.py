@@ -1,4 +1,4 @@
-"""Drop-in env step, eager and captured: python tools/scratch/dropin_time.py"""
+"""Drop-in env step, eager and captured: python tools/timeline/dropin_time.py"""
 import sys, json
 import torch
 sys.path.insert(0, ".")

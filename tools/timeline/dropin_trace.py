@@ -1,4 +1,4 @@
-"""A few drop-in env steps for a rocprofv3 --kernel-trace timeline: python tools/scratch/dropin_trace.py [envs] [K] [graph]"""
+"""A few drop-in env steps for a rocprofv3 --kernel-trace timeline: python tools/timeline/dropin_trace.py [envs] [K] [graph]"""
 import contextlib, os, sys
 import torch
 sys.path.insert(0, ".")

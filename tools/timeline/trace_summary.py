@@ -1,4 +1,4 @@
-"""Kernel totals of a rocprofv3 kernel trace: python tools/scratch/trace_summary.py <kernel_trace.csv> [top]"""
+"""Kernel totals of a rocprofv3 kernel trace: python tools/timeline/trace_summary.py <kernel_trace.csv> [top]"""
 import csv, sys
 from collections import defaultdict
 tot, cnt = defaultdict(float), defaultdict(int)

@@ -1,4 +1,4 @@
-"""Last step of a rocprofv3 kernel trace as a timeline: python tools/scratch/trace_timeline.py <kernel_trace.csv> <first kernel substring>"""
+"""Last step of a rocprofv3 kernel trace as a timeline: python tools/timeline/trace_timeline.py <kernel_trace.csv> <first kernel substring>"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))

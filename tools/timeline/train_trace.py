@@ -1,4 +1,4 @@
-"""A few training steps for a rocprofv3 --kernel-trace timeline: python tools/scratch/train_trace.py [in_dim] [defer]"""
+"""A few training steps for a rocprofv3 --kernel-trace timeline: python tools/timeline/train_trace.py [in_dim] [defer]"""
 import sys
 import torch
 sys.path.insert(0, ".")

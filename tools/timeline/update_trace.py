@@ -1,5 +1,5 @@
 """One AMP discriminator update at the reference's sizes (16 rollouts x 4096 envs, batch 4096, 6 epochs x 2 minibatches; replay 1 M rows,
-motion dataset 200 k rows) -- wall time per update and, under rocprofv3 --kernel-trace, its kernels: python tools/scratch/update_trace.py"""
+motion dataset 200 k rows) -- wall time per update and, under rocprofv3 --kernel-trace, its kernels: python tools/timeline/update_trace.py"""
 import sys, time
 import torch
 sys.path.insert(0, ".")
