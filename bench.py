@@ -600,7 +600,9 @@ def main():
                                "kernel; the rooflines use the raw brackets",
             "kernel_us_per_step": per_kernel,
             "kernel_us_per_step_note": "a separate, fully traced eager pass after the timed region: every launch carries a HIP-event "
-                                       "pair (~3-4 us of queue time each), so the sum exceeds ms_per_step of the untraced / sampled region",
+                                       "pair (created without the system-scope fence since round 4: the brackets then agree with rocprofv3's "
+                                       "kernel durations -- tail 4.9 vs 4.9 us, env launch 51.8 vs 52.8-53.3 --; with the default flag each "
+                                       "record delayed the next kernel by several us)",
             "disc_flops_per_env_step": disc_flops_per_row(spec.K * spec.D),
         }
     del hot

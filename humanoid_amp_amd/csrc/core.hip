@@ -59,7 +59,10 @@ int amp_trace_begin(int64_t capacity, const char* filter) {
   g_recs.resize((size_t)capacity);
   for (auto& r : g_recs) {
     r.name = "";
-    if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess)
+    // timing events only: no system-scope fence at the record (the default flag's cache write-back / invalidate delayed the
+    // kernel behind a record by ~8 us in a rocprofv3 timeline: the tracer perturbed what it measured)
+    if (hipEventCreateWithFlags(&r.start, hipEventDisableSystemFence) != hipSuccess ||
+        hipEventCreateWithFlags(&r.stop, hipEventDisableSystemFence) != hipSuccess)
       return fail(AMP_ERR_HIP, "amp_trace_begin: hipEventCreate failed");
   }
   g_filter = filter ? filter : "";
