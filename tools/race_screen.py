@@ -17,7 +17,11 @@ for in_dim in (166, 830, 162):
     slow = AmpDiscriminator(w, "cuda:0", precision="f32", **kw)
     g = torch.Generator(device="cuda").manual_seed(in_dim)
     deadline = time.time() + seconds / 3
+    t_print = time.time()
     while time.time() < deadline:
+        if time.time() - t_print > 30:  # a run that stays silent for minutes is taken to be hung by the GPU harness
+            print(f"  ... {launches} passes, worst {worst:.3e}", flush=True)
+            t_print = time.time()
         # half of the draws from the large-shard plans (256 x 256 tiles, 32 768-row chunks), half from the small ones
         # (64 x 128 / 128 x 128 / 256 x 128 tiles, the k-block-per-segment ring, persistent layer-1 workgroups, register-staged)
         rows = int(torch.randint(24576, 90000, (1,)).item()) if launches % 8 < 4 else int(torch.randint(1, 24576, (1,)).item())
