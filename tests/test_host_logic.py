@@ -257,3 +257,33 @@ def test_engine_library_can_be_selected_by_environment(tmp_path):
     bad = tmp_path / "missing.so"
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, AMP_ENGINE_LIB=str(bad), PYTHONPATH=ROOT), capture_output=True, text=True)
     assert r.returncode != 0 and "no CPU fallback" in r.stderr
+
+
+def test_step_counter_hand_over_arguments_are_checked_on_the_host():
+    """ABI 10: AmpPrePhysicsArgs.step_in / step_out hand the device-side step counter of a captured env step to the reset
+    launch.  The pair comes together, names two different words, and the tick of the same launch must not read the word the
+    launch writes -- all refused on the host, before anything is launched (no GPU needed for the refusals)."""
+    import ctypes as C
+
+    from humanoid_amp_amd import _native as nat
+
+    lib = nat.load()
+    words = (C.c_uint64 * 2)(7, 0)
+    base = C.addressof(words)
+    buf = (C.c_float * 64)()
+
+    def args(step_in, step_out):
+        a = nat.AmpPrePhysicsArgs()
+        a.actions_in = C.addressof(buf)
+        a.num_envs, a.n_actions = 4, 3
+        a.step_in, a.step_out = step_in, step_out
+        return a
+
+    for step_in, step_out in ((base, None), (None, base + 8), (base, base)):
+        assert lib.amp_pre_physics_step(C.byref(args(step_in, step_out)), None, None) != 0
+        assert b"step_in / step_out" in lib.amp_last_error()
+    tick = nat.AmpCommandArgs()
+    tick.command, tick.time_left = C.addressof(buf), C.addressof(buf)
+    tick.step_dev = base + 8   # the word this launch would write
+    assert lib.amp_pre_physics_step(C.byref(args(base, base + 8)), C.byref(tick), None) != 0
+    assert b"must not read the word" in lib.amp_last_error()
