@@ -571,7 +571,10 @@ int amp_disc_trainer_scaler(const AmpDiscTrainer* t, double* mean_out_dev, doubl
                             amp_stream_t stream);
 /* One step on three batches of `rows` raw AMP observations each ([rows, in_dim], row stride in elements).
  * loss_dev (may be NULL): [5] = prediction, gradient penalty, logit regularisation, weight decay (unscaled terms) and
- * [4] = loss_scale * their sum (skrl's discriminator_loss).  grads_dev (may be NULL): dL/d(W1, b1, W2, b2, W3, b3) concatenated, logical shapes. */
+ * [4] = loss_scale * their sum (skrl's discriminator_loss).  grads_dev (may be NULL): dL/d(W1, b1, W2, b2, W3, b3) concatenated, logical shapes.
+ * Asynchronous on `stream`; part of the step (the gradient-penalty chain) is enqueued on a stream the trainer owns and joined back
+ * before the step's last kernels, so the step is ordered like a single-stream enqueue for whatever follows on `stream`, and a
+ * stream capture of it stays valid. */
 int amp_disc_train_step(AmpDiscTrainer* t, const float* policy_dev, const float* replay_dev, const float* motion_dev,
                         int64_t rows, int64_t row_stride, float* loss_dev, float* grads_dev, amp_stream_t stream);
 
