@@ -179,7 +179,7 @@ static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * 
 __global__ __launch_bounds__(kBlock) void disc_weight_range_kernel(const float* __restrict__ w1p, int h1, int k1p,
                                                                    const float* __restrict__ b1, const float* __restrict__ w2,
                                                                    int64_t n2, DiscRange* __restrict__ out) {
-  unsigned* slot = reinterpret_cast<unsigned*>(out);  // [0] max |W1|, [1] max |W2|, [2] max row sum, [3] max |b1|
+  unsigned* slot = out->raw;  // [0] max |W1|, [1] max |W2|, [2] max row sum, [3] max |b1| (zero on entry: see DiscRange)
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
   float wmax1 = 0.0f, rsum_max = 0.0f, bmax = 0.0f, wmax2 = 0.0f;
@@ -215,11 +215,27 @@ __global__ __launch_bounds__(kBlock) void disc_weight_range_kernel(const float* 
     for (int w = 0; w < kBlock / kWave; ++w) m = fmaxf(m, red[threadIdx.x][w]);
     atomicMax(slot + threadIdx.x, __float_as_uint(m));
   }
-}
-__global__ void disc_weight_range_finish_kernel(DiscRange* r) {
-  r->s_w1 = plane_scale(r->s_w1);
-  r->s_w2 = plane_scale(r->s_w2);
-  r->wsum1 *= 1.0001f;  // the row sums were rounded (and summed in lane order): keep the bound a bound
+  // The workgroup that takes the last ticket publishes the record (a one-thread kernel of its own, behind a memset of the slots,
+  // until round 4: two more launches behind every training step).  Every workgroup's four atomics are performed before its
+  // ticket (barrier + fence); the finisher takes the maxima out through atomic exchanges (device-coherent), which also leaves
+  // the accumulators zero for the next launch.
+  __shared__ unsigned s_ticket;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    s_ticket = atomicAdd(&out->ticket, 1u);
+  }
+  __syncthreads();
+  if (s_ticket == gridDim.x - 1 && threadIdx.x == 0) {
+    __threadfence();
+    const float m1 = __uint_as_float(atomicExch(slot + 0, 0u)), m2 = __uint_as_float(atomicExch(slot + 1, 0u));
+    const float rs = __uint_as_float(atomicExch(slot + 2, 0u)), bm = __uint_as_float(atomicExch(slot + 3, 0u));
+    out->s_w1 = plane_scale(m1);
+    out->s_w2 = plane_scale(m2);
+    out->wsum1 = rs * 1.0001f;  // the row sums were rounded (and summed in lane order): keep the bound a bound
+    out->bmax1 = bm;
+    atomicExch(&out->ticket, 0u);
+  }
 }
 
 __global__ void disc_set_clip_kernel(DiscRange* r, float clip) { r->clip = clip; }
@@ -545,26 +561,51 @@ static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* a
 }
 
 // weights (or the scaler) changed: ranges, plane scales and the fp16 planes of W1 / W2
+// W1 [h1, k1p] -> planes [h1, k1h] (plain: w1h + plane n1; block layout: w1b) and W2 [h2, h1] likewise, one thread per four
+// columns, one read of the weights for both layouts (the bodies of split_rows_f16_kernel and split_rows_blocks_kernel)
+__global__ __launch_bounds__(kBlock) void split_weights_kernel(const float* __restrict__ w1, int h1, int k1p, int k1h,
+                                                               _Float16* __restrict__ w1h, _Float16* __restrict__ w1b, int64_t n1,
+                                                               const float* __restrict__ w2, int h2, int k2,
+                                                               _Float16* __restrict__ w2h, _Float16* __restrict__ w2b, int64_t n2,
+                                                               const DiscRange* __restrict__ range, unsigned blocks1) {
+  const bool first = blockIdx.x < blocks1;
+  const float* src = first ? w1 : w2;
+  const int rows = first ? h1 : h2, cols = first ? k1p : k2, kp = first ? k1h : k2;   // cols = source row pitch = valid columns
+  _Float16* plain = first ? w1h : w2h;
+  _Float16* blk_out = first ? w1b : w2b;
+  const int64_t plane = first ? n1 : n2;
+  const float s = first ? range->s_w1 : range->s_w2;
+  const int64_t q = (int64_t)(first ? blockIdx.x : blockIdx.x - blocks1) * kBlock + threadIdx.x, per_row = kp / 4;
+  if (q >= (int64_t)rows * per_row) return;
+  const int64_t r = q / per_row;
+  const int c = (int)(q - r * per_row) * 4;
+  fv4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = c + i < cols ? src[r * cols + c + i] * s : 0.0f;
+  h4 p0, p1;
+  split_planes4(v, p0, p1);
+  *reinterpret_cast<h4*>(&plain[r * kp + c]) = p0;
+  *reinterpret_cast<h4*>(&plain[plane + r * kp + c]) = p1;
+  _Float16* blk = blk_out + r * (2 * (int64_t)kp) + (c >> 5) * 64 + (c & 31);
+  *reinterpret_cast<h4*>(blk) = p0;
+  *reinterpret_cast<h4*>(blk + 32) = p1;
+}
+
 static int f16_refresh(AmpDisc* h, hipStream_t st) {
-  AMP_HIP(hipMemsetAsync(h->range, 0, 4 * sizeof(float), st));  // the four maxima (the clamp behind them stays)
   { amp::TraceScope trace__("disc_weight_range_kernel", st);
     disc_weight_range_kernel<<<128, kBlock, 0, st>>>(h->w1p, h->h1, h->k1p, h->b1, h->w2, (int64_t)h->h2 * h->h1, h->range);
-    disc_weight_range_finish_kernel<<<1, 1, 0, st>>>(h->range);
   }
   int rc = launch_status("disc_weight_range_kernel");
   if (rc != AMP_OK) return rc;
   const int64_t n1 = (int64_t)h->h1 * h->k1h, n2 = (int64_t)h->h2 * h->h1;
-  { amp::TraceScope trace__("split_rows_f16_kernel", st);
-    split_rows_f16_kernel<<<(unsigned)((n1 / 4 + kBlock - 1) / kBlock), kBlock, 0, st>>>(h->w1p, h->h1, h->k1p, h->k1p, &h->range->s_w1,
-                                                                                        h->w1h, h->k1h, n1);
-    split_rows_f16_kernel<<<(unsigned)((n2 / 4 + kBlock - 1) / kBlock), kBlock, 0, st>>>(h->w2, h->h2, h->h1, h->h1, &h->range->s_w2,
-                                                                                        h->w2h, h->h1, n2);
-    split_rows_blocks_kernel<<<(unsigned)((n1 / 4 + kBlock - 1) / kBlock), kBlock, 0, st>>>(h->w1p, h->h1, h->k1p, h->k1p, &h->range->s_w1,
-                                                                                           h->w1b, h->k1h);
-    split_rows_blocks_kernel<<<(unsigned)((n2 / 4 + kBlock - 1) / kBlock), kBlock, 0, st>>>(h->w2, h->h2, h->h1, h->h1, &h->range->s_w2,
-                                                                                           h->w2b, h->h1);
+  // both weights into both plane layouts in ONE launch (the training step refreshes them after every update: four 5-us launches
+  // in a row were a third of that refresh); same values as split_rows_f16_kernel / split_rows_blocks_kernel
+  const unsigned b1n = (unsigned)((n1 / 4 + kBlock - 1) / kBlock), b2n = (unsigned)((n2 / 4 + kBlock - 1) / kBlock);
+  { amp::TraceScope trace__("split_weights_kernel", st);
+    split_weights_kernel<<<b1n + b2n, kBlock, 0, st>>>(h->w1p, h->h1, h->k1p, h->k1h, h->w1h, h->w1b, n1, h->w2, h->h2, h->h1, h->w2h, h->w2b,
+                                                     n2, h->range, b1n);
   }
-  return launch_status("split_rows_f16_kernel");
+  return launch_status("split_weights_kernel");
 }
 }  // namespace amp
 

@@ -37,7 +37,14 @@ struct DiscRange {
   float wsum1, bmax1;  // max_j sum_k |W1[j, k]|, max_j |b1[j]|: |H1| <= wsum1 * bound_x + bmax1
   float clip;          // static bound of the scaled input (the scaler's clamp)
   float pad[3];
+  // disc_weight_range_kernel's accumulators: max |W1|, max |W2|, max row sum, max |b1| as uint bit patterns (atomicMax) and the
+  // ticket of its workgroups; all zero between launches (the workgroup with the last ticket publishes the fields above and
+  // clears them: no memset in front of the launch)
+  unsigned raw[4];
+  unsigned ticket;
+  unsigned pad2[3];
 };
+static_assert(sizeof(DiscRange) == 64, "DiscRange is one 64-B record");
 
 // largest power of two s with s * bound < 2^15 (fp16 tops out at 65504)
 __host__ __device__ __forceinline__ float plane_scale(float bound) {

@@ -1233,12 +1233,13 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
     // advance the device-side state here (the scaler's merge, which reads the count, is behind ev[2]; Adam, which reads the bias
     // corrections, is behind the join): off the step's critical path
     train_state_kernel<<<1, 1, 0, side>>>(t->state, c.update_scaler ? 3.0 * (double)B : 0.0, (double)c.beta1, (double)c.beta2);
-    if (scaler_to_handle) {   // the handle's copy of the statistics (read by inference only, which is behind the join)
+    rc = penalty();
+    if (rc != AMP_OK) return rc;
+    if (scaler_to_handle) {   // the handle's copy of the statistics (read by inference only, which is behind the join); at the END of
+                              // the side stream's work: in front of the chain its two small launches delayed every GEMM behind them
       rc = amp_disc_set_scaler(t->disc, t->mean64, t->var64, c.scaler_epsilon, c.scaler_clip, (amp_stream_t)side);
       if (rc != AMP_OK) return rc;
     }
-    rc = penalty();
-    if (rc != AMP_OK) return rc;
     AMP_HIP(hipEventRecord(t->ev[3], side));
   }
 

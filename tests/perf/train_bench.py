@@ -15,11 +15,11 @@ tr = AmpDiscriminatorTrainer(disc, batch_size=B)
 g = torch.Generator().manual_seed(0)
 p, r, m = (torch.randn(B, in_dim, generator=g) for _ in range(3))
 pc, rc, mc = p.cuda(), r.cuda(), m.cuda()
-for _ in range(3):
+for _ in range(10):   # (three warm-up steps left the first timed mode ~50 us per step slower than the later ones: clocks, allocator)
     tr.step(pc, rc, mc)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-n = 20
+n = 40
 for _ in range(n):
     tr.step(pc, rc, mc)
 torch.cuda.synchronize()
@@ -35,7 +35,7 @@ torch.cuda.synchronize()
 graph_ms = (time.perf_counter() - t0) / n * 1e3
 disc2 = AmpDiscriminator(w, "cuda:0", running_mean=torch.zeros(in_dim, dtype=torch.float64), running_variance=torch.ones(in_dim, dtype=torch.float64))
 tr2 = AmpDiscriminatorTrainer(disc2, batch_size=B, defer_refresh=True)
-for _ in range(3):
+for _ in range(10):
     tr2.step(pc, rc, mc)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
