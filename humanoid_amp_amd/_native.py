@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # AMP_ENGINE_LIB: load another build of the SAME library instead of the in-tree one (A/B variants from tools/build_variant.sh:
 # diagnostic stamps, ablations) -- the in-tree product file is never overwritten by an experiment.  ABI and symbols are checked as usual.
 LIB_PATH = os.environ.get("AMP_ENGINE_LIB") or os.path.join(_HERE, "csrc", "libamp_engine.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 AMP_DISC_F16X3, AMP_DISC_FP32 = 0, 1
 AMP_DISC_INPUT_F32_ROWS, AMP_DISC_INPUT_F16_BLOCKS = 0, 1
@@ -212,6 +212,7 @@ SIGNATURES = {
     "amp_disc_trainer_destroy": (C.c_int, [_vp]),
     "amp_disc_trainer_scaler": (C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_double), _vp]),
     "amp_disc_trainer_refresh": (C.c_int, [_vp, _vp]),
+    "amp_disc_trainer_adam_state": (C.c_int, [_vp, _vp, _vp, C.POINTER(_i64), _vp]),
     "amp_disc_train_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "amp_converter_create": (C.c_int, [C.POINTER(AmpKinModel), C.POINTER(_vp)]),
     "amp_converter_destroy": (C.c_int, [_vp]),
@@ -222,7 +223,7 @@ SIGNATURES = {
     "amp_ring_size": (_i64, [_vp]),
     "amp_ring_head": (_i64, [_vp]),
     "amp_ring_append": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
-    "amp_ring_sample": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _i64, _vp, _i64, _vp, _vp]),
+    "amp_ring_sample": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _i64, _i64, _vp, _i64, _vp, _vp]),
     "amp_disc_style_reward_prescaled": (C.c_int, [_vp, _vp, _i64, _f32, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "amp_disc_style_reward_prescaled_compact": (C.c_int, [_vp, _vp, _i64, _f32, _vp, _f32, _f32, _vp, _vp, _vp, _vp,
                                                           C.POINTER(AmpCompactArgs), _vp]),

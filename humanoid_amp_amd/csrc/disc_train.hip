@@ -1004,6 +1004,26 @@ int amp_disc_trainer_scaler(const AmpDiscTrainer* t, double* mean_out, double* v
   return AMP_OK;
 }
 
+int amp_disc_trainer_adam_state(const AmpDiscTrainer* t, float* exp_avg, float* exp_avg_sq, int64_t* step, amp_stream_t stream) {
+  AMP_REQUIRE(t, "amp_disc_trainer_adam_state: null handle");
+  hipStream_t st = (hipStream_t)stream;
+  const DiscParams& p = t->p;
+  const int64_t n[6] = {(int64_t)p.h1 * p.in_dim, p.h1, (int64_t)p.h2 * p.h1, p.h2, p.h2, 1};
+  int64_t off = 0;
+  for (int k = 0; k < 6; ++k) {  // the moments are stored per tensor in its logical shape (adam_multi_kernel's index i)
+    if (exp_avg) AMP_HIP(hipMemcpyAsync(exp_avg + off, t->mom[k], sizeof(float) * n[k], hipMemcpyDeviceToDevice, st));
+    if (exp_avg_sq) AMP_HIP(hipMemcpyAsync(exp_avg_sq + off, t->vel[k], sizeof(float) * n[k], hipMemcpyDeviceToDevice, st));
+    off += n[k];
+  }
+  if (step) {
+    TrainState s{};
+    AMP_HIP(hipMemcpyAsync(&s, t->state, sizeof(TrainState), hipMemcpyDeviceToHost, st));
+    AMP_HIP(hipStreamSynchronize(st));
+    *step = (int64_t)s.step;
+  }
+  return AMP_OK;
+}
+
 int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* replay, const float* motion, int64_t rows,
                         int64_t row_stride, float* loss_dev, float* grads_dev, amp_stream_t stream) {
   AMP_REQUIRE(t && policy && replay && motion, "amp_disc_train_step: null argument");

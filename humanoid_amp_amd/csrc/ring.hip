@@ -6,8 +6,11 @@
 //
 //   append  n rows (any row stride) -> storage[(head + i) % capacity]; head / size live on the host (the caller
 //           serialises appends on one stream, like every other engine call)
-//   sample  row i = storage[floor(u_i * size)], u_i = word 0 of Philox4x32-10(counter = (i, draw), key = seed):
-//           reproducible, order-independent, no host RNG; indices optionally returned (bit-exact vs oracle/rng.py)
+//   sample  row i = storage[floor(u_g * size)], g = first_row + i, u_g = word 0 of Philox4x32-10(counter = (g, draw), key = seed):
+//           reproducible, order-independent, no host RNG; indices optionally returned (bit-exact vs oracle/rng.py).
+//           `first_row` is the GLOBAL position of this call's first row in the minibatch the rows belong to: rank w of a
+//           multi-rank discriminator update draws its rows [w * n, (w + 1) * n) of the minibatch, so the variates of a
+//           minibatch do not depend on how many ranks share it (humanoid_amp_amd/distributed.py)
 #include "amp_common.hpp"
 
 struct AmpRing {
@@ -31,14 +34,15 @@ __global__ __launch_bounds__(kBlock) void ring_append_kernel(const float* __rest
 }
 
 __global__ __launch_bounds__(kBlock) void ring_sample_kernel(const float* __restrict__ rows, int64_t size, int dim, uint64_t seed,
-                                                             uint64_t draw, int64_t n, float* __restrict__ out, int64_t out_stride,
-                                                             int64_t* __restrict__ idx_out) {
+                                                             uint64_t draw, int64_t first, int64_t n, float* __restrict__ out,
+                                                             int64_t out_stride, int64_t* __restrict__ idx_out) {
   const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (e >= n * dim) return;
   const int64_t i = e / dim;
   const int c = (int)(e - i * dim);
+  const uint64_t g = (uint64_t)(first + i);
   uint32_t r[4];
-  philox4x32_10((uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)draw, (uint32_t)(draw >> 32), (uint32_t)seed,
+  philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)draw, (uint32_t)(draw >> 32), (uint32_t)seed,
                 (uint32_t)(seed >> 32), r);
   // size < 2^32: floor(u * size) with u = r0 / 2^32 (bias <= size / 2^32, as torch.randint's modulo has)
   const int64_t row = (int64_t)(((uint64_t)r[0] * (uint64_t)size) >> 32);
@@ -105,10 +109,11 @@ int amp_ring_append(AmpRing* r, const float* rows_dev, int64_t n, int64_t row_st
   return AMP_OK;
 }
 
-int amp_ring_sample(const AmpRing* r, uint64_t seed, uint64_t draw, int64_t n, float* out_dev, int64_t out_stride,
+int amp_ring_sample(const AmpRing* r, uint64_t seed, uint64_t draw, int64_t first_row, int64_t n, float* out_dev, int64_t out_stride,
                     int64_t* indices_dev, amp_stream_t stream) {
   AMP_REQUIRE(r, "amp_ring_sample: null handle");
   AMP_REQUIRE(n >= 0, "amp_ring_sample: negative row count");
+  AMP_REQUIRE(first_row >= 0, "amp_ring_sample: negative first_row");
   if (n == 0) return AMP_OK;
   AMP_REQUIRE(r->size > 0, "amp_ring_sample: the buffer is empty");
   AMP_REQUIRE(out_dev, "amp_ring_sample: null output");
@@ -116,7 +121,7 @@ int amp_ring_sample(const AmpRing* r, uint64_t seed, uint64_t draw, int64_t n, f
   hipStream_t st = (hipStream_t)stream;
   {
     amp::TraceScope trace__("ring_sample_kernel", st);
-    ring_sample_kernel<<<(unsigned)((n * r->dim + kBlock - 1) / kBlock), kBlock, 0, st>>>(r->rows, r->size, r->dim, seed, draw, n, out_dev,
+    ring_sample_kernel<<<(unsigned)((n * r->dim + kBlock - 1) / kBlock), kBlock, 0, st>>>(r->rows, r->size, r->dim, seed, draw, first_row, n, out_dev,
                                                                                      out_stride, indices_dev);
   }
   return launch_status("ring_sample_kernel");

@@ -1,9 +1,12 @@
-"""Multi-GPU plumbing: env sharding (no data-path collective) + the one real exchange step of the AMP path,
-the all-gather of the AMP replay minibatch (RCCL over xGMI through torch.distributed; gloo on CPU in tests).
+"""Multi-GPU plumbing: env sharding (no data-path collective) + the one real exchange step of the AMP path, the
+all-gather of the discriminator-update minibatch rows (RCCL over xGMI through torch.distributed; gloo on CPU in tests).
 
-The reference has no first-party collective: ``train.py:54-58,183-196`` only pins one env shard + agent replica
-per GPU and skrl all-reduces gradients.  What the sharded *hot path* needs (BASELINE.json north_star) is that each
-rank's discriminator minibatch sees replay rows from every rank's envs.
+The reference has no first-party collective: ``train.py:54-58,183-196`` pins one env shard + one agent replica per GPU and
+skrl [third-party] all-reduces the gradients of every minibatch.  BASELINE.json's north_star replaces that by ONE exchange of
+rows: every rank contributes ``batch / world`` rows of each group of every training step of an agent update, the ranks
+all-gather them, and every replica then takes the SAME optimizer steps on the SAME global minibatches -- the replicas stay
+bit-identical with no gradient traffic at all (:class:`UpdateExchange` is the collective, ``engine.AmpDiscriminatorUpdate(...,
+group=...)`` its consumer).
 """
 
 from __future__ import annotations
@@ -24,6 +27,12 @@ def shard_bounds(num_envs: int, world_size: int, rank: int) -> tuple[int, int]:
 def global_env_ids(local_ids: torch.Tensor, num_envs: int, world_size: int, rank: int) -> torch.Tensor:
     """Reset ids of a shard are local; the global id is local + the shard's first env."""
     return local_ids + shard_bounds(num_envs, world_size, rank)[0]
+
+
+def _world(group) -> tuple[int, int]:
+    if group is None or not dist.is_initialized():
+        return 1, 0
+    return dist.get_world_size(group), dist.get_rank(group)
 
 
 def allgather_minibatch(shard: torch.Tensor, out: torch.Tensor | None = None, group=None,
@@ -50,69 +59,76 @@ def allgather_minibatch(shard: torch.Tensor, out: torch.Tensor | None = None, gr
     return out
 
 
-class ReplayAllGather:
-    """Draw ``rows`` random rows of this rank's AMP observations and all-gather them (one discriminator minibatch).
+class UpdateExchange:
+    """The ONE collective of a discriminator update (``steps`` = learning_epochs x mini_batches training steps of ``groups``
+    row groups each: policy, replay, motion).
 
-    ``slots`` independent (shard, output) buffer pairs let that many gathers be in flight: ``start()`` enqueues the
-    row draw on the current stream and launches the collective asynchronously on RCCL's stream, so it runs under the
-    following env steps / GEMMs; ``wait_all()`` (or the next ``start()`` on a busy slot) joins them.  ``__call__`` is
-    the blocking form.
+    Every rank fills :attr:`contrib` ``[steps, groups, rows_per_rank, C]`` with its share of every minibatch -- the rows
+    ``[rank * rows_per_rank, (rank + 1) * rows_per_rank)`` of each -- :meth:`start` launches one all-gather of the whole block
+    (asynchronous on RCCL's stream; xGMI links are point-to-point, so one ``steps * groups * rows_per_rank * C * 4``-byte
+    message per peer uses them better than ``steps * groups`` small ones) and :meth:`finish` returns :attr:`batches`
+    ``[steps, groups, world * rows_per_rank, C]``: the global minibatches, identical on every rank.  Row ``j`` of a global
+    minibatch comes from rank ``j // rows_per_rank``, local row ``j % rows_per_rank`` (:meth:`source_of`).
 
-    ``minibatches`` > 1 fuses that many minibatches of one agent update into ONE collective (same bytes, one launch:
-    xGMI links are point-to-point, so fewer and larger messages use them better than twelve 2.7-MB ones): each rank
-    contributes ``[minibatches, rows, C]`` and the gathered tensor is ``[world, minibatches, rows, C]``;
-    :meth:`minibatch_blocks` returns minibatch i as its ``world`` contiguous ``[rows, C]`` blocks."""
+    The gathered block arrives rank-major (``[world, steps, groups, r, C]``); ``finish`` is the one strided copy that makes every
+    (step, group) batch a contiguous ``[world * r, C]`` tensor the trainer can take by pointer."""
 
-    def __init__(self, amp_obs: torch.Tensor, rows: int, seed: int = 0, group=None, slots: int = 1, minibatches: int = 1):
-        self.minibatches, self.rows_per_minibatch = int(minibatches), int(rows)
-        rows = int(rows) * self.minibatches
-        self.amp_obs, self.rows, self.group = amp_obs, int(rows), group
-        self.gen = torch.Generator(device=amp_obs.device).manual_seed(seed)
-        world = dist.get_world_size(group) if dist.is_initialized() else 1
-        mk = lambda n: torch.empty((n, amp_obs.shape[1]), dtype=amp_obs.dtype, device=amp_obs.device)  # noqa: E731
-        self.shards = [mk(self.rows) for _ in range(slots)]
-        self.outs = [mk(world * self.rows) for _ in range(slots)]
-        self.works = [None] * slots
-        self._next = 0
-        self._async = dist.is_initialized() and world > 1 and (not amp_obs.is_cuda or dist.get_backend(group) == "nccl")
+    def __init__(self, steps: int, groups: int, rows_per_rank: int, cols: int, device, dtype=torch.float32, group=None,
+                 force_collective: bool = False):
+        """``force_collective``: run the real collective even for a group of one rank (how the RCCL path is exercised on a
+        one-GPU box); by default a world of one hands the contribution back as the batch set, with no copy."""
+        self.group = group
+        self.world, self.rank = _world(group)
+        self._collective = self.world > 1 or (bool(force_collective) and group is not None and dist.is_initialized())
+        self.steps, self.groups, self.rows_per_rank, self.cols = int(steps), int(groups), int(rows_per_rank), int(cols)
+        shape = (self.steps, self.groups, self.rows_per_rank, self.cols)
+        self.contrib = torch.empty(shape, dtype=dtype, device=device)
+        if self._collective:
+            self.batches = torch.empty((self.steps, self.groups, self.world * self.rows_per_rank, self.cols), dtype=dtype, device=device)
+            self._gathered = torch.empty((self.world,) + shape, dtype=dtype, device=device)
+        else:  # world 1: the contribution IS the batch set (no gather buffer, no copy)
+            self.batches, self._gathered = self.contrib, None
+        self._work = None
+        self._pending = False
 
-    def _draw(self, slot: int):
-        idx = torch.randint(0, self.amp_obs.shape[0], (self.rows,), generator=self.gen, device=self.amp_obs.device)
-        torch.index_select(self.amp_obs, 0, idx, out=self.shards[slot])
+    @property
+    def first_row(self) -> int:
+        """Where this rank's rows sit in every global minibatch."""
+        return self.rank * self.rows_per_rank
 
-    def __call__(self) -> torch.Tensor:
-        self._draw(0)
-        return allgather_minibatch(self.shards[0], self.outs[0], self.group)
+    def source_of(self, row: int) -> tuple[int, int]:
+        """(rank, local row) a row of a global minibatch came from."""
+        return divmod(int(row), self.rows_per_rank)
 
-    def start(self) -> int:
-        """Begin one gather in the next slot (waits first if that slot is still in flight); returns the slot."""
-        slot = self._next
-        self._next = (self._next + 1) % len(self.shards)
-        if self.works[slot] is not None:
-            self.works[slot].wait()
-            self.works[slot] = None
-        self._draw(slot)
-        if self._async:
-            self.works[slot] = dist.all_gather_into_tensor(self.outs[slot], self.shards[slot], group=self.group, async_op=True)
-        else:
-            allgather_minibatch(self.shards[slot], self.outs[slot], self.group)
-        return slot
+    @property
+    def bytes_per_rank(self) -> int:
+        return self.contrib.numel() * self.contrib.element_size()
 
-    def wait_all(self):
-        for i, w in enumerate(self.works):
-            if w is not None:
-                w.wait()
-                self.works[i] = None
+    def start(self) -> None:
+        """Launch the all-gather of :attr:`contrib` (whatever the current stream has enqueued into it is ordered first)."""
+        if self._pending:
+            raise RuntimeError("UpdateExchange.start(): the previous exchange was not finished")
+        self._pending = True
+        if not self._collective:
+            return
+        if self.contrib.is_cuda and dist.get_backend(self.group) != "nccl":
+            # rehearsal path only (gloo has no device collectives): stage through the host, synchronously
+            host = torch.empty(self._gathered.shape, dtype=self._gathered.dtype)
+            dist.all_gather_into_tensor(host.view(-1), self.contrib.cpu().view(-1), group=self.group)
+            self._gathered.copy_(host)
+            return
+        self._work = dist.all_gather_into_tensor(self._gathered.view(-1), self.contrib.view(-1), group=self.group, async_op=True)
 
-    def minibatch_blocks(self, slot: int, i: int):
-        """Minibatch ``i`` of a fused gather: ``world`` contiguous ``[rows, C]`` views, rank order (no copy)."""
-        out = self.result(slot)
-        world = out.shape[0] // self.rows
-        full = out.view(world, self.minibatches, self.rows_per_minibatch, out.shape[1])
-        return [full[r, i] for r in range(world)]
-
-    def result(self, slot: int) -> torch.Tensor:
-        if self.works[slot] is not None:
-            self.works[slot].wait()
-            self.works[slot] = None
-        return self.outs[slot]
+    def finish(self) -> torch.Tensor:
+        """Join the collective and return the global minibatches ``[steps, groups, world * rows_per_rank, C]``."""
+        if not self._pending:
+            raise RuntimeError("UpdateExchange.finish() without start()")
+        self._pending = False
+        if not self._collective:
+            return self.batches
+        if self._work is not None:
+            self._work.wait()  # device tensors: a stream dependency, not a host block
+            self._work = None
+        S, G, W, r, C = self.steps, self.groups, self.world, self.rows_per_rank, self.cols
+        self.batches.view(S, G, W, r, C).copy_(self._gathered.permute(1, 2, 0, 3, 4))
+        return self.batches

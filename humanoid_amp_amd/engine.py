@@ -732,6 +732,17 @@ class AmpDiscriminatorTrainer:
                       "amp_disc_trainer_scaler")
         return mean, var, float(cnt.value)
 
+    def adam_state(self):
+        """(exp_avg, exp_avg_sq, step): Adam's moments of (W1, b1, W2, b2, W3, b3) concatenated in their logical shapes (the
+        layout of ``step(want_grads=True)["grads"]``) and the optimizer steps taken."""
+        m = torch.empty(self._n_params, dtype=torch.float32, device=self.device)
+        v = torch.empty(self._n_params, dtype=torch.float32, device=self.device)
+        n = C.c_int64()
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.amp_disc_trainer_adam_state(self._handle, nat.dptr(m), nat.dptr(v), C.byref(n), nat.stream_ptr()),
+                      "amp_disc_trainer_adam_state")
+        return m, v, int(n.value)
+
     def __del__(self):
         h, self._handle = getattr(self, "_handle", None), None
         if h is not None:
@@ -778,14 +789,16 @@ class AmpReplayBuffer:
         with torch.cuda.device(self.device):
             nat.check(self._lib.amp_ring_append(self._handle, ptr, rows.shape[0], stride, nat.stream_ptr()), "amp_ring_append")
 
-    def sample(self, batch_size: int, *, out: Optional[torch.Tensor] = None, return_indices: bool = False):
-        """``[batch_size, row_dim]`` rows (into ``out`` if given); each call advances the draw counter."""
+    def sample(self, batch_size: int, *, out: Optional[torch.Tensor] = None, return_indices: bool = False, first_row: int = 0):
+        """``[batch_size, row_dim]`` rows (into ``out`` if given); each call advances the draw counter.  ``first_row``: where
+        these rows sit in the minibatch they belong to (row i takes the variate of counter ``(first_row + i, draw)``): rank w of
+        a multi-rank update draws ``batch / world`` rows at ``first_row = w * batch / world``."""
         if out is None:
             out = torch.empty((batch_size, self.row_dim), device=self.device)
         idx = torch.empty(batch_size, dtype=torch.int64, device=self.device) if return_indices else None
         with torch.cuda.device(self.device):
-            nat.check(self._lib.amp_ring_sample(self._handle, self.seed, self._draw, batch_size, nat.dptr(out), int(out.stride(0)),
-                                                nat.dptr(idx), nat.stream_ptr()), "amp_ring_sample")
+            nat.check(self._lib.amp_ring_sample(self._handle, self.seed, self._draw, int(first_row), batch_size, nat.dptr(out),
+                                                int(out.stride(0)), nat.dptr(idx), nat.stream_ptr()), "amp_ring_sample")
         self._draw += 1
         return (out, idx) if return_indices else out
 
@@ -806,14 +819,29 @@ class AmpDiscriminatorUpdate:
     * after the update the rollout's rows are appended to the replay buffer.
 
     Every draw is on the device (ring draws: counter-based; the shuffle: a seeded ``torch.randperm``); nothing is
-    read back.  With ``torch.distributed`` the replay rows of all ranks can be exchanged first
-    (``humanoid_amp_amd.distributed.ReplayAllGather``)."""
+    read back.
+
+    **Multi-rank** (``group`` = a ``torch.distributed`` process group; the reference's ``--distributed`` mode,
+    train.py:54-58,183-196, keeps one agent replica per GPU in step through skrl's gradient all-reduce): the trainer's
+    ``batch_size`` is the GLOBAL minibatch.  Every rank contributes ``batch_size / world`` rows to each group of every training
+    step -- policy rows from its own shuffled rollout, replay / motion rows from its own rings, drawn at
+    ``first_row = rank * batch_size / world`` so that a minibatch consumes the same variates whatever the world size -- the
+    contributions of the whole update travel in ONE all-gather (``distributed.UpdateExchange``), and every replica then
+    takes the same ``learning_epochs * mini_batches`` steps on the same global minibatches: weights, Adam state and scaler
+    stay bit-identical across ranks with no gradient traffic.  Compute per rank is that of a single-GPU update
+    (``batch_size`` = ``discriminator_batch_size``); a trainer built with ``batch_size = world * discriminator_batch_size``
+    instead reproduces the mean-of-rank-means gradient of skrl's all-reduce at ``world`` times the compute.  A group of one
+    rank is bit-identical to ``group=None``."""
+
+    GROUPS = ("policy", "replay", "motion")
 
     def __init__(self, trainer: AmpDiscriminatorTrainer, replay: AmpReplayBuffer, motion_dataset: AmpReplayBuffer, *,
-                 learning_epochs: int = 6, mini_batches: int = 2, seed: int = 0, record_batches: bool = False, prefetch: bool = True):
-        """``prefetch`` (default): the three batches of training step k + 1 (shuffle, row gather, two ring draws: ~45 us of
-        sort / gather launches) are produced on a side stream while step k trains, into two alternating sets of static
-        buffers; the same draws in the same order, so the rows are identical to the in-line flow (``prefetch=False``)."""
+                 learning_epochs: int = 6, mini_batches: int = 2, seed: int = 0, record_batches: bool = False, prefetch: bool = True,
+                 group=None):
+        """``prefetch`` (default; single-rank flow only): the three batches of training step k + 1 (shuffle, row gather, two
+        ring draws: ~45 us of sort / gather launches) are produced on a side stream while step k trains, into two alternating
+        sets of static buffers; the same draws in the same order, so the rows are identical to the in-line flow
+        (``prefetch=False``).  With a ``group`` every batch of the update is produced up front (the exchange needs them all)."""
         self.trainer, self.replay, self.motion_dataset = trainer, replay, motion_dataset
         self.learning_epochs, self.mini_batches = int(learning_epochs), int(mini_batches)
         self.gen = torch.Generator(device=trainer.device).manual_seed(seed)
@@ -821,17 +849,26 @@ class AmpDiscriminatorUpdate:
         self.batches = []  # (policy, replay, motion) of every trainer step of the last update, when recording
         self.prefetch = bool(prefetch)
         self._side, self._bufs = None, None
+        self.group, self.exchange = group, None
+        if group is not None:
+            import torch.distributed as dist
+
+            world = dist.get_world_size(group)
+            if trainer.batch_size % world != 0:
+                raise nat.AmpEngineError(f"the global minibatch ({trainer.batch_size} rows) must divide over the {world} ranks of the group")
 
     def update(self, rollout_amp_states: torch.Tensor):
         rows = rollout_amp_states.reshape(-1, rollout_amp_states.shape[-1])
         bs = self.trainer.batch_size
+        if self.group is not None:
+            return self._update_exchanged(rows, bs)
         if rows.shape[0] < bs * self.mini_batches:
             raise nat.AmpEngineError(f"the rollout has {rows.shape[0]} rows; {self.mini_batches} minibatches of {bs} are needed")
         if len(self.motion_dataset) == 0:
             raise nat.AmpEngineError("the motion dataset is empty: fill it with collect_reference rows first")
         losses, self.batches = [], []
         per = rows.shape[0] // self.mini_batches
-        if self.prefetch:
+        if self.prefetch and self.learning_epochs * self.mini_batches > 0:
             return self._update_prefetched(rows, per, bs)
         for _ in range(self.learning_epochs):
             perm = torch.randperm(rows.shape[0], generator=self.gen, device=rows.device)
@@ -844,24 +881,68 @@ class AmpDiscriminatorUpdate:
                     self.batches.append((policy.clone(), replay.clone(), motion.clone()))
         return self._finish(rows, losses)
 
-    def _finish(self, rows, losses):
-        self.replay.add_samples(rows)
+    def _finish(self, rows, losses, append=True):
+        if append:
+            self.replay.add_samples(rows)
         if getattr(self.trainer, "defer_refresh", False):
             self.trainer.refresh()  # the rollouts that follow score with the trained weights
         return losses
+
+    def _update_exchanged(self, rows, bs):
+        """The multi-rank flow: this rank's ``bs / world`` rows of every group of every step -> ONE all-gather -> the steps."""
+        from .distributed import UpdateExchange
+
+        n = self.learning_epochs * self.mini_batches
+        ex = self.exchange
+        if ex is None or (ex.steps, ex.cols, ex.contrib.dtype, ex.contrib.device) != (n, rows.shape[1], rows.dtype, rows.device):
+            ex = self.exchange = UpdateExchange(n, len(self.GROUPS), bs // _group_world(self.group), rows.shape[1], rows.device,
+                                                dtype=rows.dtype, group=self.group)
+        r = ex.rows_per_rank
+        if rows.shape[0] < r * self.mini_batches:
+            raise nat.AmpEngineError(f"the rollout has {rows.shape[0]} rows on this rank; {self.mini_batches} minibatches of {r} "
+                                     f"(= {bs} / {ex.world} ranks) are needed")
+        if len(self.motion_dataset) == 0:
+            raise nat.AmpEngineError("the motion dataset is empty: fill it with collect_reference rows first")
+        per = rows.shape[0] // self.mini_batches
+        have_replay = len(self.replay) > 0
+        perm = None
+        for k in range(n):
+            mb = k % self.mini_batches
+            if mb == 0:
+                perm = torch.randperm(rows.shape[0], generator=self.gen, device=rows.device)
+            policy, replay, motion = ex.contrib[k].unbind(0)
+            torch.index_select(rows, 0, perm[mb * per: mb * per + r], out=policy)
+            if have_replay:
+                self.replay.sample(r, out=replay, first_row=ex.first_row)
+            else:
+                replay.copy_(policy)
+            self.motion_dataset.sample(r, out=motion, first_row=ex.first_row)
+        ex.start()
+        self.replay.add_samples(rows)  # the draws above are enqueued ahead of it; the append runs under the collective
+        batches = ex.finish()
+        losses, self.batches = [], []
+        for k in range(n):
+            policy, replay, motion = batches[k].unbind(0)
+            losses.append(self.trainer.step(policy, replay, motion)["loss"])
+            if self.record_batches:
+                self.batches.append((policy.clone(), replay.clone(), motion.clone()))
+        return self._finish(rows, losses, append=False)
 
     def _update_prefetched(self, rows, per, bs):
         """The same flow with the batches of step k + 1 produced on a side stream under step k.  Two static buffer sets:
         the side stream refills a set only behind the training step that last read it (an event recorded on the main
         stream), the main stream trains on a set only behind its refill (an event recorded on the side stream).  The
-        shuffles and the ring draws consume their generators / counters in the in-line order."""
+        shuffles and the ring draws consume their generators / counters in the in-line order.  The batches of step k + 1 are
+        drawn before step k trains: if a training step raises, the generator and the ring draw counters are one step ahead of
+        the in-line flow's (they are not rolled back)."""
         dev = rows.device
         main = torch.cuda.current_stream(dev)
         if self._side is None:
             self._side = torch.cuda.Stream(device=dev)
-        if self._bufs is None or self._bufs[0][0].shape != (bs, rows.shape[1]):
-            self._bufs = [[torch.empty((bs, rows.shape[1]), device=dev) for _ in range(3)] for _ in range(2)]
-        side, bufs = self._side, self._bufs
+        key = ((bs, rows.shape[1]), rows.dtype, dev)
+        if self._bufs is None or self._bufs[0] != key:
+            self._bufs = (key, [[torch.empty(key[0], dtype=rows.dtype, device=dev) for _ in range(3)] for _ in range(2)])
+        side, bufs = self._side, self._bufs[1]
         n = self.learning_epochs * self.mini_batches
         ready, done = [None, None], [None, None]
         have_replay = len(self.replay) > 0
@@ -899,3 +980,9 @@ class AmpDiscriminatorUpdate:
             done[st] = torch.cuda.Event()
             done[st].record(main)
         return self._finish(rows, losses)
+
+
+def _group_world(group) -> int:
+    import torch.distributed as dist
+
+    return dist.get_world_size(group)

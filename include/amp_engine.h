@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define AMP_ABI_VERSION 10
+#define AMP_ABI_VERSION 11
 
 typedef void* amp_stream_t; /* hipStream_t */
 typedef void* amp_event_t;  /* hipEvent_t  */
@@ -569,6 +569,13 @@ int amp_disc_trainer_refresh(AmpDiscTrainer* t, amp_stream_t stream);
 /* Copies the running statistics (fp64 [in_dim]) into caller-owned device buffers; *count (host) = samples seen. */
 int amp_disc_trainer_scaler(const AmpDiscTrainer* t, double* mean_out_dev, double* var_out_dev, double* count,
                             amp_stream_t stream);
+/* Copies the optimizer state into caller-owned device buffers: first / second Adam moments of (W1, b1, W2, b2, W3, b3)
+ * concatenated in their logical shapes (the layout of amp_disc_train_step's grads_dev; either may be NULL); *step (host, may be
+ * NULL) = optimizer steps taken (one small blocking read-back).  What a multi-rank update compares across replicas
+ * (train.py:183-196: one agent replica per GPU, kept in step) and what a checkpoint of the agent holds
+ * (torch.optim.Adam.state_dict, third-party). */
+int amp_disc_trainer_adam_state(const AmpDiscTrainer* t, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t* step,
+                                amp_stream_t stream);
 /* One step on three batches of `rows` raw AMP observations each ([rows, in_dim], row stride in elements).
  * loss_dev (may be NULL): [5] = prediction, gradient penalty, logit regularisation, weight decay (unscaled terms) and
  * [4] = loss_scale * their sum (skrl's discriminator_loss).  grads_dev (may be NULL): dL/d(W1, b1, W2, b2, W3, b3) concatenated, logical shapes.
@@ -591,9 +598,13 @@ int amp_ring_destroy(AmpRing* r);
 int64_t amp_ring_size(const AmpRing* r);   /* rows currently valid (min(total appended, capacity)) */
 int64_t amp_ring_head(const AmpRing* r);   /* next write position */
 int amp_ring_append(AmpRing* r, const float* rows_dev, int64_t n, int64_t row_stride, amp_stream_t stream);
-/* out_dev [n, out_stride]; indices_dev [n] optional (the storage rows that were drawn) */
-int amp_ring_sample(const AmpRing* r, uint64_t seed, uint64_t draw, int64_t n, float* out_dev, int64_t out_stride,
-                    int64_t* indices_dev, amp_stream_t stream);
+/* out_dev [n, out_stride]; indices_dev [n] optional (the storage rows that were drawn).  Row i of the call takes the variate of
+ * counter (first_row + i, draw): `first_row` is where this call's rows sit in the minibatch they belong to -- 0 for a whole
+ * minibatch; rank w of a multi-rank discriminator update draws its n = batch / world rows with first_row = w * n, so a minibatch
+ * consumes the same variates whatever the world size (the reference's --distributed mode keeps one memory per rank,
+ * train.py:183-196; skrl's RandomMemory.sample is third-party: parity unpinned). */
+int amp_ring_sample(const AmpRing* r, uint64_t seed, uint64_t draw, int64_t first_row, int64_t n, float* out_dev,
+                    int64_t out_stride, int64_t* indices_dev, amp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * CSV -> npz motion converter  (replaces motions/data_convert.py:161-390: 30 -> 60 fps

@@ -43,9 +43,9 @@ def sample_times(durations: np.ndarray, seed: int, step: int, index: np.ndarray,
     return ids, times
 
 
-def ring_sample_indices(size: int, seed: int, draw: int, n: int) -> np.ndarray:
-    """Storage rows csrc/ring.hip::ring_sample_kernel draws: floor(word0(Philox(counter=(i, draw), key=seed)) * size / 2^32)."""
-    i = np.arange(n, dtype=np.uint64)
+def ring_sample_indices(size: int, seed: int, draw: int, n: int, first_row: int = 0) -> np.ndarray:
+    """Storage rows csrc/ring.hip::ring_sample_kernel draws: floor(word0(Philox(counter=(first_row + i, draw), key=seed)) * size / 2^32)."""
+    i = np.arange(n, dtype=np.uint64) + np.uint64(first_row)
     r0, _, _, _ = philox4x32_10(i & MASK, i >> np.uint64(32), draw & 0xFFFFFFFF, (draw >> 32) & 0xFFFFFFFF,
                                 seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
     return ((r0 * np.uint64(size)) >> np.uint64(32)).astype(np.int64)

@@ -18,8 +18,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_rccl_world1_allgather_and_bench_collective():
-    from humanoid_amp_amd.distributed import ReplayAllGather, allgather_minibatch
+def test_rccl_world1_allgather_and_update_exchange():
+    from humanoid_amp_amd.distributed import UpdateExchange, allgather_minibatch
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
@@ -29,19 +29,19 @@ def test_rccl_world1_allgather_and_bench_collective():
         full = allgather_minibatch(shard, force_collective=True)  # really goes through RCCL
         torch.cuda.synchronize()
         assert torch.equal(full, shard)
-        table = torch.randn(20000, 166, device="cuda")
-        rg = ReplayAllGather(table, rows=4096, seed=0)
-        out = rg()
-        assert out.shape == (4096, 166)
-        # every gathered row is a row of the table
-        assert bool((out[:8].unsqueeze(1) == table.unsqueeze(0)).all(dim=2).any(dim=1).all())
-        # asynchronous slots (the bench's schedule)
-        rg2 = ReplayAllGather(table, rows=512, seed=1, slots=3)
-        rg2._async = True  # world size 1 would short-circuit: force the real async collective
-        slots = [rg2.start() for _ in range(5)]  # wraps around: slots 0 and 1 are waited and reused
-        rg2.wait_all()
-        assert slots == [0, 1, 2, 0, 1] and all(w is None for w in rg2.works)
-        assert bool((rg2.result(2)[:4].unsqueeze(1) == table.unsqueeze(0)).all(dim=2).any(dim=1).all())
+        # the update's exchange at BASELINE's shape (12 steps x 3 groups x 4096 rows x 166 floats = 97.9 MB), forced through the
+        # asynchronous RCCL collective + the strided re-blocking copy although the world is one rank
+        ex = UpdateExchange(12, 3, 4096, 166, "cuda", group=dist.group.WORLD, force_collective=True)
+        assert ex.batches.data_ptr() != ex.contrib.data_ptr() and ex.bytes_per_rank == 12 * 3 * 4096 * 166 * 4
+        for trial in range(2):                       # the buffers are reused from update to update
+            ex.contrib.normal_()
+            ex.start()
+            got = ex.finish()
+            assert got.shape == (12, 3, 4096, 166) and torch.equal(got, ex.contrib)
+        # without the flag a world of one rank is a pass-through (no copy)
+        ex1 = UpdateExchange(2, 3, 64, 166, "cuda", group=dist.group.WORLD)
+        ex1.start()
+        assert ex1.finish().data_ptr() == ex1.contrib.data_ptr()
         t = torch.tensor([1.5], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the max-over-ranks timing reduction of bench.py
         dist.barrier()

@@ -60,3 +60,27 @@ def test_uniformity_of_the_draw():
     counts = torch.bincount(idx, minlength=50).double().cpu().numpy()
     chi2 = float(((counts - 20000.0) ** 2 / 20000.0).sum())
     assert chi2 < 90.0   # 49 dof: P(chi2 > 85.4) = 0.001
+
+
+def test_first_row_slices_one_minibatch_draw():
+    """A minibatch drawn by W ranks (each its rows [w * r, (w + 1) * r) at first_row = w * r) consumes the variates of ONE
+    batch-size draw: the per-rank index lists are the slices of the whole draw, bit for bit, and match oracle/rng.py."""
+    from humanoid_amp_amd.engine import AmpReplayBuffer
+
+    buf = AmpReplayBuffer(5000, 166, "cuda:0", seed=11)
+    buf.add_samples(torch.randn(3333, 166, generator=torch.Generator().manual_seed(2)).cuda())
+    B = 4096
+    buf._draw = 7
+    rows, idx = buf.sample(B, return_indices=True)
+    assert np.array_equal(idx.cpu().numpy(), orng.ring_sample_indices(3333, 11, 7, B))
+    for world in (2, 8):
+        r = B // world
+        for w in range(world):
+            buf._draw = 7
+            part, pidx = buf.sample(r, return_indices=True, first_row=w * r)
+            assert torch.equal(pidx, idx[w * r:(w + 1) * r]) and torch.equal(part, rows[w * r:(w + 1) * r])
+            assert np.array_equal(pidx.cpu().numpy(), orng.ring_sample_indices(3333, 11, 7, r, first_row=w * r))
+    # counters past 2^32 use the high counter word
+    buf._draw = 1
+    _, hi = buf.sample(64, return_indices=True, first_row=(1 << 32) + 5)
+    assert np.array_equal(hi.cpu().numpy(), orng.ring_sample_indices(3333, 11, 1, 64, first_row=(1 << 32) + 5))
