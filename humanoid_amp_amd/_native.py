@@ -156,6 +156,11 @@ class AmpDiscInputLayout(C.Structure):
                 ("clip", C.c_float), ("plane_scale", C.c_float)]
 
 
+class AmpDiscPlanInfo(C.Structure):
+    _fields_ = [("precision", C.c_int32), ("plan", C.c_int32), ("fused_rows", C.c_int64), ("chunk_rows", C.c_int64),
+                ("fused_min_rows", C.c_int64), ("env_overrides", C.c_int32), ("cu_count", C.c_int32)]
+
+
 class AmpDiscDesc(C.Structure):
     _fields_ = [
         ("in_dim", C.c_int32), ("h1", C.c_int32), ("h2", C.c_int32), ("reserved", C.c_int32),
@@ -207,6 +212,7 @@ SIGNATURES = {
     "amp_disc_set_precision": (C.c_int, [_vp, _i32, _vp]),
     "amp_disc_workspace_bytes": (_i64, [_vp, _i64]),
     "amp_disc_input_layout": (C.c_int, [_vp, C.POINTER(AmpDiscInputLayout)]),
+    "amp_disc_plan_info": (C.c_int, [_vp, _i64, C.POINTER(AmpDiscPlanInfo)]),
     "amp_disc_get_weights": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "amp_disc_trainer_create": (C.c_int, [_vp, C.POINTER(AmpDiscTrainCfg), _vp, _vp, C.c_double, _vp, C.POINTER(_vp)]),
     "amp_disc_trainer_destroy": (C.c_int, [_vp]),

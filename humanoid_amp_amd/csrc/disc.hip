@@ -850,6 +850,28 @@ int amp_disc_input_layout(const AmpDisc* h, AmpDiscInputLayout* out) {
   return AMP_OK;
 }
 
+int amp_disc_plan_info(const AmpDisc* h, int64_t rows, AmpDiscPlanInfo* out) {
+  AMP_REQUIRE(h && out, "amp_disc_plan_info: null argument");
+  AMP_REQUIRE(rows >= 0, "amp_disc_plan_info: negative row count");
+  *out = AmpDiscPlanInfo{};
+  out->precision = h->mode;
+  out->cu_count = dma_cu_count();
+  out->fused_min_rows = fused_min_rows();
+  auto set = [](const char* name) { const char* e = getenv(name); return e && e[0]; };
+  out->env_overrides = (set("AMP_DISC_FUSED") ? AMP_ENV_DISC_FUSED : 0) | (set("AMP_DISC_FUSED_MIN_ROWS") ? AMP_ENV_DISC_FUSED_MIN_ROWS : 0) |
+                       (set("AMP_TRAIN_FORK") ? AMP_ENV_TRAIN_FORK : 0) | (set("AMP_TRAIN_BK32") ? AMP_ENV_TRAIN_BK32 : 0);
+  if (h->mode != AMP_DISC_F16X3) {
+    out->plan = AMP_DISC_PLAN_FP32;
+    out->chunk_rows = rows;
+    return AMP_OK;
+  }
+  out->fused_rows = fused_rows_of(h, rows);
+  const int64_t rest = rows - out->fused_rows;
+  out->chunk_rows = rest > 0 ? f16_chunk_rows(h, rest) : 0;
+  out->plan = f16_plan(h, rest > 0 ? out->chunk_rows : rows);  // kPlan* ids 0..4 ARE the AMP_DISC_PLAN_* values
+  return AMP_OK;
+}
+
 static int style_reward_prescaled_impl(const AmpDisc* h, const void* xs_any, int64_t rows, float scale, const float* task, float task_w,
                                        float style_w, float* logits, float* style, float* combined, void* workspace,
                                        amp_stream_t stream, const CompactLaunch* compact);

@@ -548,6 +548,21 @@ class AmpDiscriminator:
         nat.check(self._lib.amp_disc_input_layout(self._handle, C.byref(lay)), "amp_disc_input_layout")
         return lay
 
+    PLAN_NAMES = {0: "register-staged 64x64 / 128x128", 1: "LDS-DMA 128x128 both layers", 2: "LDS-DMA 256x256 + 256x128",
+                  3: "LDS-DMA 256x256 both layers", 4: "LDS-DMA 128x128 + 64x128", 16: "fp32-MFMA 128x128x16"}
+
+    def plan_info(self, rows: int) -> dict:
+        """Which kernels a style-reward call of ``rows`` rows launches on this handle and which environment switches are set
+        (``amp_disc_plan_info``): ``fused_rows`` leading rows on the one-launch two-layer kernel, the rest in ``chunk_rows``-row
+        (layer 1, layer 2) launch pairs on ``plan``."""
+        p = nat.AmpDiscPlanInfo()
+        nat.check(self._lib.amp_disc_plan_info(self._handle, int(rows), C.byref(p)), "amp_disc_plan_info")
+        env = [name for bit, name in ((1, "AMP_DISC_FUSED"), (2, "AMP_DISC_FUSED_MIN_ROWS"), (4, "AMP_TRAIN_FORK"), (8, "AMP_TRAIN_BK32"))
+               if p.env_overrides & bit]
+        return {"precision": "f32" if p.precision == nat.AMP_DISC_FP32 else "f16x3", "plan": int(p.plan),
+                "plan_name": self.PLAN_NAMES.get(int(p.plan), "?"), "fused_rows": int(p.fused_rows), "chunk_rows": int(p.chunk_rows),
+                "fused_min_rows": int(p.fused_min_rows), "env_overrides": env, "cu_count": int(p.cu_count)}
+
     def style_reward_prescaled(self, scaled: torch.Tensor, task_reward: Optional[torch.Tensor] = None, *,
                                want_logits: bool = False, compact: Optional["EnvStepKernel"] = None):
         """Same as :meth:`style_reward` for an input already scaled, padded and laid out as :meth:`input_layout`
@@ -850,6 +865,7 @@ class AmpDiscriminatorUpdate:
         self.prefetch = bool(prefetch)
         self._side, self._bufs = None, None
         self.group, self.exchange = group, None
+        self.time_phases, self._marks = False, None   # set time_phases: HIP events at the phase boundaries of every update
         if group is not None:
             import torch.distributed as dist
 
@@ -857,9 +873,29 @@ class AmpDiscriminatorUpdate:
             if trainer.batch_size % world != 0:
                 raise nat.AmpEngineError(f"the global minibatch ({trainer.batch_size} rows) must divide over the {world} ranks of the group")
 
+    def _mark(self, name=None):
+        if self.time_phases:
+            if name is None:
+                self._marks = []
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._marks.append((name, ev))
+
+    def phase_ms(self) -> dict:
+        """With ``time_phases``: milliseconds of the last update's phases on the current stream (blocks until the update is done):
+        ``produce`` (this rank's rows of every step), ``exchange`` (the all-gather + re-blocking copy, as far as it is not hidden
+        under the replay append), ``train`` (the optimizer steps + refresh), ``total``."""
+        if not self._marks:
+            return {}
+        self._marks[-1][1].synchronize()
+        out = {name: self._marks[i][1].elapsed_time(ev) for i, (name, ev) in enumerate(self._marks[1:])}
+        out["total"] = self._marks[0][1].elapsed_time(self._marks[-1][1])
+        return out
+
     def update(self, rollout_amp_states: torch.Tensor):
         rows = rollout_amp_states.reshape(-1, rollout_amp_states.shape[-1])
         bs = self.trainer.batch_size
+        self._mark()
         if self.group is not None:
             return self._update_exchanged(rows, bs)
         if rows.shape[0] < bs * self.mini_batches:
@@ -886,6 +922,7 @@ class AmpDiscriminatorUpdate:
             self.replay.add_samples(rows)
         if getattr(self.trainer, "defer_refresh", False):
             self.trainer.refresh()  # the rollouts that follow score with the trained weights
+        self._mark("train")
         return losses
 
     def _update_exchanged(self, rows, bs):
@@ -917,9 +954,11 @@ class AmpDiscriminatorUpdate:
             else:
                 replay.copy_(policy)
             self.motion_dataset.sample(r, out=motion, first_row=ex.first_row)
+        self._mark("produce")
         ex.start()
         self.replay.add_samples(rows)  # the draws above are enqueued ahead of it; the append runs under the collective
         batches = ex.finish()
+        self._mark("exchange")
         losses, self.batches = [], []
         for k in range(n):
             policy, replay, motion = batches[k].unbind(0)

@@ -346,6 +346,50 @@ class HotPath:
         torch.cuda.synchronize(self.device)
 
 
+class AgentSide:
+    """What an AMP agent does with the hot path's output between two rollouts, on the engine (skrl's AMP is
+    third-party: parity unpinned; sizes agents/skrl_g1_walk_amp_cfg.yaml:44-58,64-66,91): a rollout store of the shard's AMP rows
+    (``record()`` after every env step), the replay and motion-dataset rings, the discriminator trainer on the hot path's
+    discriminator, and ``update()`` = one ``AmpDiscriminatorUpdate`` over the stored rollout (with ``group``: the multi-rank flow,
+    ONE all-gather per update).  ``batch_size`` is the GLOBAL minibatch."""
+
+    def __init__(self, hot: HotPath, *, rollouts: int = 16, batch_size: int = 4096, learning_epochs: int = 6, mini_batches: int = 2,
+                 replay_rows: int = 1_000_000, motion_rows: int = 200_000, seed: int = 0, group=None, rank: int = 0):
+        from .engine import AmpDiscriminatorTrainer, AmpDiscriminatorUpdate, AmpReplayBuffer
+
+        self.hot, self.rollouts = hot, int(rollouts)
+        N, C = hot.num_envs, hot.spec.K * hot.spec.D
+        dev = hot.device
+        self.store = torch.empty((self.rollouts, N, C), device=dev)
+        self.store.copy_(hot.kernel.amp_observation_buffer.view(1, N, C).expand(self.rollouts, N, C))  # valid rows before the first rollout
+        self.replay = AmpReplayBuffer(int(replay_rows), C, dev, seed=seed + 1)
+        self.motion_dataset = AmpReplayBuffer(int(motion_rows), C, dev, seed=seed + 2)
+        # the motion dataset: expert rows at uniformly drawn (clip, time), as the agent fills it from collect_reference_motions
+        # (g1_amp_env.py:445-486); every rank draws its own
+        ml = hot.motion
+        gen = np.random.default_rng(seed + 17 + 7919 * rank)
+        durations = np.asarray(ml.durations, dtype=np.float64).reshape(-1)
+        left = int(motion_rows)
+        while left > 0:
+            n = min(left, 65536)
+            ids = gen.integers(0, len(durations), n)
+            times = gen.uniform(0.0, 1.0, n) * durations[ids]
+            self.motion_dataset.add_samples(ml.collect_reference(torch.from_numpy(times), torch.from_numpy(ids), hot.spec.K))
+            left -= n
+        self.trainer = AmpDiscriminatorTrainer(hot.disc, batch_size=batch_size, defer_refresh=True)
+        self.updater = AmpDiscriminatorUpdate(self.trainer, self.replay, self.motion_dataset, learning_epochs=learning_epochs,
+                                              mini_batches=mini_batches, seed=seed + 3 + rank, group=group)
+        self._slot = 0
+
+    def record(self) -> None:
+        """Store the step's AMP rows (what skrl's rollout memory keeps of ``extras["amp_obs"]``)."""
+        self.store[self._slot % self.rollouts].copy_(self.hot.kernel.amp_observation_buffer.view(self.hot.num_envs, -1))
+        self._slot += 1
+
+    def update(self):
+        return self.updater.update(self.store)
+
+
 def make_disc_weights(in_dim: int, seed: int = 0, hidden=(1024, 512)):
     """torch.nn.Linear default init under torch.manual_seed(seed) -> [(W, b)] * 3 on the CPU."""
     torch.manual_seed(seed)

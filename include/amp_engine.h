@@ -449,6 +449,25 @@ typedef struct {
   float plane_scale;       /* F16_BLOCKS: the power of two s with s * clip < 2^15 */
 } AmpDiscInputLayout;
 int amp_disc_input_layout(const AmpDisc* h, AmpDiscInputLayout* out);
+/* Which kernels a style-reward call of `rows` rows would launch on this handle, and which process-environment switches are in
+ * force (they are read once, at the first call that needs them: AMP_DISC_FUSED=0 switches the fused two-layer plan off,
+ * AMP_DISC_FUSED_MIN_ROWS moves its threshold, AMP_TRAIN_FORK=0 / AMP_TRAIN_BK32=0 change the training step's schedule / k-tile:
+ * A/B switches for measurements, never needed for correctness -- every plan gives the same bits per row).  Pure host
+ * arithmetic; a run can log the plan it took.  (Replaces nothing in the reference: skrl's discriminator forward is one
+ * torch.nn.Sequential call, agents/skrl_g1_walk_amp_cfg.yaml:31-39.) */
+enum { AMP_DISC_PLAN_REGISTER = 0, AMP_DISC_PLAN_DMA_128 = 1, AMP_DISC_PLAN_DMA_256_128 = 2, AMP_DISC_PLAN_DMA_256 = 3,
+       AMP_DISC_PLAN_DMA_128_64 = 4, AMP_DISC_PLAN_FP32 = 16 };
+enum { AMP_ENV_DISC_FUSED = 1, AMP_ENV_DISC_FUSED_MIN_ROWS = 2, AMP_ENV_TRAIN_FORK = 4, AMP_ENV_TRAIN_BK32 = 8 };
+typedef struct {
+  int32_t precision;        /* AMP_DISC_F16X3 / AMP_DISC_FP32 */
+  int32_t plan;             /* AMP_DISC_PLAN_*: tiles of the two-kernel (layer 1, layer 2) launches that take the rows NOT on the fused kernel */
+  int64_t fused_rows;       /* leading rows that run both layers as ONE launch (disc_mlp_fused_kernel); 0: none */
+  int64_t chunk_rows;       /* rows per (layer 1, layer 2) launch pair of the remaining rows */
+  int64_t fused_min_rows;   /* the fused plan's threshold in force (INT64_MAX: switched off) */
+  int32_t env_overrides;    /* AMP_ENV_* bits: which of the environment switches are SET in this process */
+  int32_t cu_count;         /* compute units the plans were sized for */
+} AmpDiscPlanInfo;
+int amp_disc_plan_info(const AmpDisc* h, int64_t rows, AmpDiscPlanInfo* out);
 /* amp_obs_dev [rows, in_dim] (row stride in elements) -> logits [rows], style [rows] =
  * -log(max(1 - sigmoid(logit), 1e-4)) * reward_scale, combined = task_w * task + style_w * style.
  * logits / style / task / combined may be NULL.

@@ -53,7 +53,7 @@ def test_struct_layouts_match_the_header(tmp_path):
     from humanoid_amp_amd import _native as nat
 
     structs = {"AmpMotionDesc": nat.AmpMotionDesc, "AmpEnvCfg": nat.AmpEnvCfg, "AmpSimState": nat.AmpSimState,
-               "AmpEnvBuffers": nat.AmpEnvBuffers, "AmpDiscDesc": nat.AmpDiscDesc, "AmpDiscInputLayout": nat.AmpDiscInputLayout,
+               "AmpEnvBuffers": nat.AmpEnvBuffers, "AmpDiscDesc": nat.AmpDiscDesc, "AmpDiscInputLayout": nat.AmpDiscInputLayout, "AmpDiscPlanInfo": nat.AmpDiscPlanInfo,
                "AmpResetArgs": nat.AmpResetArgs, "AmpCommandArgs": nat.AmpCommandArgs, "AmpCompactArgs": nat.AmpCompactArgs, "AmpScatterRows": nat.AmpScatterRows, "AmpRewardLogArgs": nat.AmpRewardLogArgs, "AmpPrePhysicsArgs": nat.AmpPrePhysicsArgs, "AmpHotStepArgs": nat.AmpHotStepArgs, "AmpDiscTrainCfg": nat.AmpDiscTrainCfg, "AmpKinModel": nat.AmpKinModel,
                "AmpConvertOutputs": nat.AmpConvertOutputs}
     lines = ["#include <stddef.h>", "#include <stdio.h>", '#include "amp_engine.h"', "int main(void) {"]
