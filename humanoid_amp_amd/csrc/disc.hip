@@ -412,6 +412,10 @@ static int f16_kernels_init() {
   AMP_HIP((dma_kernel_init<1, 2, 1, 4>()));
   AMP_HIP((dma_kernel_init<1, 1, 1, 4>()));
   AMP_HIP((dma_kernel_init<1, 1, 1>()));
+  AMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_mlp_fused_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              FusedLds<4>::kBytes));
+  AMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_mlp_fused_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              FusedLds<5>::kBytes));
   AMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_mlp_fused_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               FusedLds<6>::kBytes));
   if (dev >= 0 && dev < 64) done[dev] = true;
@@ -452,7 +456,8 @@ static int64_t fused_min_rows() {
 // column-split two-kernel plans, which scale down (measured, us per step fused / split / unfused: 40 960 rows 231.9 / - / 225.3,
 // 49 152 rows 243.6 / - / 241.6 before the split; profiles/r04_fused_mlp_kernel.md).  Any split gives the same bits per row.
 static int64_t fused_rows_of(const AmpDisc* h, int64_t rows) {
-  if (!(h->h2 == kFusedN2 && h->k1h == 192 && h->h1 % 32 == 0 && h->h1 <= 1024) || rows < fused_min_rows() || rows < kFusedRows) return 0;
+  // input widths K D in (96, 192]: 4, 5 or 6 k-blocks of activation fragments resident in registers (KX = k1h / 32)
+  if (!(h->h2 == kFusedN2 && h->k1h >= 128 && h->k1h <= 192 && h->h1 % 32 == 0 && h->h1 <= 1024) || rows < fused_min_rows() || rows < kFusedRows) return 0;
   const int64_t per_round = (int64_t)dma_cu_count() * kFusedRows;
   const int64_t full = rows / per_round * per_round, rem = rows - full;
   return rem >= fused_min_rows() || rem == 0 ? rows : full;
@@ -490,7 +495,9 @@ static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* a
     f.range = h->range; f.amax = amax; f.h1 = h->h1; f.partial = partial;
     const unsigned grid = (unsigned)((n_fused + kFusedRows - 1) / kFusedRows);
     { amp::TraceScope trace__("disc_mlp_fused_kernel", st);
-      disc_mlp_fused_kernel<6><<<grid, kFusedThreads, FusedLds<6>::kBytes, st>>>(f);
+      if (h->k1h == 128) disc_mlp_fused_kernel<4><<<grid, kFusedThreads, FusedLds<4>::kBytes, st>>>(f);
+      else if (h->k1h == 160) disc_mlp_fused_kernel<5><<<grid, kFusedThreads, FusedLds<5>::kBytes, st>>>(f);
+      else disc_mlp_fused_kernel<6><<<grid, kFusedThreads, FusedLds<6>::kBytes, st>>>(f);
     }
     rc = launch_status("disc_mlp_fused_kernel");
     if (rc != AMP_OK) return rc;
@@ -589,6 +596,14 @@ __global__ __launch_bounds__(kBlock) void split_weights_kernel(const float* __re
   _Float16* blk = blk_out + r * (2 * (int64_t)kp) + (c >> 5) * 64 + (c & 31);
   *reinterpret_cast<h4*>(blk) = p0;
   *reinterpret_cast<h4*>(blk + 32) = p1;
+}
+
+// disc_weight_range_kernel keeps its accumulators and workgroup ticket in the record between launches (the finisher clears them).
+// A launch that faulted, or two refreshes of one handle in flight on different streams, would leave them non-zero and every later
+// refresh would publish partial maxima: the entries off the hot path (amp_disc_set_weights, amp_disc_trainer_create) re-zero them.
+int disc_range_reset(AmpDisc* h, hipStream_t st) {
+  AMP_HIP(hipMemsetAsync(reinterpret_cast<char*>(h->range) + offsetof(DiscRange, raw), 0, sizeof(unsigned) * 5, st));
+  return AMP_OK;
 }
 
 static int f16_refresh(AmpDisc* h, hipStream_t st) {
@@ -719,6 +734,8 @@ int amp_disc_set_weights(AmpDisc* h, const AmpDiscDesc* d, amp_stream_t stream) 
     disc_pad_rows_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(d->w1, h->h1, h->in_dim, h->k1p, h->w1p);
   }
   int rc = launch_status("disc_pad_rows_kernel");
+  if (rc != AMP_OK) return rc;
+  rc = disc_range_reset(h, st);
   if (rc != AMP_OK) return rc;
   return f16_refresh(h, st);
 }

@@ -109,13 +109,16 @@ __global__ __launch_bounds__(kFusedThreads, 2) void disc_mlp_fused_kernel(FusedA
   // 8 rows per kbx, 4 KX pieces per k-block: wave w issues pieces 3 w .. 3 w + 2 (KX = 6).  W2 half hf (256 LDS rows): LDS row
   // rho = 64 wn' + r holds column 128 wn' + 64 hf + r; 32 pieces, wave w issues 4 w .. 4 w + 3.  Lane l of a piece: row
   // 8 j + (l >> 3), stored chunk l & 7 = source chunk (l & 7) ^ ((row >> 1) & 7).
+  // KX = 5 (20 pieces on 8 waves x 3): the last four slots re-issue pieces 16 .. 19 -- the same bytes to the same LDS addresses a
+  // second time -- so that every wave issues the same NUMBER of pieces and the counted vmcnt waits stay wave-independent.
   constexpr int NP1 = (4 * KX + 7) / 8, NP2 = 4;
   uint32_t off1[NP1], off2[2];  // off2: pieces t and t + 2 differ by 16 rows (same swizzle): a wave-uniform + 16 pitch2 on the base
   int dst1[NP1];
   const uint32_t pitch1 = KX * 128u, pitch2 = (uint32_t)nq * 128u;  // bytes per weight row (block layout)
 #pragma unroll
   for (int t = 0; t < NP1; ++t) {
-    const int p = wave * NP1 + t;
+    int p = wave * NP1 + t;
+    if (p >= 4 * KX) p -= 4;
     const int kbx = p >> 2, j = p & 3;
     const int rho = 8 * j + (lane >> 3), u = rho >> 4, i = rho & 15;
     const int unit = 8 * (i >> 2) + 4 * u + (i & 3);
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(kFusedThreads, 2) void disc_mlp_fused_kernel(FusedA
     for (int t = 0; t < NP2; ++t)
       __builtin_amdgcn_global_load_lds((gptr_t)(src + (t >> 1) * (16 * (int64_t)pitch2) + off2[t & 1]), (lptr_t)(dst + t * 1024), 16, 0, 0);
   };
-  static_assert((4 * KX) % 8 == 0 && NP1 == 3 && NP2 == 4, "the counted vmcnt waits are written for 3 + 4 pieces per wave");
+  static_assert(KX >= 4 && KX <= 6 && 8 * NP1 - 4 * KX <= 4 && NP2 == 4, "piece plan: 8 waves x NP1 slots cover the 4 KX pieces (+ <= 4 repeats)");
 
   // prologue: W2a(0), W1(0) -- then the steady issue order W2b(q), W2a(q + 1), W1(q + 1) of the interval heads.  Everything the
   // first phase needs is REQUESTED before anything is awaited (stages, activation fragments above, the raw bias, the range
@@ -193,10 +196,23 @@ __global__ __launch_bounds__(kFusedThreads, 2) void disc_mlp_fused_kernel(FusedA
     // puts this wave's 36 first; its epilogue then runs under the partner's remaining MFMAs.
     __builtin_amdgcn_s_setprio(2);
 #endif
+#if defined(AMP_FUSED_XP_W1_READS)
+    // ABLATION builds only (tools/build_variant.sh ... -DAMP_FUSED_XP_W1_READS=2 / 6; results are WRONG): the W1 fragments are read
+    // for every AMP_FUSED_XP_W1_READS-th k-block only and reused for the others -- the same MFMAs on half (or a sixth of) layer 1's
+    // LDS fragment reads: what a kernel whose W1 fragments fed two (six) row blocks could gain at most.
+    h8 w00{}, w01{}, w10{}, w11{};
+#endif
 #pragma unroll
     for (int kb = 0; kb < KX; ++kb) {
+#if defined(AMP_FUSED_XP_W1_READS)
+      if (kb % AMP_FUSED_XP_W1_READS == 0) {
+        w00 = *reinterpret_cast<const h8*>(s1 + kb * 4096 + ch0); w01 = *reinterpret_cast<const h8*>(s1 + kb * 4096 + ch1);
+        w10 = *reinterpret_cast<const h8*>(s1 + kb * 4096 + 2048 + ch0); w11 = *reinterpret_cast<const h8*>(s1 + kb * 4096 + 2048 + ch1);
+      }
+#else
       const h8 w00 = *reinterpret_cast<const h8*>(s1 + kb * 4096 + ch0), w01 = *reinterpret_cast<const h8*>(s1 + kb * 4096 + ch1);
       const h8 w10 = *reinterpret_cast<const h8*>(s1 + kb * 4096 + 2048 + ch0), w11 = *reinterpret_cast<const h8*>(s1 + kb * 4096 + 2048 + ch1);
+#endif
       a0 = mfma16(w00, x[kb][1], a0);
       a1 = mfma16(w10, x[kb][1], a1);
       a0 = mfma16(w01, x[kb][0], a0);
@@ -268,15 +284,15 @@ __global__ __launch_bounds__(kFusedThreads, 2) void disc_mlp_fused_kernel(FusedA
   for (int a = 0; a < 4; ++a) hf0[a] = hf1[a] = h8{0, 0, 0, 0, 0, 0, 0, 0};
   // (Two loops, one per group -- the group is wave-uniform, and in ONE loop with a branch per interval the compiler has to keep
   //  hf0 / hf1 alive through the other group's phase A: 420 B of scratch.  Both loops execute the same barriers.)
+  // younger pieces that stay in flight behind the awaited stage: W1(q) + W2b(q) behind W2a(q) (NP1 + NP2 = 7 at KX = 5 / 6, 6 at
+  // KX = 4), W2a(q + 1) behind W2b(q) (NP2 = 4), nothing behind W1(q + 1)
   auto end_interval = [&](auto younger_c) {
     constexpr int Y = decltype(younger_c)::value;
-    if constexpr (Y == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
-    else if constexpr (Y == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(Y) : "memory");
     __builtin_amdgcn_s_barrier();
   };
-  using y7 = std::integral_constant<int, 7>;
-  using y4 = std::integral_constant<int, 4>;
+  using y7 = std::integral_constant<int, NP1 + NP2>;
+  using y4 = std::integral_constant<int, NP2>;
   using y0 = std::integral_constant<int, 0>;
   int m3 = 0;  // (2 q) % 3
   AMP_FUSED_STAMP(0);

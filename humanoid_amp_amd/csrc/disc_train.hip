@@ -25,6 +25,7 @@ struct DiscParams {
 };
 DiscParams disc_params(AmpDisc* h);
 int disc_refresh_derived(AmpDisc* h, hipStream_t st);  // after the weights changed (split planes, ...)
+int disc_range_reset(AmpDisc* h, hipStream_t st);      // zero the range record's accumulators / ticket (off the hot path)
 
 static inline int64_t up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
@@ -922,6 +923,10 @@ int amp_disc_trainer_create(AmpDisc* disc, const AmpDiscTrainCfg* cfg, const dou
   t->disc = disc;
   t->cfg = *cfg;
   t->p = disc_params(disc);
+  if (disc_range_reset(disc, (hipStream_t)stream) != AMP_OK) {
+    delete t;
+    return AMP_ERR_HIP;
+  }
   t->max_rows = up(cfg->max_rows_per_group, 16);
   t->kN = (int)up(t->p.k1p, 64);
   const DiscParams& p = t->p;

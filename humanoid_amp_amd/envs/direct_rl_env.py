@@ -83,7 +83,13 @@ class DirectRLEnv:
             torch.manual_seed(seed)
             if hasattr(self, "_reset_seed"):  # the engine's counter-based draws follow the run seed as torch.rand does
                 if self._graph is not None and int(seed) != self._reset_seed:
-                    self._graph = None  # a captured step has the old key baked into its launches: back to eager (capture again)
+                    # a captured step has the old key baked into its launches: back to eager until capture_step() is called again.
+                    # `graph_actions` stays the same static buffer, so `step(env.graph_actions)` keeps working (eagerly).
+                    import warnings
+
+                    warnings.warn("reset(seed=...) with a new seed dropped the captured step graph: the env steps eagerly until "
+                                  "capture_step() is called again", RuntimeWarning, stacklevel=2)
+                    self._graph = None
                 self._reset_seed = int(seed)
         self._reset_idx(None)
         return self._get_observations(), self.extras
@@ -139,9 +145,10 @@ class DirectRLEnv:
 
     @property
     def graph_actions(self) -> torch.Tensor | None:
-        """The captured step's static action buffer (``None`` before ``capture_step``): ``step(env.graph_actions)`` after
-        writing the actions into it replays without the per-step copy."""
-        return getattr(self, "_graph_actions", None) if self._graph is not None else None
+        """The captured step's static action buffer (``None`` before the first ``capture_step``): ``step(env.graph_actions)``
+        after writing the actions into it replays without the per-step copy.  It outlives a dropped graph (``reset`` with a new
+        seed): the same call then steps eagerly on it."""
+        return getattr(self, "_graph_actions", None)
 
     def _after_replay(self):
         """Refresh per-step Python objects (``extras``) after a graph replay; tasks override."""

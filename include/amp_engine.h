@@ -583,7 +583,10 @@ int amp_disc_trainer_destroy(AmpDiscTrainer* t);
  * (skrl's AMP._update is third-party; shapes: agents/skrl_g1_walk_amp_cfg.yaml:31-39, discriminator_batch_size :91.) */
 int amp_disc_train_tt_plan(int32_t M, int32_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int32_t split, int32_t* bm,
                            int32_t* bn, int32_t* slices);
-/* With cfg.defer_refresh: bring the attached AmpDisc's inference-side derived data up to date with the trained weights / scaler. */
+/* With cfg.defer_refresh: bring the attached AmpDisc's inference-side derived data up to date with the trained weights / scaler.
+ * RULE: at most ONE refresh of a handle in flight (this call, a non-deferred amp_disc_train_step, amp_disc_set_weights: issue them
+ * on one stream, or order the streams) -- the refresh kernel keeps a workgroup ticket in the handle's range record between launches;
+ * amp_disc_set_weights and amp_disc_trainer_create re-zero it, so a faulted launch does not poison later refreshes. */
 int amp_disc_trainer_refresh(AmpDiscTrainer* t, amp_stream_t stream);
 /* Copies the running statistics (fp64 [in_dim]) into caller-owned device buffers; *count (host) = samples seen. */
 int amp_disc_trainer_scaler(const AmpDiscTrainer* t, double* mean_out_dev, double* var_out_dev, double* count,

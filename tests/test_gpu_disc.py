@@ -168,7 +168,7 @@ def test_graph_replay_matches_eager():
 
 @pytest.mark.parametrize("precision,bar", [("f16x3", 1e-6), ("f32", 1e-6)])
 @pytest.mark.parametrize("in_dim,rows", [(166, 4096), (830, 777), (162, 70000), (166, 20000), (166, 30001), (830, 49153),
-                                         (166, 2500), (166, 3500), (830, 5000)])
+                                         (166, 2500), (166, 3500), (830, 5000), (130, 30001), (142, 65536), (128, 33000)])
 def test_gemm_engines_vs_fp64(precision, bar, in_dim, rows):
     """Both GEMM engines (fp16-split default, fp32 MFMA) must be as accurate as an fp32 forward: <= 1e-6 against the
     fp64 evaluation of the same fp32 weights on O(1) logits, a tenth of the path's 1e-5 budget.  The row counts walk
@@ -334,11 +334,12 @@ def test_set_weights_in_place():
         disc.set_weights(dev(odisc.make_weights(162, seed=1)))
 
 
-@pytest.mark.parametrize("in_dim", [166, 830])
+@pytest.mark.parametrize("in_dim", [166, 830, 130, 142, 100])
 def test_a_rows_logit_does_not_depend_on_the_kernel_plan(in_dim):
     """The same 1 500 rows scored inside batches that select every kernel plan of the fp16 engine -- register-staged 64 x 64
     tiles (2 000 rows), LDS-DMA 128 x 128 + 64 x 128 on the four-stage ring (3 500) and on two stages (5 000), 128 x 128 (9 000,
-    20 000), 256 x 256 + 256 x 128 (14 000), and at in_dim 166 the fused two-layer kernel: one ragged round (30 000), a full round + a
+    20 000), 256 x 256 + 256 x 128 (14 000), and at in_dim 166 / 142 / 130 / 100 (6 / 5 / 5 / 4 k-blocks of activation fragments: the
+    23-DoF D = 71 variant of configs[1] is K D = 142) the fused two-layer kernel: one ragged round (30 000), a full round + a
     column-split remainder (40 000: 32 768 + 7 232), two rounds (58 000) and two full rounds + a remainder (70 000); at in_dim 830
     256 x 256 tiles (30 000, ragged last tile moved up) and 32 768-row chunks -- give the
     same logits and style rewards bit for bit: every kernel of a layer issues the same MFMA shape in the same k order and reduces

@@ -8,14 +8,16 @@ mkdir -p "$out"
 for rep in 1 2; do
   for v in base "$@"; do
     if [ "$v" = base ]; then lib=""; n=base; else lib=$(readlink -f "$v"); n=$(basename "$v" .so); fi
-    AMP_ENGINE_LIB="$lib" timeout -k 10 200 python bench.py --no-dropin --no-configs --steps 100 > "$out/bench_${n}_$rep.json" 2>/dev/null
-    python - "$out/bench_${n}_$rep.json" "$n" <<'PY'
+    AMP_ENGINE_LIB="$lib" timeout -k 10 200 python bench.py --no-dropin --no-configs --no-update --no-cpu-baseline --no-fp32-engine --steps 100 > "$out/bench_${n}_$rep.json" 2> "$out/bench_${n}_$rep.err"
+    python - "$out/bench_${n}_$rep.json" "$out/bench_${n}_$rep.err" "$n" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-k = d["kernel_us_per_step"]
+det = [json.loads(l[len("[bench detail] "):]) for l in open(sys.argv[2], errors="replace") if l.startswith("[bench detail] ")][-1]
+k = det["kernel_us_per_step"]
 gemm = "  ".join(f"{n.replace('disc_', '').replace('_kernel', '')} {v:6.1f}" for n, v in k.items() if n.startswith("disc_"))
-print(f"{sys.argv[2]:28s} {d['ms_per_step']*1e3:7.1f} us/step  env {k['env_step_reference_kernel']:6.1f}  {gemm}  "
-      f"tail {k['step_tail_kernel']:4.1f} | 8192: {d['envs_8192']['ms_per_step']*1e3:5.1f}  4096: {d['envs_4096']['ms_per_step']*1e3:5.1f}")
+r = d["roofline"]
+print(f"{sys.argv[3]:28s} {d['ms_per_step']*1e3:7.1f} us/step  env {k['env_step_reference_kernel']:6.1f}  {gemm}  "
+      f"tail {k['step_tail_kernel']:4.1f} | 8192: {r['envs_8192']['ms_per_step']*1e3:5.1f}  4096: {r['envs_4096']['ms_per_step']*1e3:5.1f}")
 PY
   done
 done

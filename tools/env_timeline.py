@@ -1,7 +1,8 @@
 """Per-workgroup phase stamps of the fused env-step + expert launch (diagnostic build of the engine: env_step.hip compiled with
 -DAMP_ENV_TIMELINE; the product library carries no stamp).  Build here, run on the GPU box:
    tools/build_variant.sh env_tl env_step.hip -DAMP_ENV_TIMELINE
-   gpurun -- 'cp tools/bin/libamp_env_tl.so humanoid_amp_amd/csrc/libamp_engine.so && python tools/env_timeline.py [envs] [workload]'"""
+   gpurun -- 'AMP_ENGINE_LIB=tools/bin/libamp_env_tl.so python tools/env_timeline.py [envs] [workload]'
+(AMP_ENGINE_LIB loads the variant instead of the in-tree library: nothing is copied over libamp_engine.so)"""
 import ctypes as C
 import sys
 
