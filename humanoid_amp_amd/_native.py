@@ -213,6 +213,7 @@ SIGNATURES = {
     "amp_disc_workspace_bytes": (_i64, [_vp, _i64]),
     "amp_disc_input_layout": (C.c_int, [_vp, C.POINTER(AmpDiscInputLayout)]),
     "amp_disc_plan_info": (C.c_int, [_vp, _i64, C.POINTER(AmpDiscPlanInfo)]),
+    "amp_disc_set_plan": (C.c_int, [_vp, _i32, _i64]),
     "amp_disc_get_weights": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "amp_disc_trainer_create": (C.c_int, [_vp, C.POINTER(AmpDiscTrainCfg), _vp, _vp, C.c_double, _vp, C.POINTER(_vp)]),
     "amp_disc_trainer_destroy": (C.c_int, [_vp]),

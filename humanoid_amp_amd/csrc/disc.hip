@@ -50,6 +50,8 @@ struct AmpDisc {
   _Float16* w1b;      // the same planes in block layout [h1][k1h / 32][2][32] (LDS-DMA kernels)
   _Float16* w2b;      // [h2][h1 / 32][2][32]
   DiscRange* range;   // device
+  // per-handle plan overrides (amp_disc_set_plan; -1 = automatic: the process environment, then the measured defaults)
+  int64_t ovr_fused_min_rows = -1;   // >= 128: the fused two-layer plan's threshold; INT64_MAX: plan off
 };
 
 namespace amp {
@@ -441,7 +443,8 @@ enum { kPlanRegister = 0, kPlanDmaSmall = 1, kPlanDmaMid = 2, kPlanDmaLarge = 3,
 // Fused two-layer kernel (disc_mlp_fused.hpp): one workgroup per 128 rows and all 512 output columns, so it needs at least one
 // workgroup per CU to pay (AMP_DISC_FUSED_MIN_ROWS overrides the threshold, AMP_DISC_FUSED=0 switches the plan off: A/B runs and
 // the plan-independence tests); shapes: h2 = 512 (the accumulator tile), K D padded to 192 (activation fragments in registers).
-static int64_t fused_min_rows() {
+static int64_t fused_min_rows(const AmpDisc* h) {
+  if (h && h->ovr_fused_min_rows >= 0) return h->ovr_fused_min_rows;
   static int64_t v = -1;
   if (v < 0) {
     const char* off = getenv("AMP_DISC_FUSED");
@@ -457,10 +460,10 @@ static int64_t fused_min_rows() {
 // 49 152 rows 243.6 / - / 241.6 before the split; profiles/r04_fused_mlp_kernel.md).  Any split gives the same bits per row.
 static int64_t fused_rows_of(const AmpDisc* h, int64_t rows) {
   // input widths K D in (96, 192]: 4, 5 or 6 k-blocks of activation fragments resident in registers (KX = k1h / 32)
-  if (!(h->h2 == kFusedN2 && h->k1h >= 128 && h->k1h <= 192 && h->h1 % 32 == 0 && h->h1 <= 1024) || rows < fused_min_rows() || rows < kFusedRows) return 0;
+  if (!(h->h2 == kFusedN2 && h->k1h >= 128 && h->k1h <= 192 && h->h1 % 32 == 0 && h->h1 <= 1024) || rows < fused_min_rows(h) || rows < kFusedRows) return 0;
   const int64_t per_round = (int64_t)dma_cu_count() * kFusedRows;
   const int64_t full = rows / per_round * per_round, rem = rows - full;
-  return rem >= fused_min_rows() || rem == 0 ? rows : full;
+  return rem >= fused_min_rows(h) || rem == 0 ? rows : full;
 }
 static int f16_plan(const AmpDisc* h, int64_t rows) {
   if (h->h1 % kDmaBN != 0 || h->h2 % kDmaBN != 0) return kPlanRegister;   // the LDS-DMA tiles need 256-column multiples
@@ -867,13 +870,21 @@ int amp_disc_input_layout(const AmpDisc* h, AmpDiscInputLayout* out) {
   return AMP_OK;
 }
 
+int amp_disc_set_plan(AmpDisc* h, int32_t fused, int64_t fused_min_rows_) {
+  AMP_REQUIRE(h, "amp_disc_set_plan: null handle");
+  AMP_REQUIRE(fused >= -1 && fused <= 1, "amp_disc_set_plan: fused must be -1 (automatic), 0 (off) or 1 (on)");
+  AMP_REQUIRE(fused_min_rows_ == -1 || fused_min_rows_ >= kFusedRows, "amp_disc_set_plan: fused_min_rows must be -1 or >= %d", kFusedRows);
+  h->ovr_fused_min_rows = fused == 0 ? INT64_MAX : (fused_min_rows_ >= 0 ? fused_min_rows_ : (fused == 1 ? 24576 : -1));
+  return AMP_OK;
+}
+
 int amp_disc_plan_info(const AmpDisc* h, int64_t rows, AmpDiscPlanInfo* out) {
   AMP_REQUIRE(h && out, "amp_disc_plan_info: null argument");
   AMP_REQUIRE(rows >= 0, "amp_disc_plan_info: negative row count");
   *out = AmpDiscPlanInfo{};
   out->precision = h->mode;
   out->cu_count = dma_cu_count();
-  out->fused_min_rows = fused_min_rows();
+  out->fused_min_rows = fused_min_rows(h);
   auto set = [](const char* name) { const char* e = getenv(name); return e && e[0]; };
   out->env_overrides = (set("AMP_DISC_FUSED") ? AMP_ENV_DISC_FUSED : 0) | (set("AMP_DISC_FUSED_MIN_ROWS") ? AMP_ENV_DISC_FUSED_MIN_ROWS : 0) |
                        (set("AMP_TRAIN_FORK") ? AMP_ENV_TRAIN_FORK : 0) | (set("AMP_TRAIN_BK32") ? AMP_ENV_TRAIN_BK32 : 0);

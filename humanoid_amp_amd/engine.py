@@ -551,6 +551,12 @@ class AmpDiscriminator:
     PLAN_NAMES = {0: "register-staged 64x64 / 128x128", 1: "LDS-DMA 128x128 both layers", 2: "LDS-DMA 256x256 + 256x128",
                   3: "LDS-DMA 256x256 both layers", 4: "LDS-DMA 128x128 + 64x128", 16: "fp32-MFMA 128x128x16"}
 
+    def set_plan(self, *, fused: Optional[bool] = None, fused_min_rows: Optional[int] = None) -> None:
+        """Per-handle kernel-plan override (``amp_disc_set_plan``; ``None`` = automatic): ``fused`` allows / forbids the one-launch
+        two-layer kernel, ``fused_min_rows`` moves its threshold.  Every plan scores a row the same bit for bit."""
+        f = -1 if fused is None else int(bool(fused))
+        nat.check(self._lib.amp_disc_set_plan(self._handle, f, -1 if fused_min_rows is None else int(fused_min_rows)), "amp_disc_set_plan")
+
     def plan_info(self, rows: int) -> dict:
         """Which kernels a style-reward call of ``rows`` rows launches on this handle and which environment switches are set
         (``amp_disc_plan_info``): ``fused_rows`` leading rows on the one-launch two-layer kernel, the rest in ``chunk_rows``-row

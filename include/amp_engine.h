@@ -468,6 +468,11 @@ typedef struct {
   int32_t cu_count;         /* compute units the plans were sized for */
 } AmpDiscPlanInfo;
 int amp_disc_plan_info(const AmpDisc* h, int64_t rows, AmpDiscPlanInfo* out);
+/* Per-handle plan choice, overriding the process environment and the measured defaults (what tests and A/B measurements use
+ * instead of environment variables): fused = -1 automatic / 0 never / 1 allowed with the threshold `fused_min_rows` (-1: the default
+ * 24 576 rows).  Host-side state of the handle: call it between launches, not concurrently with them.  Every plan scores a row
+ * the same bit for bit. */
+int amp_disc_set_plan(AmpDisc* h, int32_t fused, int64_t fused_min_rows);
 /* amp_obs_dev [rows, in_dim] (row stride in elements) -> logits [rows], style [rows] =
  * -log(max(1 - sigmoid(logit), 1e-4)) * reward_scale, combined = task_w * task + style_w * style.
  * logits / style / task / combined may be NULL.
