@@ -161,15 +161,20 @@ __global__ __launch_bounds__(kBlock) void dh2_kernel(const float* __restrict__ d
 //   dH2[i][c] = H2[i][c] > 0 ? dlogit[i] * w3[c] : 0
 //   part[0][ch][c] = sum_i H2[i][c] * dlogit[i]   (-> gw3)      part[1][ch][c] = sum_i dH2[i][c]   (-> gb2)
 //   part[2][ch][0] = sum_i dlogit[i]              (-> gb3; column block 0 only)
+// `planes` (fp16-split step; cols % 32 == 0): also the two fp16 planes of plane_scale(bound[0]) * dH2 in block layout
+// [rows][cols / 32][2][32] -- the A operand of dH1 = dH2 W2 on the fp16 pipe -- so that no separate split pass reads dH2 back.
 __global__ __launch_bounds__(kBlock) void dh2_colsum_kernel(const float* __restrict__ dlogit, const float* __restrict__ w3,
                                                             const float* __restrict__ H2, int64_t rows, int cols,
-                                                            float* __restrict__ dH2, float* __restrict__ part) {
+                                                            float* __restrict__ dH2, float* __restrict__ part,
+                                                            _Float16* __restrict__ planes, const float* __restrict__ bound) {
   __shared__ float red[3][4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), p = threadIdx.x >> 6;
   const int64_t per = (rows + kChunks - 1) / kChunks;
   const int64_t lo = (int64_t)blockIdx.y * per, hi = lo + per < rows ? lo + per : rows;
   float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
   const float w = c < cols ? w3[c] : 0.0f;
+  const float sp = planes ? plane_scale(bound[0]) : 0.0f;
+  _Float16* const pl = planes ? planes + (c >> 5) * 64 + (c & 31) : nullptr;
   if (c < cols)
     for (int64_t i = lo + p; i < hi; i += 4) {
       const float h = H2[i * cols + c], dl = dlogit[i];
@@ -178,6 +183,12 @@ __global__ __launch_bounds__(kBlock) void dh2_colsum_kernel(const float* __restr
       s0 += v;
       const float d = h > 0.0f ? dl * w : 0.0f;   // dh2_kernel
       dH2[i * cols + c] = d;
+      if (pl) {
+        const float sd = d * sp;
+        const _Float16 a = (_Float16)sd;
+        pl[i * (2 * (int64_t)cols)] = a;
+        pl[i * (2 * (int64_t)cols) + 32] = (_Float16)(sd - (float)a);
+      }
       s1 += d;
       if (c == 0) s2 += dl;
     }
@@ -614,42 +625,156 @@ struct AmpDiscTrainer {
   float* ws;                     // workspace
   int64_t ws_floats;
   int kN;
-  // fp16-split GEMM path (gemm_f16x3): block-layout planes of the two operands of the running product + abs-max slots
-  _Float16* planes[2];
-  int64_t plane_halves;          // capacity of each
-  float* amax;                   // [kAmaxSlots]
-  int amax_next;
+  // fp16-split GEMM path (cfg.gemm_f16x3): the two large products of the prediction loss's backward -- dH1 = (dH2 W2) * (H1 > 0) and
+  // gW2 = dH2^T H1 -- run at fp32 accuracy on the fp16 matrix pipe (three MFMAs per product, disc_gemm_f16_dma.hpp MODE 2) on
+  // block-layout planes written once per step, each with ONE power-of-two scale from a bound that costs no pass on the step's
+  // critical path: dH2's from max|dlogit| x max|w3| (a one-workgroup kernel over 3 B + h2 floats), W2's and H1's from abs-max passes
+  // on the side stream (under the scaler passes / the fp32 forward of layer 2).
+  _Float16* dh2p;                // [Mp][h2 / 32][2][32]   planes of dH2            (K = h2: the A operand of dH1)
+  _Float16* w2tp;                // [h1][h2 / 32][2][32]   planes of W2^T           (its W operand)
+  _Float16* dh2tp;               // [h2][Mp / 32][2][32]   planes of dH2^T          (K = batch rows: the A operand of gW2)
+  _Float16* h1tp;                // [h1][Mp / 32][2][32]   planes of H1^T           (its W operand)
+  // ... and three of the gradient-penalty chain's six (a1 = a2 W2, gW2 += a2^T e1, da2 = e1 W2^T: 12.9 of its 17.7 GFLOP):
+  _Float16* w2p;                 // [h2][h1 / 32][2][32]   planes of W2             (the W operand of da2)
+  _Float16* a2p;                 // [Bp][h2 / 32][2][32]   planes of a2             (A of a1)
+  _Float16* a2tp;                // [h2][Bp / 32][2][32]   planes of a2^T           (A of the penalty's gW2 product)
+  _Float16* e1p;                 // [Bp][h1 / 32][2][32]   planes of e1             (A of da2)
+  _Float16* e1tp;                // [h1][Bp / 32][2][32]   planes of e1^T           (W of the penalty's gW2 product)
+  // ... and the prediction loss's W1 gradient gW1 = dH1^T Xs (output width kN padded to the 128-column tile: zero rows of Xs^T):
+  _Float16* dh1tp;               // [h1][Mp / 32][2][32]   planes of dH1^T          (A of gW1)
+  _Float16* xstp;                // [kNp][Mp / 32][2][32]  planes of Xs^T, kNp = kN rounded up to 128 (rows >= kN stay zero)
+  float* bound;                  // [16]: [0] bound of |dH2|, [1] max|W2|, [2] max|H1|, [3] max|w3| (bounds |a2|), [4] max|e1|,
+                                 //      [5] h2 x [0] x [1] (bounds |dH1|), [6] max|Xs|, [8] max row sum of |W1|, [9] max|b1|; [2] = [8] x [6] + [9]
   // the gradient-penalty chain (six GEMMs over the motion rows, grids that do not fill the chip) runs beside the prediction
   // loss's backward on a stream of the trainer's own: fork / join through these events (capturable: the side stream joins back)
   hipStream_t side;
-  hipEvent_t ev[4];              // step start | W^T copies written | forward done | penalty chain done
+  hipEvent_t ev[6];              // step start | W^T copies (+ W2^T planes) written | forward done | penalty chain done | H1 written | H1^T planes written
 };
 
 namespace {
 
 unsigned blocks(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
-constexpr int kAmaxSlots = 64;
-constexpr int kShapeNotSupported = 1;  // gemm_f16x3: "not for this shape" (not an error: the caller takes the fp32 engine)
+constexpr int kShapeNotSupported = 1;  // "not for this shape" (not an error: the caller takes the fp32 engine)
 
-// abs-max of a [rows, cols] block (row pitch ld) into out[0] (zeroed before): non-negative floats order like their bit
-// patterns, so one integer atomicMax per workgroup does it
-__global__ __launch_bounds__(kBlock) void amax_kernel(const float* __restrict__ x, int64_t rows, int cols, int64_t ld,
-                                                      float* __restrict__ out) {
+// abs-max of a contiguous array of n4 float4 into out[0] (zeroed before): non-negative floats order like their bit patterns, so an
+// integer atomicMax does it.  Four independent 16-B loads per lane and trip; a workgroup issues its atomic only if its maximum exceeds
+// what the slot already holds (atomics on one address serialise in the L2 at ~50 ns each: after the first few workgroups almost
+// none is needed).
+__global__ __launch_bounds__(kBlock) void amax_flat_kernel(const fv4* __restrict__ x, int64_t n4, float* __restrict__ out) {
   __shared__ float s_part[kBlock / 64];
   float m = 0.0f;
-  const int64_t n = rows * cols;
-  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (int64_t)gridDim.x * kBlock) {
-    const int64_t r = e / cols;
-    m = fmaxf(m, fabsf(x[r * ld + (e - r * cols)]));
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n4; e += 4 * stride) {
+    fv4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = e + j * stride < n4 ? x[e + j * stride] : fv4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m = fmaxf(fmaxf(m, fmaxf(fabsf(v[j][0]), fabsf(v[j][1]))), fmaxf(fabsf(v[j][2]), fabsf(v[j][3])));
   }
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
   if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int i = 1; i < kBlock / 64; ++i) m = fmaxf(m, s_part[i]);
-    atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
+    if (m > __builtin_nontemporal_load(out)) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
   }
+}
+// out[0] = max_j sum_k |W[j][k]| (zeroed before; one wave per row, conditional atomic as above), out[1] = max_j |b[j]|:
+// |relu(x W^T + b)| <= out[0] * max|x| + out[1], the a-priori bound of the hidden layer (what DiscRange holds for inference)
+__global__ __launch_bounds__(kBlock) void rowsum_bound_kernel(const float* __restrict__ W, int rows, int cols, int64_t ld,
+                                                              const float* __restrict__ b, float* __restrict__ out) {
+  __shared__ float s_part[2][kBlock / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * (kBlock / 64) + wave;
+  float rs = 0.0f, bm = 0.0f;
+  if (j < rows) {
+    for (int k = lane; k < cols; k += 64) rs += fabsf(W[j * ld + k]);
+    for (int off = 32; off > 0; off >>= 1) rs += __shfl_xor(rs, off, 64);
+    bm = fabsf(b[j]);
+  }
+  if (lane == 0) { s_part[0][wave] = rs; s_part[1][wave] = bm; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < kBlock / 64; ++i) { rs = fmaxf(rs, s_part[0][i]); bm = fmaxf(bm, s_part[1][i]); }
+    if (rs > __builtin_nontemporal_load(out)) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(rs));
+    if (bm > __builtin_nontemporal_load(out + 1)) atomicMax(reinterpret_cast<unsigned int*>(out + 1), __float_as_uint(bm));
+  }
+}
+// out[0] = a[0] * b[0] * 1.0001f + c[0]  (the row sums were rounded: keep the bound a bound)
+__global__ void bound_affine_kernel(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c) {
+  out[0] = a[0] * b[0] * 1.0001f + c[0];
+}
+// (rows x cols contiguous floats, rows * cols % 4 == 0)
+void amax_flat(hipStream_t st, const float* x, int64_t n, float* out) {
+  const int64_t n4 = n / 4;
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(1024, (n4 + 4 * kBlock - 1) / (4 * kBlock)));
+  amax_flat_kernel<<<grid, kBlock, 0, st>>>(reinterpret_cast<const fv4*>(x), n4, out);
+}
+
+// out[0] = max_i |a[i]| * max_j |b[j]| (one workgroup of 1 024 lanes, twelve loads in flight per lane): the bound of
+// |dH2| = |dlogit (x) w3 * mask| from 3 B + h2 floats
+// (+ out2[0] = factor * out[0] * c[0]: the bound of the NEXT product's result)
+__global__ __launch_bounds__(1024) void bound_product_kernel(const float* __restrict__ a, int64_t na, const float* __restrict__ b, int nb,
+                                                             float* __restrict__ out, const float* __restrict__ c, float factor,
+                                                             float* __restrict__ out2) {
+  __shared__ float red[2][16];
+  float ma = 0.0f, mb = 0.0f;
+  for (int64_t i0 = threadIdx.x; i0 < na; i0 += 12 * 1024) {
+    float v[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) v[j] = i0 + (int64_t)j * 1024 < na ? a[i0 + (int64_t)j * 1024] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) ma = fmaxf(ma, fabsf(v[j]));
+  }
+  for (int i = threadIdx.x; i < nb; i += 1024) mb = fmaxf(mb, fabsf(b[i]));
+  for (int off = 32; off > 0; off >>= 1) {
+    ma = fmaxf(ma, __shfl_down(ma, off, 64));
+    mb = fmaxf(mb, __shfl_down(mb, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ma; red[1][threadIdx.x >> 6] = mb; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 16; ++i) { ma = fmaxf(ma, red[0][i]); mb = fmaxf(mb, red[1][i]); }
+    out[0] = ma * mb;
+    out2[0] = factor * (ma * mb) * c[0];
+  }
+}
+
+// src [R, C] fp32 (row pitch ld) -> the planes of s * src^T in block layout dst[C][Rp / 32][2][32] halves (k = the source ROW index:
+// the operand layout of a product that reduces over the batch), s = plane_scale(bound[0]); source rows in [R, Rp) are zero.
+// One workgroup per 32 source rows x 64 columns through an LDS tile; a lane then owns 8 consecutive k of one column: one 16-B
+// store per plane, four lanes fill a column's 128-B block.  C % 64 == 0, ld % 4 == 0, Rp % 32 == 0.
+__global__ __launch_bounds__(kBlock) void split_transpose_blocks_kernel(const float* __restrict__ src, int64_t R, int C, int64_t ld,
+                                                                        const float* __restrict__ bound, _Float16* __restrict__ dst,
+                                                                        int64_t Rp) {
+  __shared__ float tile[32][65];
+  const int c0 = blockIdx.x * 64;
+  const int64_t r0 = (int64_t)blockIdx.y * 32;
+  {
+    const int q = threadIdx.x & 15, rr = threadIdx.x >> 4;  // 16 column quads x 16 rows, two passes
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int r = rr + 16 * pass;
+      fv4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (r0 + r < R) v = *reinterpret_cast<const fv4*>(src + (r0 + r) * ld + c0 + 4 * q);
+      tile[r][4 * q] = v[0]; tile[r][4 * q + 1] = v[1]; tile[r][4 * q + 2] = v[2]; tile[r][4 * q + 3] = v[3];
+    }
+  }
+  __syncthreads();
+  const float s = plane_scale(bound[0]);
+  const int col = threadIdx.x >> 2, part = threadIdx.x & 3;
+  h8 p0, p1;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float v = tile[8 * part + i][col] * s;
+    const _Float16 a = (_Float16)v;
+    p0[i] = a;
+    p1[i] = (_Float16)(v - (float)a);
+  }
+  _Float16* out = dst + ((int64_t)(c0 + col) * (Rp >> 5) + blockIdx.y) * 64 + 8 * part;
+  *reinterpret_cast<h8*>(out) = p0;
+  *reinterpret_cast<h8*>(out + 32) = p1;
 }
 
 template <int TM, int TN>
@@ -669,60 +794,45 @@ int f16x3_init() {
   return AMP_OK;
 }
 
-// C[M, N] (ld = ldc) = A W^T at fp32 accuracy on the fp16 matrix pipe: both operands are split into two fp16 planes in
-// block layout (scale = the power of two that brings the operand's abs-max below 2^15) and multiplied by the LDS-DMA
-// kernel of the inference path (three MFMAs per product, disc_gemm_f16_dma.hpp, MODE 2).  A is [M, K] (row pitch lda),
-// W is [N, K] (row pitch ldw); K is padded to 32 with zeros.  Returns kShapeNotSupported when the shape does not
-// fit the kernel (kShapeNotSupported: the caller then takes the fp32 engine).
-int gemm_f16x3(hipStream_t st, AmpDiscTrainer* t, const float* A, int64_t lda, int64_t M, const float* W, int64_t ldw, int N,
-               int K, const float* bias, int relu, float* C, int64_t ldc, const float* mask, int64_t ldmask, int accumulate,
-               float* split, int64_t split_floats) {
-  const int Kp = (int)up(K, 32);
-  if (!t->planes[0] || N % 128 != 0 || M < 128 || M * (int64_t)Kp * 2 > t->plane_halves || (int64_t)N * Kp * 2 > t->plane_halves)
-    return kShapeNotSupported;
-  if (t->amax_next + 2 > kAmaxSlots) return kShapeNotSupported;
-  float* am_a = t->amax + t->amax_next++;
-  float* am_w = t->amax + t->amax_next++;
-  const int64_t na = M * (int64_t)K, nw = (int64_t)N * K;
-  amax_kernel<<<(unsigned)std::min<int64_t>(1024, (na + kBlock - 1) / kBlock), kBlock, 0, st>>>(A, M, K, lda, am_a);
-  amax_kernel<<<(unsigned)std::min<int64_t>(1024, (nw + kBlock - 1) / kBlock), kBlock, 0, st>>>(W, N, K, ldw, am_w);
-  split_rows_blocks_kernel<<<blocks(M * (Kp / 4)), kBlock, 0, st>>>(A, M, K, lda, am_a, t->planes[0], Kp, 1);
-  split_rows_blocks_kernel<<<blocks((int64_t)N * (Kp / 4)), kBlock, 0, st>>>(W, N, K, ldw, am_w, t->planes[1], Kp, 1);
-  GemmF16Args g{};
-  g.A = t->planes[0]; g.lda = Kp; g.M = M;
-  g.W = t->planes[1]; g.Kp = Kp; g.N = N;
-  g.bias = bias; g.relu = relu;
-  g.C = C; g.ldc = ldc; g.amax_a = am_a; g.amax_w = am_w;
-  g.mask = mask; g.ldmask = ldmask; g.accumulate = accumulate;
-  // tile: 256 x 256 when that still gives ~3/4 of the CUs a workgroup, then 256 x 128, else 128 x 128; split-K (only the
-  // weight-gradient products: a few output tiles, thousands of k-blocks) on 128 x 128 tiles
-  const int nq = Kp / 32;
-  int tm = 2, tn = 1, slices = 1;
+// Tile and k-slice plan of C[M, N] = A W^T on planes (K = 32 nq): 256 x 256 when that still gives ~3/4 of the CUs a workgroup, then
+// 256 x 128, else 128 x 128; split-K (the weight-gradient product: a few output tiles, hundreds of k-blocks) on 128 x 128 tiles,
+// at most `max_slices` slices of >= 8 k-blocks.
+struct F16Plan { int tm, tn, slices; };
+F16Plan f16_planes_plan(int64_t M, int N, int nq, int max_slices) {
+  F16Plan q{2, 1, 1};
   auto tiles = [&](int bm, int bn) { return (int)((M + bm - 1) / bm) * (N / bn); };
-  if (split && !mask && !bias) {
-    while (slices < 16 && tiles(128, 128) * slices * 2 <= 512 && nq % (slices * 2) == 0 && nq / (slices * 2) >= 8 &&
-           (int64_t)(slices * 2) * M * ldc <= split_floats)
-      slices *= 2;
+  while (q.slices * 2 <= max_slices && tiles(128, 128) * q.slices * 2 <= 512 && nq % (q.slices * 2) == 0 && nq / (q.slices * 2) >= 8) q.slices *= 2;
+  // The forked step runs these products BESIDE the other stream's fp32 GEMMs: a 256-row tile owns a CU's whole LDS and waits for
+  // every co-resident workgroup of the other stream to drain before it can start; 128 x 128 tiles (two per CU) interleave
+  // (K D = 166: 0.620 -> 0.593 ms per step, same box; AMP_TRAIN_F16_BIG=1 restores the large tiles for A/B runs)
+  static const bool small_only = !(getenv("AMP_TRAIN_F16_BIG") && getenv("AMP_TRAIN_F16_BIG")[0] == '1');
+  if (q.slices == 1 && !small_only) {
+    if (N % 256 == 0 && tiles(256, 256) >= 192) { q.tm = 4; q.tn = 2; }
+    else if (tiles(256, 128) >= 192) { q.tm = 4; q.tn = 1; }
   }
-  if (slices == 1) {
-    if (N % 256 == 0 && tiles(256, 256) >= 192) { tm = 4; tn = 2; }
-    else if (tiles(256, 128) >= 192) { tm = 4; tn = 1; }
-  }
-  const int bm = 64 * tm, bn = 128 * tn;
+  return q;
+}
+// C[M, N] (ld = ldc) = A W^T at fp32 accuracy on the fp16 matrix pipe: A planes [M][Kp / 32][2][32] of plane_scale(bound_a[0]) A,
+// W planes [N][Kp / 32][2][32] of plane_scale(bound_w[0]) W, the LDS-DMA kernel of the inference path (disc_gemm_f16_dma.hpp, MODE 2).
+// plan.slices > 1: slice s of the reduction lands in C + s * slice_stride (summed by the caller: Adam does it for the weight gradients).
+int gemm_f16_planes(hipStream_t st, const _Float16* A, int64_t M, const _Float16* W, int N, int Kp, const float* bound_a,
+                    const float* bound_w, float* C, int64_t ldc, const float* mask, int64_t ldmask, F16Plan plan, int64_t slice_stride) {
+  GemmF16Args g{};
+  g.A = A; g.lda = Kp; g.M = M;
+  g.W = W; g.Kp = Kp; g.N = N;
+  g.C = C; g.ldc = ldc; g.amax_a = bound_a; g.amax_w = bound_w;
+  g.mask = mask; g.ldmask = ldmask;
+  const int bm = 64 * plan.tm, bn = 128 * plan.tn;
   g.m_tiles = (int)((M + bm - 1) / bm); g.n_tiles = N / bn;
-  if (slices > 1) { g.k_slices = slices; g.slice_stride = M * ldc; g.C = split; g.accumulate = 0; }
-  const unsigned grid = (unsigned)(((int64_t)g.m_tiles * g.n_tiles * slices + 7) / 8 * 8);
+  if (plan.slices > 1) { g.k_slices = plan.slices; g.slice_stride = slice_stride; }
+  const unsigned grid = (unsigned)(((int64_t)g.m_tiles * g.n_tiles * plan.slices + 7) / 8 * 8);
   {
     amp::TraceScope trace__("disc_gemm_f16_dma_kernel<2>", st);
-    if (tm == 4 && tn == 2) disc_gemm_f16_dma_kernel<2, 4, 2><<<grid, kDmaThreads, DmaTile<4, 2>::kLds, st>>>(g);
-    else if (tm == 4) disc_gemm_f16_dma_kernel<2, 4, 1><<<grid, kDmaThreads, DmaTile<4, 1>::kLds, st>>>(g);
+    if (plan.tm == 4 && plan.tn == 2) disc_gemm_f16_dma_kernel<2, 4, 2><<<grid, kDmaThreads, DmaTile<4, 2>::kLds, st>>>(g);
+    else if (plan.tm == 4) disc_gemm_f16_dma_kernel<2, 4, 1><<<grid, kDmaThreads, DmaTile<4, 1>::kLds, st>>>(g);
     else disc_gemm_f16_dma_kernel<2, 2, 1><<<grid, kDmaThreads, DmaTile<2, 1>::kLds, st>>>(g);
   }
-  int rc = launch_status("disc_gemm_f16_dma_kernel<2>");
-  if (rc != AMP_OK || slices == 1) return rc;
-  const int64_t n = M * ldc;
-  sum_slices_kernel<<<(unsigned)((n + kBlock - 1) / kBlock), kBlock, 0, st>>>(split, slices, n, n, C, accumulate);
-  return launch_status("sum_slices_kernel");
+  return launch_status("disc_gemm_f16_dma_kernel<2>");
 }
 
 // C[M, N] (ld = ldc) = A W^T, optionally gated / accumulated.  `split` (scratch of k_slices * M * ldc floats) enables
@@ -902,9 +1012,18 @@ int amp_disc_trainer_destroy(AmpDiscTrainer* t) {
   (void)hipFree(t->mean64);
   (void)hipFree(t->var64);
   (void)hipFree(t->ws);
-  (void)hipFree(t->planes[0]);
-  (void)hipFree(t->planes[1]);
-  (void)hipFree(t->amax);
+  (void)hipFree(t->dh2p);
+  (void)hipFree(t->w2tp);
+  (void)hipFree(t->dh2tp);
+  (void)hipFree(t->h1tp);
+  (void)hipFree(t->w2p);
+  (void)hipFree(t->dh1tp);
+  (void)hipFree(t->xstp);
+  (void)hipFree(t->a2p);
+  (void)hipFree(t->a2tp);
+  (void)hipFree(t->e1p);
+  (void)hipFree(t->e1tp);
+  (void)hipFree(t->bound);
   for (hipEvent_t e : t->ev)
     if (e) (void)hipEventDestroy(e);
   if (t->side) (void)hipStreamDestroy(t->side);
@@ -961,18 +1080,30 @@ int amp_disc_trainer_create(AmpDisc* disc, const AmpDiscTrainCfg* cfg, const dou
   t->ws_floats = f + (int64_t)16 * p.h2 * p.h1 + (int64_t)16 * p.h1 * t->kN + 64 + 2 * ((M + 3) / 4) + 16 + (int64_t)kChunks * 1024 + 1024 + 3 * (up((int64_t)kChunks * p.in_dim * 2, 8) * 2) + 16 +
                  16 * 40 + 6 * up(p.k1p, 16) + M * (t->kN - p.k1p) + 2 * (int64_t)kChunks * 1024;
   t->ws_floats += (int64_t)16 * p.h2 * p.h1 + (int64_t)16 * p.h1 * t->kN + (int64_t)3 * kChunks * 1024 + 1024 + 64;  // the side stream's slices + partials
+  t->ws_floats += (int64_t)32 * p.h1 * (up(t->kN, 128) - t->kN) + 64;                                                 // gW1's slices at the padded pitch
   if (e == hipSuccess) e = hipMalloc(&t->ws, sizeof(float) * t->ws_floats);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking);
   // device-side ordering between two streams of this device only: no timing, no system-scope fence at the record (that fence
   // delayed the kernel behind a record by ~8 us in the rocprofv3 timeline of the step)
-  for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&t->ev[i], hipEventDisableTiming | hipEventDisableSystemFence);
-  if (e == hipSuccess && cfg->gemm_f16x3) {
-    // fp16-split GEMM path: planes of the largest operand ([3B (padded), max(h1, h2)] or its transpose), twice
-    const int64_t rows = up(Mp, 32), cols = up(std::max<int64_t>(std::max(p.h1, p.h2), up(t->kN, 32)), 32);
-    t->plane_halves = 2 * rows * cols;
-    e = hipMalloc(&t->planes[0], sizeof(_Float16) * t->plane_halves);
-    if (e == hipSuccess) e = hipMalloc(&t->planes[1], sizeof(_Float16) * t->plane_halves);
-    if (e == hipSuccess) e = hipMalloc(&t->amax, sizeof(float) * kAmaxSlots);
+  for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&t->ev[i], hipEventDisableTiming | hipEventDisableSystemFence);
+  if (e == hipSuccess && cfg->gemm_f16x3 && p.h2 % 128 == 0 && p.h1 % 128 == 0) {
+    // fp16-split GEMM path: the planes of dH2, W2^T, dH2^T, H1^T (2 halves per element; batch rows padded to the k-block)
+    const int64_t Mk = up(M, 32);
+    e = hipMalloc(&t->dh2p, sizeof(_Float16) * 2 * Mk * p.h2);
+    if (e == hipSuccess) e = hipMalloc(&t->w2tp, sizeof(_Float16) * 2 * (size_t)p.h1 * p.h2);
+    if (e == hipSuccess) e = hipMalloc(&t->dh2tp, sizeof(_Float16) * 2 * Mk * p.h2);
+    if (e == hipSuccess) e = hipMalloc(&t->h1tp, sizeof(_Float16) * 2 * Mk * p.h1);
+    const int64_t Bk = up(B, 32), kNp = up(t->kN, 128);
+    if (e == hipSuccess) e = hipMalloc(&t->dh1tp, sizeof(_Float16) * 2 * Mk * p.h1);
+    if (e == hipSuccess) e = hipMalloc(&t->xstp, sizeof(_Float16) * 2 * Mk * kNp);
+    if (e == hipSuccess) e = hipMemsetAsync(t->xstp, 0, sizeof(_Float16) * 2 * Mk * kNp, st);   // rows [kN, kNp) are never written again
+    if (e == hipSuccess) e = hipMalloc(&t->w2p, sizeof(_Float16) * 2 * (size_t)p.h1 * p.h2);
+    if (e == hipSuccess) e = hipMalloc(&t->a2p, sizeof(_Float16) * 2 * Bk * p.h2);
+    if (e == hipSuccess) e = hipMalloc(&t->a2tp, sizeof(_Float16) * 2 * Bk * p.h2);
+    if (e == hipSuccess) e = hipMalloc(&t->e1p, sizeof(_Float16) * 2 * Bk * p.h1);
+    if (e == hipSuccess) e = hipMalloc(&t->e1tp, sizeof(_Float16) * 2 * Bk * p.h1);
+    if (e == hipSuccess) e = hipMalloc(&t->bound, sizeof(float) * 16);
+    if (e == hipSuccess) e = hipMemsetAsync(t->bound, 0, sizeof(float) * 16, st);
     if (e == hipSuccess && f16x3_init() != AMP_OK) e = hipErrorUnknown;
   }
   if (e != hipSuccess) {
@@ -1071,7 +1202,8 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
   float* gb3 = take(1);
   float* loss = take(16);  // [0] prediction, [1] gradient penalty, [2] logit reg, [3] weight decay
   float* split = take((int64_t)32 * H2n * H1n);                  // split-K partial products of gW2: <= 16 slices per product, two products
-  float* split1 = take((int64_t)32 * H1n * kN);                  // ... of gW1 (both weights' slices are alive at once: deferred sums)
+  float* split1 = take((int64_t)32 * H1n * up(kN, 128));         // ... of gW1 (both weights' slices are alive at once: deferred sums; row
+                                                                  //     pitch kN, or kN rounded up to 128 when the fp16 pipe writes them)
   float* part = take((int64_t)3 * kChunks * 1024 + 1024);      // column-sum / scalar partials (three planes: dh2_colsum_kernel)
   float* part_side = take((int64_t)3 * kChunks * 1024 + 1024); // ... of the gradient-penalty chain when it runs on the side stream
   const int64_t dpart_stride = up((int64_t)kChunks * p.in_dim * 2, 8);                 // doubles per batch
@@ -1095,25 +1227,16 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
   int rc;
   // layer 1's bias gradient = colsum(dH1) comes out of the TT product dH1^T Xs when Xs carries a column of ones in its padding
   // (column in_dim; needs a spare column and the TT route: the fp16-split option keeps the separate column sum)
-  const int ones_col = (t->planes[0] == nullptr && p.in_dim < kN) ? p.in_dim : -1;
-  // The BACKWARD products whose shape fits run at fp32 accuracy on the fp16 matrix pipe (gemm_f16x3) when cfg.gemm_f16x3 is set;
-  // the others (output width kN = 192: the W1-gradient products and g) and the two FORWARD GEMMs stay on the fp32 pipe.
+  const int ones_col = p.in_dim < kN ? p.in_dim : -1;
+  // cfg.gemm_f16x3: the two large products of the prediction loss's backward (dH1, gW2: 2 x 12.9 of the backward's 30.6 GFLOP on the
+  // caller's stream) run at fp32 accuracy on the fp16 matrix pipe; everything else -- the two FORWARD GEMMs, the products of output
+  // width kN = 192, the gradient-penalty chain on the side stream -- stays on the fp32 pipe.
   // The forward decides the ReLU masks: a pre-activation within rounding of zero flips its mask with any change of the
   // summation (measured: one of 786 432 H2 entries between the two engines at 3 x 512 rows), and one flipped unit moves its
   // column of the bias / weight gradients by ~1 / sqrt(rows) of the column sum -- 6e-3 here, two orders above the parity bar
   // although both forwards are 1e-6 from fp64.  The backward products are linear in their operands: no such cliff.
-  const bool f16 = t->planes[0] != nullptr;
-  if (f16) {
-    t->amax_next = 0;
-    AMP_HIP(hipMemsetAsync(t->amax, 0, sizeof(float) * kAmaxSlots, st));
-  }
-  const int64_t split_floats = (int64_t)16 * H2n * H1n;
   auto nt_on = [&](hipStream_t s_, const float* A, int64_t lda, int64_t Mr, const float* W, int Kp, int N, float* C, int64_t ldc,
                    const float* mask, int64_t ldmask, int accumulate, float* split_ws = nullptr) -> int {
-    if (f16) {
-      const int r = gemm_f16x3(s_, t, A, lda, Mr, W, Kp, N, Kp, nullptr, 0, C, ldc, mask, ldmask, accumulate, split_ws, split_floats);
-      if (r != kShapeNotSupported) return r;
-    }
     return gemm_nt(s_, A, lda, Mr, W, Kp, N, C, ldc, mask, ldmask, accumulate, split_ws);
   };
   auto nt = [&](const float* A, int64_t lda, int64_t Mr, const float* W, int Kp, int N, float* C, int64_t ldc, const float* mask,
@@ -1123,7 +1246,7 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
   // ---- fork: the gradient-penalty chain on the trainer's side stream when all four weight-gradient products take the TT kernel
   const bool pair = c.grad_penalty_scale != 0.0f;
   int sl_w2[2] = {0, 0}, sl_w1[2] = {0, 0};   // k-slices of (prediction, penalty) product of gW2 / gW1
-  bool fork = pair && !f16 && fork_ok() && t->side != nullptr;
+  bool fork = pair && fork_ok() && t->side != nullptr;
   if (fork) {
     TtPlan q;
     fork = tt_plan(H2n, H1n, M, H2n, H1n, H1n, true, &q) == AMP_OK;
@@ -1134,6 +1257,30 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
     sl_w1[1] = q.slices;
     fork = fork && tt_plan(H2n, H1n, B, H2n, H1n, H1n, true, &q) == AMP_OK;
     sl_w2[1] = q.slices;
+  }
+  // fp16-split products (forked step only: their planes are written on the side stream): dH1 [M, h1] over K = h2, gW2 [h2, h1] over
+  // K = the batch rows padded to the k-block (zero rows), its k-slices summed by Adam like the TT product's
+  const int64_t Mk = up(M, 32);
+  const bool f16 = fork && t->dh2p != nullptr && M >= 128 && H2n % 32 == 0;
+  // ... and of the penalty chain (B motion rows): a1 [B, h1] over K = h2, gW2's second product [h2, h1] over K = B (padded), da2
+  // [B, h2] over K = h1
+  const int64_t Bk = up(B, 32);
+  const bool f16p = f16 && B >= 128 && H1n % 32 == 0;
+  F16Plan plan_dh1{}, plan_gw2{}, plan_a1{}, plan_gw2p{}, plan_da2{}, plan_gw1{};
+  const int kNp = (int)up(kN, 128);
+  const int64_t gN = f16 ? kNp : kN;   // row pitch of gW1's k-slices
+  if (f16) {
+    plan_dh1 = f16_planes_plan(M, H1n, H2n / 32, 1);
+    plan_gw2 = f16_planes_plan(H2n, H1n, (int)(Mk / 32), 16);
+    plan_gw1 = f16_planes_plan(H1n, kNp, (int)(Mk / 32), 16);
+    sl_w2[0] = plan_gw2.slices;
+    sl_w1[0] = plan_gw1.slices;
+  }
+  if (f16p) {
+    plan_a1 = f16_planes_plan(B, H1n, H2n / 32, 1);
+    plan_gw2p = f16_planes_plan(H2n, H1n, (int)(Bk / 32), 16);
+    plan_da2 = f16_planes_plan(B, H2n, H1n / 32, 1);
+    sl_w2[1] = plan_gw2p.slices;
   }
   hipStream_t side = fork ? t->side : st;
   // whatever path leaves this function, the side stream has joined the caller's stream (an error return between fork and join
@@ -1152,6 +1299,16 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
     AMP_HIP(hipStreamWaitEvent(side, t->ev[0], 0));
     transpose(side, p.w2, H2n, H1n, H1n, t->w2t, H2n, H1n);               // W2^T [h1, h2]
     transpose(side, p.w1p, H1n, k1p, k1p, t->w1t, H1n, kN);               // W1^T [kN, h1] (zero rows >= k1p)
+    if (f16) {
+      // the planes of W2^T (the W operand of dH1) with the scale of max|W2|: 2 MB, under the scaler passes
+      // (abs-max kernels: one atomic per workgroup on one address -- ~50 ns each in the L2 --, so few, long workgroups)
+      AMP_HIP(hipMemsetAsync(t->bound + 1, 0, 9 * sizeof(float), side));
+      amax_flat(side, p.w2, (int64_t)H2n * H1n, t->bound + 1);
+      amax_flat(side, p.w3, H2n, t->bound + 3);
+      rowsum_bound_kernel<<<(unsigned)((H1n + 3) / 4), kBlock, 0, side>>>(p.w1p, H1n, k1p, k1p, p.b1, t->bound + 8);
+      split_transpose_blocks_kernel<<<dim3(H1n / 64, H2n / 32), kBlock, 0, side>>>(p.w2, H2n, H1n, H1n, t->bound + 1, t->w2tp, H2n);
+      if (f16p) split_rows_blocks_kernel<<<blocks((int64_t)H2n * (H1n / 4)), kBlock, 0, side>>>(p.w2, H2n, H1n, H1n, t->bound + 1, t->w2p, H1n, 1);
+    }
     AMP_HIP(hipEventRecord(t->ev[1], side));
   }
   // ---- 1. scaler (train=True): update the running statistics with each batch, then scale it --------------------
@@ -1194,6 +1351,20 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
   // ---- 2. forward, keeping H1 / H2 -----------------------------------------------------------------------------
   rc = gemm_fwd(st, Xs, kN, M, p.w1p, k1p, H1n, p.b1, H1);
   if (rc != AMP_OK) return rc;
+  if (f16) {
+    // H1 is complete: its abs-max and the planes of H1^T (the W operand of gW2; 50 MB in, 50 MB out) on the side stream, under
+    // layer 2's fp32 forward
+    AMP_HIP(hipEventRecord(t->ev[4], st));
+    AMP_HIP(hipStreamWaitEvent(side, t->ev[4], 0));
+    // |H1| <= max_j sum_k |W1[j][k]| x max|Xs| + max|b1|: an a-priori bound (a 50-MB abs-max pass over H1 under the forward
+    // of layer 2 cost that GEMM ~12 us); max|Xs| is needed for Xs^T's planes anyway
+    amax_flat(side, Xs, M * kN, t->bound + 6);
+    bound_affine_kernel<<<1, 1, 0, side>>>(t->bound + 2, t->bound + 8, t->bound + 6, t->bound + 9);
+    split_transpose_blocks_kernel<<<dim3(H1n / 64, (unsigned)(Mk / 32)), kBlock, 0, side>>>(H1, M, H1n, H1n, t->bound + 2, t->h1tp, Mk);
+    // ... and of Xs^T (the W operand of gW1; the column of ones that yields gb1 included)
+    split_transpose_blocks_kernel<<<dim3(kN / 64, (unsigned)(Mk / 32)), kBlock, 0, side>>>(Xs, M, kN, kN, t->bound + 6, t->xstp, Mk);
+    AMP_HIP(hipEventRecord(t->ev[5], side));
+  }
   rc = gemm_fwd(st, H1, H1n, M, p.w2, H1n, H2n, p.b2, H2);
   if (rc != AMP_OK) return rc;
   const unsigned n_bce = (unsigned)((M + 3) / 4);
@@ -1204,9 +1375,9 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
   int def_w1 = 0, def_w2 = 0;
   auto tt = [&](const float* A, int64_t lda, int Mo, const float* W, int64_t ldw, int No, int64_t Kr, float* C, int64_t ldc, int acc,
                 float* sp, int* defer) -> int {
-    return f16 ? kShapeNotSupported : gemm_tt(st, A, lda, Mo, W, ldw, No, Kr, C, ldc, acc, sp, pair ? defer : nullptr);
+    return gemm_tt(st, A, lda, Mo, W, ldw, No, Kr, C, ldc, acc, sp, pair ? defer : nullptr);
   };
-  const int64_t n_w2 = (int64_t)H2n * H1n, n_w1 = (int64_t)H1n * kN;
+  const int64_t n_w2 = (int64_t)H2n * H1n, n_w1 = (int64_t)H1n * gN;
   auto penalty = [&]() -> int {
     hipStream_t s_ = side;
     float* part_ = fork ? part_side : part;
@@ -1214,7 +1385,14 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
     const float* H2m = H2 + 2 * B * H2n;
     int r;
     a2_kernel<<<blocks(B * H2n), kBlock, 0, s_>>>(p.w3, H2m, B, H2n, a2);
-    r = nt_on(s_, a2, H2n, B, t->w2t, H2n, H1n, a1, H1n, H1m, H1n, 0);        // a1 = (a2 W2) * m1
+    if (f16p) {
+      // a2 = w3 * (H2 > 0): |a2| <= max|w3| exactly; its planes in both orientations, then a1 on the fp16 pipe against W2^T's planes
+      split_rows_blocks_kernel<<<blocks(B * (H2n / 4)), kBlock, 0, s_>>>(a2, B, H2n, H2n, t->bound + 3, t->a2p, H2n, 1);
+      split_transpose_blocks_kernel<<<dim3(H2n / 64, (unsigned)(Bk / 32)), kBlock, 0, s_>>>(a2, B, H2n, H2n, t->bound + 3, t->a2tp, Bk);
+      r = gemm_f16_planes(s_, t->a2p, B, t->w2tp, H1n, H2n, t->bound + 3, t->bound + 1, a1, H1n, H1m, H1n, plan_a1, 0);
+    } else {
+      r = nt_on(s_, a2, H2n, B, t->w2t, H2n, H1n, a1, H1n, H1m, H1n, 0);        // a1 = (a2 W2) * m1
+    }
     if (r != AMP_OK) return r;
     r = nt_on(s_, a1, H1n, B, t->w1t, H1n, kN, g, kN, nullptr, 0, 0);         // g = a1 W1      [B, kN]
     if (r != AMP_OK) return r;
@@ -1222,7 +1400,7 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
     sumsq(s_, part_, g, B, p.in_dim, kN, 2.0f * c.grad_penalty_scale * c.loss_scale / (float)B, 1, c.grad_penalty_scale / (float)B, 1, 0);
     if (fork) {
       int n = 0;
-      r = gemm_tt(s_, a1, H1n, H1n, g, kN, kN, B, nullptr, kN, 0, split1 + sl_w1[0] * n_w1, nullptr, &n);   // gW1's penalty slices
+      r = gemm_tt(s_, a1, H1n, H1n, g, kN, kN, B, nullptr, gN, 0, split1 + sl_w1[0] * n_w1, nullptr, &n);   // gW1's penalty slices
     } else {
       r = tt(a1, H1n, H1n, g, kN, kN, B, gW1, kN, 1, split1, &def_w1);        // gW1 += a1^T dg
       if (r == kShapeNotSupported) {
@@ -1234,7 +1412,14 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
     if (r != AMP_OK) return r;
     r = nt_on(s_, g, kN, B, p.w1p, k1p, H1n, e1, H1n, H1m, H1n, 0);           // e1 = (dg W1^T) * m1   (K = k1p <= kN)
     if (r != AMP_OK) return r;
-    if (fork) {
+    if (f16p) {
+      // e1's abs-max (16 MB) and planes in both orientations; gW2's penalty slices = a2^T e1 and da2 = e1 W2^T on the fp16 pipe
+      amax_flat(s_, e1, B * H1n, t->bound + 4);   // (slot zeroed at the head of the side stream's work)
+      split_transpose_blocks_kernel<<<dim3(H1n / 64, (unsigned)(Bk / 32)), kBlock, 0, s_>>>(e1, B, H1n, H1n, t->bound + 4, t->e1tp, Bk);
+      split_rows_blocks_kernel<<<blocks(B * (H1n / 4)), kBlock, 0, s_>>>(e1, B, H1n, H1n, t->bound + 4, t->e1p, H1n, 1);
+      r = gemm_f16_planes(s_, t->a2tp, H2n, t->e1tp, H1n, (int)Bk, t->bound + 3, t->bound + 4, split + sl_w2[0] * n_w2, H1n, nullptr, 0,
+                          plan_gw2p, n_w2);
+    } else if (fork) {
       int n = 0;
       r = gemm_tt(s_, a2, H2n, H2n, e1, H1n, H1n, B, nullptr, H1n, 0, split + sl_w2[0] * n_w2, nullptr, &n);  // gW2's penalty slices
     } else {
@@ -1246,7 +1431,8 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
       }
     }
     if (r != AMP_OK) return r;
-    r = nt_on(s_, e1, H1n, B, p.w2, H1n, H2n, da2, H2n, nullptr, 0, 0);       // da2 = e1 W2^T
+    if (f16p) r = gemm_f16_planes(s_, t->e1p, B, t->w2p, H2n, H1n, t->bound + 4, t->bound + 1, da2, H2n, nullptr, 0, plan_da2, 0);
+    else r = nt_on(s_, e1, H1n, B, p.w2, H1n, H2n, da2, H2n, nullptr, 0, 0);       // da2 = e1 W2^T
     if (r != AMP_OK) return r;
     // gw3 += colsum(m2 * da2): the partial sums here, the accumulation into gw3 after the join when forked
     colsum_part_kernel<<<dim3((H2n + 63) / 64, kChunks), kBlock, 0, s_>>>(da2, B, H2n, H2n, nullptr, H2m, H2n, part_);
@@ -1270,7 +1456,12 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
 
   // ---- 3. backward of the prediction loss ----------------------------------------------------------------------
   // dH2 = dlogit (x) w3 * (H2 > 0), gw3 = H2^T dlogit, gb2 = colsum(dH2), gb3 = sum(dlogit): one pass over H2
-  dh2_colsum_kernel<<<dim3((H2n + 63) / 64, kChunks), kBlock, 0, st>>>(dlogit, p.w3, H2, M, H2n, dH2, part);
+  if (f16) {
+    AMP_HIP(hipStreamWaitEvent(st, t->ev[1], 0));   // max|W2| (bound[1]) is in place
+    // |dH2| <= max|dlogit| max|w3|;  |dH1| <= h2 max|dH2| max|W2|
+    bound_product_kernel<<<1, 1024, 0, st>>>(dlogit, M, p.w3, H2n, t->bound, t->bound + 1, (float)H2n, t->bound + 5);
+  }
+  dh2_colsum_kernel<<<dim3((H2n + 63) / 64, kChunks), kBlock, 0, st>>>(dlogit, p.w3, H2, M, H2n, dH2, part, f16 ? t->dh2p : nullptr, t->bound);
   dh2_colsum_final_kernel<<<(H2n + kBlock - 1) / kBlock, kBlock, 0, st>>>(part, H2n, gw3, gb2, gb3);
   if (fork) {
     AMP_HIP(hipStreamWaitEvent(st, t->ev[1], 0));
@@ -1278,7 +1469,13 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
     transpose(st, p.w2, H2n, H1n, H1n, t->w2t, H2n, H1n);               // W2^T [h1, h2]
     transpose(st, p.w1p, H1n, k1p, k1p, t->w1t, H1n, kN);               // W1^T [kN, h1] (zero rows >= k1p)
   }
-  rc = nt(dH2, H2n, M, t->w2t, H2n, H1n, dH1, H1n, H1, H1n, 0);   // dH1 = (dH2 W2) * (H1 > 0)
+  if (f16) {
+    // dH2's planes in both orientations (one scale), then dH1 = (dH2 W2) * (H1 > 0) on the fp16 pipe
+    // (dH2's row planes came out of dh2_colsum_kernel; the transposed ones -- gW2's A operand -- behind dH1's launch)
+    rc = gemm_f16_planes(st, t->dh2p, M, t->w2tp, H1n, H2n, t->bound, t->bound + 1, dH1, H1n, H1, H1n, plan_dh1, 0);
+  } else {
+    rc = nt(dH2, H2n, M, t->w2t, H2n, H1n, dH1, H1n, H1, H1n, 0);   // dH1 = (dH2 W2) * (H1 > 0)
+  }
   if (rc != AMP_OK) return rc;
   if (ones_col < 0) colsum(dH1, M, H1n, H1n, nullptr, nullptr, 0, gb1, 0);
   // the weight gradients reduce over the batch: the TT kernel takes both operands as the kernels above left them (rows = batch)
@@ -1287,9 +1484,20 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
   // accumulates into its slices; forked, the two write slice regions of their own and one sum follows the join
   if (fork) {
     int n = 0;
-    rc = gemm_tt(st, dH2, H2n, H2n, H1, H1n, H1n, M, nullptr, H1n, 0, split, nullptr, &n);        // gW2 = dH2^T H1
+    if (f16) {
+      split_transpose_blocks_kernel<<<dim3(H2n / 64, (unsigned)(Mk / 32)), kBlock, 0, st>>>(dH2, M, H2n, H2n, t->bound, t->dh2tp, Mk);
+      AMP_HIP(hipStreamWaitEvent(st, t->ev[5], 0));   // H1^T's planes (written under the forward of layer 2)
+      rc = gemm_f16_planes(st, t->dh2tp, H2n, t->h1tp, H1n, (int)Mk, t->bound, t->bound + 2, split, H1n, nullptr, 0, plan_gw2, n_w2);
+    } else {
+      rc = gemm_tt(st, dH2, H2n, H2n, H1, H1n, H1n, M, nullptr, H1n, 0, split, nullptr, &n);      // gW2 = dH2^T H1
+    }
     if (rc != AMP_OK) return rc;
-    rc = gemm_tt(st, dH1, H1n, H1n, Xs, kN, kN, M, nullptr, kN, 0, split1, nullptr, &n);          // gW1 = dH1^T Xs (+ gb1 in column ones_col)
+    if (f16) {
+      split_transpose_blocks_kernel<<<dim3(H1n / 64, (unsigned)(Mk / 32)), kBlock, 0, st>>>(dH1, M, H1n, H1n, t->bound + 5, t->dh1tp, Mk);
+      rc = gemm_f16_planes(st, t->dh1tp, H1n, t->xstp, kNp, (int)Mk, t->bound + 5, t->bound + 6, split1, gN, nullptr, 0, plan_gw1, n_w1);
+    } else {
+      rc = gemm_tt(st, dH1, H1n, H1n, Xs, kN, kN, M, nullptr, kN, 0, split1, nullptr, &n);        // gW1 = dH1^T Xs (+ gb1 in column ones_col)
+    }
     if (rc != AMP_OK) return rc;
     AMP_HIP(hipStreamWaitEvent(st, t->ev[3], 0));   // join; Adam sums the slices and the penalty's w3 column partials itself
     fork_guard.armed = false;
@@ -1334,7 +1542,7 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
     const int64_t sst[6] = {n_w1, n_w1, n_w2, 0, 0, 0};
     a.colpart = fork ? part_side : nullptr;
     a.colpart_chunks = kChunks;
-    const int64_t ldp[6] = {k1p, col ? 1 : H1n, H1n, H2n, H2n, 1}, ldg[6] = {kN, col ? kN : H1n, H1n, H2n, H2n, 1};
+    const int64_t ldp[6] = {k1p, col ? 1 : H1n, H1n, H2n, H2n, 1}, ldg[6] = {fork ? gN : kN, col ? (fork ? gN : kN) : H1n, H1n, H2n, H2n, 1};
     const int64_t rows_[6] = {H1n, col ? H1n : 1, H2n, 1, 1, 1};
     const int cols_[6] = {p.in_dim, col ? 1 : H1n, H1n, H2n, H2n, 1};
     const float reg[6] = {wd2, 0.0f, wd2, 0.0f, wd2 + lr2, 0.0f};

@@ -639,13 +639,17 @@ class AmpDiscriminatorTrainer:
                  discriminator_gradient_penalty_scale: float = 5.0, discriminator_weight_decay_scale: float = 1e-4,
                  betas=(0.9, 0.999), adam_epsilon: float = 1e-8, use_scaler: bool = True, update_scaler: bool = True,
                  running_mean: Optional[torch.Tensor] = None, running_variance: Optional[torch.Tensor] = None,
-                 current_count: float = 1.0, apply_update: bool = True, gemm_precision: str = "f32",
+                 current_count: float = 1.0, apply_update: bool = True, gemm_precision: str = "f16x3",
                  defer_refresh: bool = False):
-        """``gemm_precision``: "f32" (default) runs every GEMM on the fp32 matrix pipe; "f16x3" runs the large BACKWARD
-        products at fp32 accuracy on the fp16 matrix pipe (two fp16 planes per operand, three MFMAs per product -- the
-        inference path's engine).  Same gradients to 1e-6, but at BASELINE's minibatch (3 x 4 096 rows) the extra operand
-        passes (abs-max + plane split per operand) cost more than the faster products save: 1.20 vs 1.02 ms per step
-        (DESIGN.md section 7b), so it is opt-in."""
+        """``gemm_precision``: "f32" runs every GEMM on the fp32 matrix pipe; "f16x3" (default) runs six of the backward's ten
+        products -- dH1 = dH2 W2, gW2 = dH2^T H1, gW1 = dH1^T Xs of the prediction loss and a1 = a2 W2, gW2 += a2^T e1,
+        da2 = e1 W2^T of the gradient penalty: 44 of the backward's 48 GFLOP at K D = 166 -- at fp32 accuracy on the fp16 matrix pipe:
+        two fp16 planes per operand, three MFMAs per product (the inference path's engine), planes written once per step with one
+        power-of-two scale per operand from a bound that costs no pass on the step's critical path (a-priori bounds, or abs-max
+        passes on the side stream).  The forward GEMMs stay on the fp32 pipe in both modes (they decide the ReLU masks).  Same
+        gradients to 1e-5 of each tensor's scale; 0.66 -> 0.58 ms per step at K D = 166, 1.14 -> 0.99 at 830
+        (profiles/r05_train_step.md).  Needs the forked step (gradient penalty on, hidden widths multiples of 128); otherwise
+        the fp32 products run."""
         if gemm_precision not in ("f16x3", "f32"):
             raise ValueError(f"gemm_precision must be 'f16x3' or 'f32', got {gemm_precision!r}")
         self.disc, self.device, self._lib = disc, disc.device, nat.load()

@@ -564,9 +564,12 @@ typedef struct {
   int32_t use_scaler;           /* 0: feed raw observations */
   int32_t update_scaler;        /* 1: train=True statistics update with every batch (fp64) */
   int32_t apply_update;         /* 0: compute loss / gradients only (Adam moments still advance with lr = 0) */
-  int32_t gemm_f16x3;           /* 0 (default, also what a zero-initialised struct gets): every GEMM on the fp32 matrix pipe -- the
-                                 * faster choice at 3 x 4 096 rows; 1: opt in to the large backward products at fp32 accuracy on the
-                                 * fp16 matrix pipe (two fp16 planes per operand, three MFMAs per product, like the inference path) */
+  int32_t gemm_f16x3;           /* 0 (also what a zero-initialised struct gets): every GEMM on the fp32 matrix pipe; 1: six of the backward's
+                                 * ten products (dH1, gW2, gW1 of the prediction loss; a1, gW2's second product, da2 of the gradient penalty)
+                                 * at fp32 accuracy on the fp16 matrix pipe (two fp16 planes per operand, three MFMAs per product, like the
+                                 * inference path), planes written once per step with one power-of-two scale per operand; the forward stays
+                                 * on the fp32 pipe.  Needs the forked step (gradient penalty on, hidden widths multiples of 128), else the
+                                 * fp32 products run */
   int32_t defer_refresh;        /* 0 (default): every step ends by refreshing what the attached AmpDisc derives from its weights / scaler
                                  * for INFERENCE (fp16 planes, plane scales, fp32 scaler vectors: ~45 us of small launches); 1: the
                                  * steps leave them stale (the handle is then IN BETWEEN -- trained biases, old weight planes -- and

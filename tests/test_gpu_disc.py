@@ -390,3 +390,35 @@ def test_other_hidden_widths_vs_fp64(hidden, rows):
     # ... and a row's logit does not depend on the batch it is scored in
     part = d.style_reward(x[:min(rows, 700)].cuda(), want_logits=True)["logits"]
     assert torch.equal(part, out["logits"][:part.shape[0]])
+
+
+def test_set_plan_switches_the_fused_kernel_per_handle_without_changing_a_bit():
+    """amp_disc_set_plan / amp_disc_plan_info: the per-handle override decides whether 30 000 rows take the one-launch two-layer
+    kernel or the column-split two-kernel plan, plan_info reports what will run, and the logits are bit-identical either way."""
+    from humanoid_amp_amd import _native as nat
+    from humanoid_amp_amd.engine import AmpDiscriminator
+
+    g = torch.Generator().manual_seed(11)
+    w = odisc.make_weights(166, seed=5)
+    x = (torch.randn(30000, 166, generator=g) * 1.5).cuda()
+    d = AmpDiscriminator([(p.cuda(), q.cuda()) for p, q in w], "cuda:0", running_mean=torch.zeros(166, dtype=torch.float64),
+                         running_variance=torch.ones(166, dtype=torch.float64))
+    auto = d.plan_info(30000)
+    assert auto["fused_rows"] == 30000 and auto["precision"] == "f16x3" and auto["cu_count"] > 0
+    with nat.KernelTrace(capacity=64) as tr:
+        fused = d.style_reward(x, want_logits=True)["logits"]
+    assert "disc_mlp_fused_kernel" in tr.summary()
+    d.set_plan(fused=False)
+    off = d.plan_info(30000)
+    assert off["fused_rows"] == 0 and off["chunk_rows"] == 30000 and off["plan_name"].startswith("LDS-DMA 256x256")
+    with nat.KernelTrace(capacity=64) as tr:
+        split = d.style_reward(x, want_logits=True)["logits"]
+    assert "disc_mlp_fused_kernel" not in tr.summary() and torch.equal(split, fused)
+    d.set_plan(fused=True, fused_min_rows=128)           # the threshold moved down: 1 000 rows take the fused kernel too
+    assert d.plan_info(1000)["fused_rows"] == 1000
+    assert torch.equal(d.style_reward(x[:1000], want_logits=True)["logits"], fused[:1000])
+    d.set_plan()
+    assert d.plan_info(1000)["fused_rows"] == 0 and d.plan_info(30000)["fused_rows"] == 30000
+    assert d.plan_info(4096)["plan_name"] == "LDS-DMA 128x128 + 64x128" and d.plan_info(100)["plan"] == 0
+    with pytest.raises(nat.AmpEngineError):
+        d.set_plan(fused=True, fused_min_rows=5)
