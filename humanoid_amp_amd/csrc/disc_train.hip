@@ -745,9 +745,11 @@ __global__ __launch_bounds__(1024) void bound_product_kernel(const float* __rest
 // the operand layout of a product that reduces over the batch), s = plane_scale(bound[0]); source rows in [R, Rp) are zero.
 // One workgroup per 32 source rows x 64 columns through an LDS tile; a lane then owns 8 consecutive k of one column: one 16-B
 // store per plane, four lanes fill a column's 128-B block.  C % 64 == 0, ld % 4 == 0, Rp % 32 == 0.
+// `rows_dst` (optional): also the planes of s * src in ROW block layout [R][C / 32][2][32] (the operand layout of a product that
+// reduces over the columns) from the same tile: one read of the source for both orientations.
 __global__ __launch_bounds__(kBlock) void split_transpose_blocks_kernel(const float* __restrict__ src, int64_t R, int C, int64_t ld,
                                                                         const float* __restrict__ bound, _Float16* __restrict__ dst,
-                                                                        int64_t Rp) {
+                                                                        int64_t Rp, _Float16* __restrict__ rows_dst = nullptr) {
   __shared__ float tile[32][65];
   const int c0 = blockIdx.x * 64;
   const int64_t r0 = (int64_t)blockIdx.y * 32;
@@ -775,6 +777,22 @@ __global__ __launch_bounds__(kBlock) void split_transpose_blocks_kernel(const fl
   _Float16* out = dst + ((int64_t)(c0 + col) * (Rp >> 5) + blockIdx.y) * 64 + 8 * part;
   *reinterpret_cast<h8*>(out) = p0;
   *reinterpret_cast<h8*>(out + 32) = p1;
+  if (rows_dst) {
+    const int r = threadIdx.x >> 3, cg = threadIdx.x & 7;   // row of the tile, group of 8 columns (two k-blocks of four groups)
+    if (r0 + r < R) {
+      h8 q0, q1;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float v = tile[r][8 * cg + i] * s;
+        const _Float16 a = (_Float16)v;
+        q0[i] = a;
+        q1[i] = (_Float16)(v - (float)a);
+      }
+      _Float16* ro = rows_dst + (r0 + r) * (2 * (int64_t)C) + ((c0 >> 5) + (cg >> 2)) * 64 + 8 * (cg & 3);
+      *reinterpret_cast<h8*>(ro) = q0;
+      *reinterpret_cast<h8*>(ro + 32) = q1;
+    }
+  }
 }
 
 template <int TM, int TN>
@@ -1387,8 +1405,7 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
     a2_kernel<<<blocks(B * H2n), kBlock, 0, s_>>>(p.w3, H2m, B, H2n, a2);
     if (f16p) {
       // a2 = w3 * (H2 > 0): |a2| <= max|w3| exactly; its planes in both orientations, then a1 on the fp16 pipe against W2^T's planes
-      split_rows_blocks_kernel<<<blocks(B * (H2n / 4)), kBlock, 0, s_>>>(a2, B, H2n, H2n, t->bound + 3, t->a2p, H2n, 1);
-      split_transpose_blocks_kernel<<<dim3(H2n / 64, (unsigned)(Bk / 32)), kBlock, 0, s_>>>(a2, B, H2n, H2n, t->bound + 3, t->a2tp, Bk);
+      split_transpose_blocks_kernel<<<dim3(H2n / 64, (unsigned)(Bk / 32)), kBlock, 0, s_>>>(a2, B, H2n, H2n, t->bound + 3, t->a2tp, Bk, t->a2p);
       r = gemm_f16_planes(s_, t->a2p, B, t->w2tp, H1n, H2n, t->bound + 3, t->bound + 1, a1, H1n, H1m, H1n, plan_a1, 0);
     } else {
       r = nt_on(s_, a2, H2n, B, t->w2t, H2n, H1n, a1, H1n, H1m, H1n, 0);        // a1 = (a2 W2) * m1
@@ -1415,8 +1432,7 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
     if (f16p) {
       // e1's abs-max (16 MB) and planes in both orientations; gW2's penalty slices = a2^T e1 and da2 = e1 W2^T on the fp16 pipe
       amax_flat(s_, e1, B * H1n, t->bound + 4);   // (slot zeroed at the head of the side stream's work)
-      split_transpose_blocks_kernel<<<dim3(H1n / 64, (unsigned)(Bk / 32)), kBlock, 0, s_>>>(e1, B, H1n, H1n, t->bound + 4, t->e1tp, Bk);
-      split_rows_blocks_kernel<<<blocks(B * (H1n / 4)), kBlock, 0, s_>>>(e1, B, H1n, H1n, t->bound + 4, t->e1p, H1n, 1);
+      split_transpose_blocks_kernel<<<dim3(H1n / 64, (unsigned)(Bk / 32)), kBlock, 0, s_>>>(e1, B, H1n, H1n, t->bound + 4, t->e1tp, Bk, t->e1p);
       r = gemm_f16_planes(s_, t->a2tp, H2n, t->e1tp, H1n, (int)Bk, t->bound + 3, t->bound + 4, split + sl_w2[0] * n_w2, H1n, nullptr, 0,
                           plan_gw2p, n_w2);
     } else if (fork) {
