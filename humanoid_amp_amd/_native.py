@@ -78,8 +78,7 @@ class AmpHotStepArgs(C.Structure):
                 ("times", C.c_void_p), ("motion_ids", C.c_void_p), ("n_samples", C.c_int64), ("K", C.c_int32), ("reserved", C.c_int32),
                 ("expert_out", C.c_void_p), ("disc", C.c_void_p), ("reward_scale", C.c_float), ("task_weight", C.c_float),
                 ("style_weight", C.c_float), ("reserved2", C.c_int32), ("logits", C.c_void_p), ("style", C.c_void_p),
-                ("combined", C.c_void_p), ("workspace", C.c_void_p), ("compact", C.c_void_p), ("disc_stream", C.c_void_p),
-                ("wait_before_env", C.c_void_p), ("env_done", C.c_void_p), ("disc_done", C.c_void_p)]
+                ("combined", C.c_void_p), ("workspace", C.c_void_p), ("compact", C.c_void_p)]
 
 
 class AmpCommandArgs(C.Structure):
@@ -136,7 +135,7 @@ class AmpEnvBuffers(C.Structure):
         ("time_out", C.c_void_p), ("reset_mask", C.c_void_p), ("reset_tile_counts", C.c_void_p),
         ("disc_input", C.c_void_p), ("disc_input_stride", C.c_int64), ("scaler_mean", C.c_void_p), ("scaler_den", C.c_void_p),
         ("scaler_clip", C.c_float), ("disc_input_format", C.c_int32), ("disc_plane_scale", C.c_float),
-        ("reserved", C.c_int32),
+        ("amp_obs_read_next", C.c_int32),
     ]
 
 
@@ -158,7 +157,8 @@ class AmpDiscInputLayout(C.Structure):
 
 class AmpDiscPlanInfo(C.Structure):
     _fields_ = [("precision", C.c_int32), ("plan", C.c_int32), ("fused_rows", C.c_int64), ("chunk_rows", C.c_int64),
-                ("fused_min_rows", C.c_int64), ("env_overrides", C.c_int32), ("cu_count", C.c_int32)]
+                ("fused_min_rows", C.c_int64), ("env_overrides", C.c_int32), ("cu_count", C.c_int32), ("raw_input", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class AmpDiscDesc(C.Structure):
@@ -234,6 +234,8 @@ SIGNATURES = {
     "amp_disc_style_reward_prescaled": (C.c_int, [_vp, _vp, _i64, _f32, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "amp_disc_style_reward_prescaled_compact": (C.c_int, [_vp, _vp, _i64, _f32, _vp, _f32, _f32, _vp, _vp, _vp, _vp,
                                                           C.POINTER(AmpCompactArgs), _vp]),
+    "amp_disc_style_reward_compact": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp, _f32, _f32, _vp, _vp, _vp, _vp,
+                                                C.POINTER(AmpCompactArgs), _vp]),
     "amp_hot_step": (C.c_int, [C.POINTER(AmpHotStepArgs), _vp]),
     "amp_disc_train_tt_plan": (C.c_int, [_i32, _i32, _i64, _i64, _i64, _i64, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "amp_disc_style_reward": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -414,6 +414,12 @@ static int f16_kernels_init() {
   AMP_HIP((dma_kernel_init<1, 2, 1, 4>()));
   AMP_HIP((dma_kernel_init<1, 1, 1, 4>()));
   AMP_HIP((dma_kernel_init<1, 1, 1>()));
+  AMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_mlp_fused_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              FusedLds<4>::kBytes));
+  AMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_mlp_fused_kernel<5, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              FusedLds<5>::kBytes));
+  AMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_mlp_fused_kernel<6, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              FusedLds<6>::kBytes));
   AMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_mlp_fused_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               FusedLds<4>::kBytes));
   AMP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(disc_mlp_fused_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -482,9 +488,14 @@ static bool f16_use_dma(const AmpDisc* h, int64_t rows) { return f16_plan(h, row
 static int64_t f16_chunk_rows(const AmpDisc* h, int64_t rows) {
   return f16_plan(h, kChunkRows) == kPlanDmaLarge && rows > kChunkRows + kChunkRows / 2 ? kChunkRows : rows;
 }
+// fp32 observation rows handed straight to the fused two-layer kernel (its RAWX instantiation scales / clamps / splits them itself)
+struct RawRows { const float* x; int64_t ld; };
+// ... possible when the whole batch takes the fused kernel, a clamping scaler bounds the input, and the rows are 8-B aligned pairs
+static bool raw_rows_ok(const AmpDisc* h, int64_t rows, const float* x, int64_t row_stride);
+
 static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* amax, int64_t rows, _Float16* H1p, float* partial,
                             float scale, const float* task, float task_w, float style_w, float* logits, float* style,
-                            float* combined, hipStream_t st, const CompactLaunch* compact = nullptr) {
+                            float* combined, hipStream_t st, const CompactLaunch* compact = nullptr, const RawRows* raw = nullptr) {
   // every kernel below accumulates in the same order and emits the same canonical partial logits (one per row and
   // 32-column block), so the choice changes the time, never a bit of the result
   const int64_t n_fused = fused_rows_of(h, rows);  // leading rows on the fused two-layer kernel (no hidden layer in memory)
@@ -497,7 +508,16 @@ static int disc_forward_f16(const AmpDisc* h, const _Float16* Xp, const float* a
     f.W1b = h->w1b; f.W2b = h->w2b; f.b1 = h->b1; f.b2 = h->b2; f.w3 = h->w3;
     f.range = h->range; f.amax = amax; f.h1 = h->h1; f.partial = partial;
     const unsigned grid = (unsigned)((n_fused + kFusedRows - 1) / kFusedRows);
-    { amp::TraceScope trace__("disc_mlp_fused_kernel", st);
+    if (raw) {
+      AMP_REQUIRE(n_fused == rows, "disc_forward_f16: raw rows need the whole batch on the fused kernel");
+      f.raw = raw->x; f.raw_ld = raw->ld; f.raw_cols = h->in_dim; f.mean = h->mean; f.den = h->den; f.clip = h->clip;
+      f.s_x = plane_scale(h->clip);
+      amp::TraceScope trace__("disc_mlp_fused_kernel", st);
+      if (h->k1h == 128) disc_mlp_fused_kernel<4, true><<<grid, kFusedThreads, FusedLds<4>::kBytes, st>>>(f);
+      else if (h->k1h == 160) disc_mlp_fused_kernel<5, true><<<grid, kFusedThreads, FusedLds<5>::kBytes, st>>>(f);
+      else disc_mlp_fused_kernel<6, true><<<grid, kFusedThreads, FusedLds<6>::kBytes, st>>>(f);
+    } else {
+      amp::TraceScope trace__("disc_mlp_fused_kernel", st);
       if (h->k1h == 128) disc_mlp_fused_kernel<4><<<grid, kFusedThreads, FusedLds<4>::kBytes, st>>>(f);
       else if (h->k1h == 160) disc_mlp_fused_kernel<5><<<grid, kFusedThreads, FusedLds<5>::kBytes, st>>>(f);
       else disc_mlp_fused_kernel<6><<<grid, kFusedThreads, FusedLds<6>::kBytes, st>>>(f);
@@ -803,6 +823,10 @@ static DiscWorkspace disc_workspace(const AmpDisc* h, int64_t rows, void* base) 
 }
 // the clamp bounds the scaled input only when a scaler with a finite positive clamp is set
 static bool static_bound(const AmpDisc* h) { return h->has_scaler && h->clip > 0.0f && h->clip < 1e30f; }
+static bool raw_rows_ok(const AmpDisc* h, int64_t rows, const float* x, int64_t row_stride) {
+  return h->mode == AMP_DISC_F16X3 && static_bound(h) && rows >= kFusedRows && fused_rows_of(h, rows) == rows && (h->in_dim & 1) == 0 &&
+         (row_stride & 1) == 0 && ((uintptr_t)x & 7) == 0;
+}
 }  // namespace amp
 
 int64_t amp_disc_workspace_bytes(const AmpDisc* h, int64_t rows) {
@@ -823,6 +847,14 @@ int amp_disc_style_reward(const AmpDisc* h, const float* x, int64_t rows, int64_
   hipStream_t st = (hipStream_t)stream;
   const DiscWorkspace ws = disc_workspace(h, rows, workspace);
   const float* mean = h->has_scaler ? h->mean : nullptr;
+  if (raw_rows_ok(h, rows, x, row_stride)) {
+    // the whole batch takes the fused two-layer kernel: it reads the fp32 rows itself (no scaler pass, no scaled copy)
+    const RawRows raw{x, row_stride};
+    const int rc = disc_forward_f16(h, nullptr, nullptr, rows, (_Float16*)ws.h1, ws.partial, scale, task, task_w, style_w, logits, style,
+                                    combined, st, nullptr, &raw);
+    if (rc == AMP_OK && inputs_consumed) AMP_HIP(hipEventRecord((hipEvent_t)inputs_consumed, st));  // (here: after the whole call)
+    return rc;
+  }
   if (h->mode == AMP_DISC_F16X3) {
     const float* amax = nullptr;
     if (!static_bound(h)) {  // no clamp: the bound of the scaled input is its abs-max (one extra pass)
@@ -894,6 +926,7 @@ int amp_disc_plan_info(const AmpDisc* h, int64_t rows, AmpDiscPlanInfo* out) {
     return AMP_OK;
   }
   out->fused_rows = fused_rows_of(h, rows);
+  out->raw_input = raw_rows_ok(h, rows, nullptr, 0) ? 1 : 0;
   const int64_t rest = rows - out->fused_rows;
   out->chunk_rows = rest > 0 ? f16_chunk_rows(h, rest) : 0;
   out->plan = f16_plan(h, rest > 0 ? out->chunk_rows : rows);  // kPlan* ids 0..4 ARE the AMP_DISC_PLAN_* values
@@ -930,6 +963,33 @@ int amp_disc_style_reward_prescaled_compact(const AmpDisc* h, const void* xs_any
     return style_reward_prescaled_impl(h, xs_any, rows, scale, task, task_w, style_w, logits, style, combined, workspace, stream, nullptr);
   }
   return style_reward_prescaled_impl(h, xs_any, rows, scale, task, task_w, style_w, logits, style, combined, workspace, stream, &cl);
+}
+
+int amp_disc_style_reward_compact(const AmpDisc* h, const float* x, int64_t rows, int64_t row_stride, float scale, const float* task,
+                                  float task_w, float style_w, float* logits, float* style, float* combined, void* workspace,
+                                  const AmpCompactArgs* c, amp_stream_t stream) {
+  AMP_REQUIRE(h && c && x && workspace, "amp_disc_style_reward_compact: null argument");
+  AMP_REQUIRE(c->num_envs >= 1 && c->mask && c->tile_counts && c->ids && c->count, "amp_disc_style_reward_compact: null compaction buffer");
+  AMP_REQUIRE(c->tile_envs == 8 || c->tile_envs == 16 || c->tile_envs == 32 || c->tile_envs == 64, "amp_disc_style_reward_compact: tile_envs must be 8, 16, 32 or 64");
+  AMP_REQUIRE(rows >= 1 && rows <= ((int64_t)1 << 30), "amp_disc_style_reward_compact: rows out of range");
+  AMP_REQUIRE(row_stride >= h->in_dim, "amp_disc_style_reward_compact: row_stride %lld < in_dim %d", (long long)row_stride, h->in_dim);
+  AMP_REQUIRE((uintptr_t)workspace % 16 == 0, "amp_disc_style_reward_compact: workspace must be 16-byte aligned");
+  if (!raw_rows_ok(h, rows, x, row_stride)) {
+    // any other plan / engine: the two calls it stands for, back to back (same results)
+    const int rc = amp_reset_compact_tiles(c->mask, c->tile_counts, c->tile_envs, c->num_envs, c->ids, c->count, stream);
+    if (rc != AMP_OK) return rc;
+    return amp_disc_style_reward(h, x, rows, row_stride, scale, task, task_w, style_w, logits, style, combined, workspace, nullptr, stream);
+  }
+  CompactLaunch cl;
+  cl.mask = c->mask; cl.counts = c->tile_counts; cl.N = c->num_envs;
+  cl.n_tiles = (c->num_envs + kTile - 1) / kTile;
+  cl.n_counts = (c->num_envs + c->tile_envs - 1) / c->tile_envs;
+  cl.sub = kTile / c->tile_envs; cl.ids = c->ids; cl.count = c->count;
+  cl.blocks = (int)((cl.n_tiles + 3) / 4);
+  const DiscWorkspace ws = disc_workspace(h, rows, workspace);
+  const RawRows raw{x, row_stride};
+  return disc_forward_f16(h, nullptr, nullptr, rows, (_Float16*)ws.h1, ws.partial, scale, task, task_w, style_w, logits, style, combined,
+                          (hipStream_t)stream, &cl, &raw);
 }
 
 static int style_reward_prescaled_impl(const AmpDisc* h, const void* xs_any, int64_t rows, float scale, const float* task, float task_w,

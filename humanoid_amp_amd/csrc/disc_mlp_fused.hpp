@@ -55,6 +55,13 @@ struct FusedArgs {
   const DiscRange* range; const float* amax;
   int32_t h1;                                  // hidden units (multiple of 32, <= 1024)
   float* partial;                              // [M, 16] canonical partial logits
+  // RAWX instantiation: the activation fragments come straight from the fp32 observation rows -- the kernel applies the scaler,
+  // the clamp and the plane split to its 8 KX elements per lane itself (the arithmetic of disc_scale_split_kernel / of the env
+  // step's fused scaler, operation for operation: the same bits), so no scaled copy of the input is ever written
+  const float* raw; int64_t raw_ld;            // [M, raw_cols] fp32 rows, pitch raw_ld floats (even; rows 8-B aligned)
+  int32_t raw_cols;                            // K D (even); columns in [raw_cols, 32 KX) are zero
+  const float* mean; const float* den;         // scaler vectors (fp32, >= raw_cols entries)
+  float clip, s_x;                             // the clamp and the input planes' scale
 };
 
 constexpr int kFusedThreads = 512, kFusedRows = 128, kFusedN2 = 512;
@@ -80,7 +87,7 @@ extern "C" int amp_debug_fused_timeline(unsigned long long* buf) {
 #else
 #define AMP_FUSED_STAMP(slot) do {} while (0)
 #endif
-template <int KX>
+template <int KX, bool RAWX = false>
 __global__ __launch_bounds__(kFusedThreads, 2) void disc_mlp_fused_kernel(FusedArgs g) {
   using L = FusedLds<KX>;
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
@@ -96,7 +103,24 @@ __global__ __launch_bounds__(kFusedThreads, 2) void disc_mlp_fused_kernel(FusedA
 
   // ---- activation fragments of the wave's 16 layer-1 rows: B operand, lane (i, kq) = row i, k = 32 kbx + 8 kq .. + 7 ----------
   h8 x[KX][2];
-  {
+  // RAWX: the fp32 row pieces, scaler means and denominators of the lane's 8 KX columns are REQUESTED here (column pairs (c, c + 1),
+  // c even: one 8-B load each; K D is even, so a pair is wholly inside or outside the row) and converted behind the first stage
+  // fills' issue, so that the ~1 000 VALU operations of the conversion run under the fills' latency
+  typedef float f2_t __attribute__((ext_vector_type(2)));
+  f2_t rv[RAWX ? KX : 1][4], rmu[RAWX ? KX : 1][4], rdn[RAWX ? KX : 1][4];
+  if constexpr (RAWX) {
+    const float* rr = g.raw + (m0 + 16 * wave + i16) * g.raw_ld + 8 * kq;
+#pragma unroll
+    for (int kb = 0; kb < KX; ++kb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = 32 * kb + 8 * kq + 2 * j;
+        const bool in = c < g.raw_cols;
+        rv[kb][j] = in ? *reinterpret_cast<const f2_t*>(rr + 32 * kb + 2 * j) : f2_t{0.0f, 0.0f};
+        rmu[kb][j] = in ? *reinterpret_cast<const f2_t*>(g.mean + c) : f2_t{0.0f, 0.0f};
+        rdn[kb][j] = in ? *reinterpret_cast<const f2_t*>(g.den + c) : f2_t{1.0f, 1.0f};
+      }
+  } else {
     const _Float16* xr = g.X + (m0 + 16 * wave + i16) * (2 * g.ldx) + 8 * kq;
 #pragma unroll
     for (int kb = 0; kb < KX; ++kb) {
@@ -161,6 +185,22 @@ __global__ __launch_bounds__(kFusedThreads, 2) void disc_mlp_fused_kernel(FusedA
 #pragma unroll
   for (int u = 0; u < 2; ++u) b1raw[u] = tid + u * kFusedThreads < g.h1 ? g.b1[tid + u * kFusedThreads] : 0.0f;
   __builtin_amdgcn_sched_barrier(0);
+  if constexpr (RAWX) {
+    // scaler, clamp, plane split: the arithmetic of disc_scale_split_kernel and of the env step's fused scaler, operation for operation
+    const float clip = g.clip, s_x = g.s_x;
+#pragma unroll
+    for (int kb = 0; kb < KX; ++kb)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float t = ((i & 1) ? rv[kb][i >> 1].y : rv[kb][i >> 1].x) - ((i & 1) ? rmu[kb][i >> 1].y : rmu[kb][i >> 1].x);
+        t = t / ((i & 1) ? rdn[kb][i >> 1].y : rdn[kb][i >> 1].x);   // skrl RunningStandardScaler: exact fp32 divide
+        t = fminf(fmaxf(t, -clip), clip);
+        const float y = t * s_x;
+        const _Float16 a = (_Float16)y;
+        x[kb][0][i] = a;
+        x[kb][1][i] = (_Float16)(y - (float)a);
+      }
+  }
   const LayerScales sc1 = layer_scales(g.range, g.amax, 1);
   const float s_h = sc1.s_out, ds = sc1.descale * s_h;
   const float descale2 = layer_scales(g.range, g.amax, 2).descale;

@@ -603,10 +603,18 @@ __device__ __forceinline__ void env_step_dma_pass(const EnvPlan& p, const AmpSim
      // hidden layer the GEMMs are about to stream through (measured: 328 -> 320 us per step at 65 536 envs)
     const f4* img4 = reinterpret_cast<const f4*>(s_img);
     f4* dst4 = reinterpret_cast<f4*>(buf);
-    for (int i = tid; i < T * KD / 4; i += kBlock) __builtin_nontemporal_store(img4[i], dst4 + i);
+    if (bf.amp_obs_read_next) {
+      for (int i = tid; i < T * KD / 4; i += kBlock) dst4[i] = img4[i];
+    } else {
+      for (int i = tid; i < T * KD / 4; i += kBlock) __builtin_nontemporal_store(img4[i], dst4 + i);
+    }
   }
   AMP_ENV_STAMP(5);  // AMP buffer stores issued
+#ifdef AMP_ENV_XP_NO_DISC_WALK   // ABLATION builds only (results wrong): what the launch gives back if the discriminator's input is not produced here
+  if (false) {
+#else
   if (fused) {
+#endif
     // the same rows, scaled, as the discriminator's input.  A lane owns the column pair (c, c + 1) -- c even, so both
     // sit in one 32-column k-block -- and walks rows r0, r0 + step, ...; `scaled` / `blocks` are compile-time inside
     // the row loop (one instantiation per combination, picked once)

@@ -1,6 +1,6 @@
 // One env-step of the hot path issued by ONE call across the C ABI: amp_env_step_with_reference (dones + task reward +
 // observations + fused scaler + expert-motion sample) followed by amp_disc_style_reward_prescaled_compact (layer 1, layer 2,
-// finalize + reset-id compaction).  Nothing new is computed here: it is the launch sequence of humanoid_amp_amd/workloads.py's
+// finalize + reset-id compaction) -- or, without a fused scaler, by amp_disc_style_reward_compact on the raw AMP rows.  Nothing new is computed here: it is the launch sequence of humanoid_amp_amd/workloads.py's
 // HotPath.step() moved below the ABI, because on the 8 192-env shards of the multi-GPU configurations the GPU needs ~64 us
 // per step while four separate ctypes calls with their argument marshalling cost the host ~90 us: the step was HOST-bound.
 // Launches are asynchronous on `stream` as everywhere else; one call costs the host four kernel launches.
@@ -10,11 +10,8 @@ extern "C" {
 
 int amp_hot_step(const AmpHotStepArgs* a, amp_stream_t stream) {
   AMP_REQUIRE(a && a->cfg && a->state && a->bufs && a->disc && a->compact, "amp_hot_step: null argument");
-  AMP_REQUIRE(a->bufs->disc_input && a->bufs->reward, "amp_hot_step: the env buffers need disc_input (fused scaler) and reward");
+  AMP_REQUIRE(a->bufs->reward && a->bufs->amp_obs_buffer, "amp_hot_step: the env buffers need reward and amp_obs_buffer");
   int rc;
-  const bool two = a->disc_stream != nullptr;
-  AMP_REQUIRE(!two || (a->env_done && a->disc_done), "amp_hot_step: the two-stream schedule needs env_done and disc_done events");
-  if (two && a->wait_before_env) AMP_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)a->wait_before_env, 0));
   if (a->motion) {
     rc = amp_env_step_with_reference(a->cfg, a->state, a->bufs, a->num_envs, AMP_PHASE_DONES | AMP_PHASE_REWARD | AMP_PHASE_OBS, a->motion,
                                      a->times, a->motion_ids, a->n_samples, a->K, a->expert_out, stream);
@@ -22,17 +19,15 @@ int amp_hot_step(const AmpHotStepArgs* a, amp_stream_t stream) {
     rc = amp_env_step(a->cfg, a->state, a->bufs, a->num_envs, AMP_PHASE_DONES | AMP_PHASE_REWARD | AMP_PHASE_OBS, stream);
   }
   if (rc != AMP_OK) return rc;
-  amp_stream_t ds = stream;
-  if (two) {
-    AMP_HIP(hipEventRecord((hipEvent_t)a->env_done, (hipStream_t)stream));
-    AMP_HIP(hipStreamWaitEvent((hipStream_t)a->disc_stream, (hipEvent_t)a->env_done, 0));
-    ds = a->disc_stream;
+  if (!a->bufs->disc_input) {
+    // no fused scaler: the discriminator reads the AMP rows the env launch just wrote ([N, K D] fp32, D = 2 n_dof + 13 + 3 n_key)
+    const int64_t row = (int64_t)a->cfg->num_amp_observations * (2 * a->cfg->n_dof + 13 + 3 * a->cfg->n_key);
+    return amp_disc_style_reward_compact(a->disc, a->bufs->amp_obs_buffer, a->num_envs, row, a->reward_scale, a->bufs->reward, a->task_weight,
+                                         a->style_weight, a->logits, a->style, a->combined, a->workspace, a->compact, stream);
   }
-  rc = amp_disc_style_reward_prescaled_compact(a->disc, a->bufs->disc_input, a->num_envs, a->reward_scale, a->bufs->reward,
+  return amp_disc_style_reward_prescaled_compact(a->disc, a->bufs->disc_input, a->num_envs, a->reward_scale, a->bufs->reward,
                                                  a->task_weight, a->style_weight, a->logits, a->style, a->combined, a->workspace,
-                                                 a->compact, ds);
-  if (rc == AMP_OK && two) AMP_HIP(hipEventRecord((hipEvent_t)a->disc_done, (hipStream_t)a->disc_stream));
-  return rc;
+                                                 a->compact, stream);
 }
 
 }  // extern "C"

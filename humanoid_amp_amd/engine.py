@@ -133,6 +133,7 @@ class EnvStepKernel:
         b.reward, b.reward_terms = p(self.reward), p(self.reward_terms)
         b.died, b.time_out, b.reset_mask = p(self.died), p(self.time_out), p(self.reset_mask)
         b.reset_tile_counts = p(self.reset_tile_counts)
+        b.amp_obs_read_next = int(bool(getattr(self, "amp_obs_read_next", False)))  # a discriminator that takes the raw rows reads them next
         if self.disc_input is not None:
             lay = self._disc_layout
             b.disc_input, b.disc_input_stride = self.disc_input.data_ptr(), lay.padded_dim  # elements per row
@@ -567,7 +568,8 @@ class AmpDiscriminator:
                if p.env_overrides & bit]
         return {"precision": "f32" if p.precision == nat.AMP_DISC_FP32 else "f16x3", "plan": int(p.plan),
                 "plan_name": self.PLAN_NAMES.get(int(p.plan), "?"), "fused_rows": int(p.fused_rows), "chunk_rows": int(p.chunk_rows),
-                "fused_min_rows": int(p.fused_min_rows), "env_overrides": env, "cu_count": int(p.cu_count)}
+                "fused_min_rows": int(p.fused_min_rows), "env_overrides": env, "cu_count": int(p.cu_count),
+                "raw_input": bool(p.raw_input)}
 
     def style_reward_prescaled(self, scaled: torch.Tensor, task_reward: Optional[torch.Tensor] = None, *,
                                want_logits: bool = False, compact: Optional["EnvStepKernel"] = None):

@@ -87,19 +87,11 @@ class HotPath:
     def __init__(self, spec: WorkloadSpec, num_envs: int, device, seed: int = 0, log_reward_terms: bool = False,
                  overlap: bool = False, fused_scaler: bool = True, disc_precision: str = "f16x3",
                  expert_stream: bool = False, fused_expert: bool = True, state: dict | None = None, state_sets: int = 1,
-                 fused_tail: bool = True, one_call: bool = True, two_streams: bool = False):
+                 fused_tail: bool = True, one_call: bool = True):
         """``state``: use this synthetic state (a ``make_state`` dict on the device, e.g. a row block of a larger
         shard's state) instead of drawing one from ``seed``.  ``state_sets`` > 1: that many independently drawn input
         sets (seeds ``seed + 7919 i``), visited round-robin by successive steps, so that a benchmark's state reads are
         not served by the 256 MB Infinity Cache from the previous step's identical addresses.
-
-        ``two_streams`` (needs the default one-call path): ``amp_hot_step``'s two-stream schedule -- the discriminator
-        half of step t (layer 1, layer 2, tail) runs on a side stream while the env launch of step t + 1 runs on the
-        current stream, with everything the two halves hand over double-buffered by step parity (two
-        :class:`EnvStepKernel` objects sharing the AMP history and the policy observation).  On the 8 192-env shards of
-        the multi-GPU configurations the env launch is latency-bound (12.6 of the step's 63.6 us) and fits under the
-        GEMMs.  ``step()`` then returns the parity's fixed ``[N, 1]`` output tensors (valid until the step after next);
-        ``self.kernel`` is the parity of the LAST step; ``synchronize()`` joins both streams.
 
         ``overlap``: run the discriminator on a second HIP stream so that the HBM-bound kernels of step t+1
         (motion sample, env step, compaction) execute under the MFMA-bound GEMMs of step t.  The style reward is
@@ -120,9 +112,6 @@ class HotPath:
         self.overlap = bool(overlap)
         self.fused_tail = bool(fused_tail)  # compaction + finalize as one launch (amp_disc_style_reward_prescaled_compact)
         self.one_call = bool(one_call)      # the whole step as one amp_hot_step call on prebuilt arguments
-        self.two_streams = bool(two_streams)
-        if self.two_streams and (overlap or expert_stream or not (one_call and fused_scaler and fused_tail and fused_expert)):
-            raise nat.AmpEngineError("two_streams needs the default one-call path (fused scaler / tail / expert, no other overlap mode)")
         self.fused_scaler = bool(fused_scaler) and not self.overlap  # the overlapped schedule needs the snapshot pass
         self.device = nat.require_gpu(device)
         files = ",".join(os.path.join(MOTIONS_DIR, c + ".npz") for c in spec.clips)
@@ -154,24 +143,15 @@ class HotPath:
                                      running_variance=torch.ones(spec.K * D, dtype=torch.float64),
                                      task_reward_weight=spec.task_weight, style_reward_weight=spec.style_weight,
                                      precision=disc_precision)
+        # a shard whose whole batch takes the one-launch two-layer kernel: that kernel reads the AMP rows itself (scaler, clamp and
+        # plane split on the 48 elements a lane holds), so the env step writes no discriminator input at all
+        self.raw_rows = self.fused_scaler and self.fused_tail and self.one_call and bool(self.disc.plan_info(self.num_envs)["raw_input"])
+        if self.raw_rows:
+            self.fused_scaler = False
+            self.kernel.amp_obs_read_next = True   # ... and keeps the rows in the cache hierarchy for it (default store policy)
         if self.fused_scaler:  # the env step emits the discriminator's scaled input directly (no separate scaler pass)
             self.kernel.attach_discriminator(self.disc)
         self._kernels = [self.kernel]
-        if self.two_streams:
-            # second parity: its own hand-over buffers (scaled input, task reward, done bits, reset mask / counts / ids), the
-            # SAME AMP history (shifted in place by consecutive env launches of one stream) and policy observation
-            k2 = EnvStepKernel(self.cfg, self.num_envs, self.device, log_reward_terms=log_reward_terms)
-            k2.amp_observation_buffer, k2.policy_obs = self.kernel.amp_observation_buffer, self.kernel.policy_obs
-            k2.attach_discriminator(self.disc)
-            self._kernels.append(k2)
-            self._side = torch.cuda.Stream(device=self.device)
-            self._ev_env = [torch.cuda.Event(), torch.cuda.Event()]
-            self._ev_disc = [torch.cuda.Event(), torch.cuda.Event()]
-            for ev in self._ev_env + self._ev_disc:  # torch creates the hipEvent lazily: force it, the C ABI needs the handle
-                ev.record(self._side)
-            f32 = dict(dtype=torch.float32, device=self.device)
-            self._outs = [{"style": torch.empty((self.num_envs, 1), **f32), "combined": torch.empty((self.num_envs, 1), **f32)}
-                          for _ in range(2)]
         # expert rows are a plausible AMP history to start from
         self.motion.collect_reference(self.state["motion_times"], self.state["motion_ids"], spec.K,
                                       out=self.kernel.amp_observation_buffer)
@@ -236,10 +216,6 @@ class HotPath:
             a.reward_scale, a.task_weight, a.style_weight = self.disc.reward_scale, self.disc.task_reward_weight, self.disc.style_reward_weight
             a.logits = None  # style / combined are set per step
             a.workspace, a.compact = ws.data_ptr(), C.addressof(c)
-            if self.two_streams:
-                a.disc_stream = self._side.cuda_stream
-                a.env_done, a.disc_done = self._ev_env[par].cuda_event, self._ev_disc[par].cuda_event
-                a.style, a.combined = self._outs[par]["style"].data_ptr(), self._outs[par]["combined"].data_ptr()
             self._hot_keep.append((s, b, c))
             per_parity.append(a)
           args.append(per_parity)
@@ -259,22 +235,11 @@ class HotPath:
         i = (self._n if which is None else which) % len(self.states)
         s, k = self.states[i], self.kernel
         self.state, self._sim = s, self._sims[i]
-        if self.one_call and self.fused_scaler and self.fused_tail and self.fused_expert and not self.overlap:
+        if self.one_call and (self.fused_scaler or self.raw_rows) and self.fused_tail and self.fused_expert and not self.overlap:
             import ctypes as C
 
             if self._hot_args is None or self._hot_ptrs != self._hot_pointer_key():
                 self._build_hot_args()
-            if self.two_streams:
-                par = self._n & 1
-                a = self._hot_args[i][par]
-                # this parity's buffers were last read by the discriminator half of step n - 2
-                a.wait_before_env = self._ev_disc[par].cuda_event if self._n >= 2 else None
-                with torch.cuda.device(self.device):
-                    nat.check(self._hot_lib.amp_hot_step(C.byref(a), nat.stream_ptr()), "amp_hot_step")
-                self.kernel = self._kernels[par]
-                self._n += 1
-                self.last = self._outs[par]
-                return self.last
             a = self._hot_args[i][0]
             # fresh [N, 1] outputs per step (a caller may keep earlier steps' results), everything else is prebuilt
             style = torch.empty((self.num_envs, 1), dtype=torch.float32, device=self.device)
@@ -325,8 +290,8 @@ class HotPath:
         """Capture one env-step into a hipGraph (every engine launch is asynchronous on the caller's stream and
         allocation-free, so the whole step is capturable); later ``step()`` calls replay it.  Pays off when the
         shard is small enough for the step to be launch-bound (a few thousand envs)."""
-        if self.overlap or self.two_streams:
-            raise nat.AmpEngineError("graph capture and the two-stream schedules are mutually exclusive")
+        if self.overlap:
+            raise nat.AmpEngineError("graph capture and the overlapped schedule are mutually exclusive")
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):

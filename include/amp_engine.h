@@ -255,7 +255,8 @@ typedef struct {
   float scaler_clip;
   int32_t disc_input_format;
   float disc_plane_scale;
-  int32_t reserved;
+  int32_t amp_obs_read_next; /* 1: the kernel that follows reads amp_obs_buffer (a discriminator taking the raw rows): store it with the
+                              * default cache policy; 0: non-temporal stores (nothing in the step reads the rows back) */
 } AmpEnvBuffers;
 
 enum { AMP_PHASE_DONES = 1, AMP_PHASE_REWARD = 2, AMP_PHASE_OBS = 4 };
@@ -466,6 +467,10 @@ typedef struct {
   int64_t fused_min_rows;   /* the fused plan's threshold in force (INT64_MAX: switched off) */
   int32_t env_overrides;    /* AMP_ENV_* bits: which of the environment switches are SET in this process */
   int32_t cu_count;         /* compute units the plans were sized for */
+  int32_t raw_input;        /* 1: the whole batch takes the fused kernel AND that kernel can read fp32 observation rows itself (clamping
+                             * scaler, even in_dim): amp_disc_style_reward(_compact) then run no scaler pass, and an env step need not
+                             * produce disc_input for this batch size (8-B aligned rows of even stride assumed) */
+  int32_t reserved;
 } AmpDiscPlanInfo;
 int amp_disc_plan_info(const AmpDisc* h, int64_t rows, AmpDiscPlanInfo* out);
 /* Per-handle plan choice, overriding the process environment and the measured defaults (what tests and A/B measurements use
@@ -502,15 +507,28 @@ int amp_disc_style_reward_prescaled_compact(const AmpDisc* h, const void* scaled
                                             float* logits_dev, float* style_dev, float* combined_dev, void* workspace_dev,
                                             const AmpCompactArgs* compact, amp_stream_t stream);
 
+/* amp_disc_style_reward + amp_reset_compact_tiles with ONE tail launch, on the RAW observation rows: where the whole batch takes the
+ * one-launch two-layer kernel (amp_disc_plan_info: fused_rows == rows; fp16-split engine, clamping scaler, even in_dim / row_stride,
+ * 8-B aligned rows) that kernel reads the fp32 rows itself and applies scaler, clamp and plane split to the 48 elements a lane
+ * holds -- no scaler pass, no scaled copy of the input in memory; everywhere else it is the two calls back to back.  Same results
+ * bit for bit as amp_disc_style_reward (skrl's amp_state_preprocessor + discriminator forward, third-party: parity unpinned;
+ * agents/skrl_g1_walk_amp_cfg.yaml:31-39,77-78). */
+int amp_disc_style_reward_compact(const AmpDisc* h, const float* amp_obs_dev, int64_t rows, int64_t row_stride, float reward_scale,
+                                  const float* task_reward_dev, float task_weight, float style_weight, float* logits_dev,
+                                  float* style_dev, float* combined_dev, void* workspace_dev, const AmpCompactArgs* compact,
+                                  amp_stream_t stream);
+
 /* One env-step of the hot path (motion sample + sim AMP obs / history / policy obs + dones + reset ids +
  * task reward + style reward) issued by ONE call: amp_env_step_with_reference(all phases) followed by
- * amp_disc_style_reward_prescaled_compact on bufs->disc_input / bufs->reward.  Same launches, same results; it exists
+ * amp_disc_style_reward_prescaled_compact on bufs->disc_input / bufs->reward -- or, when bufs->disc_input is NULL (no fused
+ * scaler: what a shard whose whole batch takes the fused two-layer kernel wants), by amp_disc_style_reward_compact on the rows of
+ * bufs->amp_obs_buffer.  Same launches, same results; it exists
  * because four separately marshalled calls cost the host more than a small shard's step costs the GPU.  Every pointer
  * is borrowed for the duration of the enqueue; motion == NULL skips the expert-motion sample. */
 typedef struct {
   const AmpEnvCfg* cfg;
   const AmpSimState* state;
-  const AmpEnvBuffers* bufs;    /* needs disc_input (fused scaler, amp_disc_input_layout of `disc`) and reward */
+  const AmpEnvBuffers* bufs;    /* needs reward; disc_input (fused scaler, amp_disc_input_layout of `disc`) or NULL (raw rows) */
   int64_t num_envs;
   const AmpMotion* motion;      /* expert-motion sample of the step, or NULL */
   const double* times;          /* dev [n_samples] */
@@ -527,17 +545,6 @@ typedef struct {
   float* combined;              /* dev [num_envs] or NULL */
   void* workspace;              /* amp_disc_workspace_bytes(disc, num_envs) */
   const AmpCompactArgs* compact;
-  /* Optional two-stream schedule (all four NULL = everything on `stream`): the discriminator half runs on disc_stream so
-   * that the NEXT step's env launch (latency-bound on a small shard) executes under this step's GEMMs.  The caller
-   * double-buffers what the two halves hand over (bufs->disc_input / reward / reset mask + tile counts, compact outputs,
-   * style / combined) by step parity and passes, per parity, two events:
-   *   env launch:   waits wait_before_env (the disc_done of the step that last used this parity's buffers; NULL on the
-   *                 first use), then records env_done on `stream`;
-   *   disc launches: disc_stream waits env_done, runs layer 1 / layer 2 / tail, records disc_done. */
-  amp_stream_t disc_stream;
-  amp_event_t wait_before_env;
-  amp_event_t env_done;
-  amp_event_t disc_done;
 } AmpHotStepArgs;
 int amp_hot_step(const AmpHotStepArgs* args, amp_stream_t stream);
 

@@ -41,7 +41,7 @@ def test_gemm_kernels_use_no_scratch(tmp_path):
     assert len(dma) >= 5 and all(v[1] <= 256 for v in dma.values()), dma   # 8 waves per workgroup: 256 registers each
     # the fused two-layer kernel (round 4) lives at 254 of 256 registers: one more long-lived address register and it spills
     fused = {k: v for k, v in every.items() if "disc_mlp_fused_kernel" in k}
-    assert len(fused) == 3 and all(v[0] == 0 and v[1] <= 256 for v in fused.values()), fused   # KX = 4, 5, 6 (K D in (96, 192])
+    assert len(fused) == 6 and all(v[0] == 0 and v[1] <= 256 for v in fused.values()), fused   # KX = 4, 5, 6 x {plane input, raw fp32 rows}
 
 
 def test_training_step_gemm_kernels_use_no_scratch(tmp_path):

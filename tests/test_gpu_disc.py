@@ -422,3 +422,62 @@ def test_set_plan_switches_the_fused_kernel_per_handle_without_changing_a_bit():
     assert d.plan_info(4096)["plan_name"] == "LDS-DMA 128x128 + 64x128" and d.plan_info(100)["plan"] == 0
     with pytest.raises(nat.AmpEngineError):
         d.set_plan(fused=True, fused_min_rows=5)
+
+
+def test_raw_row_input_of_the_fused_kernel_is_bit_identical_to_the_plane_input():
+    """Where the whole batch takes the one-launch two-layer kernel it reads the fp32 observation rows itself (scaler, clamp and
+    plane split of the 48 elements a lane holds: `disc_mlp_fused_kernel<KX, true>`), so neither a scaler pass nor the env step's
+    fused scaler writes a scaled copy.  Same arithmetic, same bits: (1) style_reward on 32 768 rows (raw rows) == the same rows
+    through the plane input (the fused plan switched off and on with a threshold that makes the batch a partial round is not needed:
+    the two-kernel plans consume planes); (2) the hot path at 32 768 envs through amp_hot_step's raw-row branch == the same steps
+    with the env step's fused scaler feeding plane blocks (one_call=False keeps the attached layout), over K + 2 steps; (3) odd row
+    strides / unaligned rows fall back to the scaler pass and still agree."""
+    import contextlib
+    import io
+
+    from humanoid_amp_amd import _native as nat
+    from humanoid_amp_amd.engine import AmpDiscriminator
+    from humanoid_amp_amd.workloads import WORKLOADS, HotPath
+
+    g = torch.Generator().manual_seed(21)
+    w = odisc.make_weights(166, seed=6)
+    x = (torch.randn(32768, 166, generator=g) * 1.5).cuda()
+    mean = torch.randn(166, generator=g, dtype=torch.float64) * 0.2
+    var = torch.rand(166, generator=g, dtype=torch.float64) + 0.1
+    d = AmpDiscriminator([(p.cuda(), q.cuda()) for p, q in w], "cuda:0", running_mean=mean, running_variance=var)
+    assert d.plan_info(32768)["raw_input"] and not d.plan_info(8192)["raw_input"] and not d.plan_info(40000)["raw_input"]
+    with nat.KernelTrace(capacity=64) as tr:
+        raw = d.style_reward(x, want_logits=True)
+    assert "disc_scale_split_kernel" not in tr.summary() and "disc_mlp_fused_kernel" in tr.summary()
+    d.set_plan(fused=False)
+    with nat.KernelTrace(capacity=64) as tr:
+        planes = d.style_reward(x, want_logits=True)
+    assert "disc_scale_split_kernel" in tr.summary()
+    assert torch.equal(raw["logits"], planes["logits"]) and torch.equal(raw["style"], planes["style"])
+    d.set_plan()
+    wide = torch.zeros(32768, 167, device="cuda")       # odd row stride: 8-B alignment of the rows is lost -> scaler pass
+    wide[:, :166] = x
+    with nat.KernelTrace(capacity=64) as tr:
+        odd = d.style_reward(wide[:, :166], want_logits=True)
+    assert "disc_scale_split_kernel" in tr.summary() and torch.equal(odd["logits"], raw["logits"])
+
+    res = {}
+    for one_call in (True, False):
+        with contextlib.redirect_stdout(io.StringIO()):
+            hot = HotPath(WORKLOADS["g1_walk"], 32768, "cuda:0", seed=4, state_sets=2, one_call=one_call)
+        assert hot.raw_rows == one_call and (hot.kernel.disc_input is None) == one_call
+        kd = hot.spec.K * hot.spec.D
+        g = torch.Generator().manual_seed(22)           # the same scaler for both runs
+        hot.disc.set_scaler(torch.randn(kd, generator=g, dtype=torch.float64) * 0.3, torch.rand(kd, generator=g, dtype=torch.float64) + 0.2)
+        if not one_call:
+            hot.kernel.attach_discriminator(hot.disc)
+        rec = []
+        for _ in range(hot.spec.K + 2):
+            out = hot.step()
+            hot.synchronize()
+            n = int(hot.kernel.reset_count.item())
+            rec.append((out["style"].clone(), out["combined"].clone(), hot.kernel.reset_ids[:n].clone()))
+        res[one_call] = (rec, hot.kernel.amp_observation_buffer.clone(), hot.kernel.policy_obs.clone())
+    for a, b in zip(res[True][0], res[False][0]):
+        assert all(torch.equal(u, v) for u, v in zip(a, b))
+    assert torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][2], res[False][2])

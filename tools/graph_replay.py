@@ -8,11 +8,10 @@ from humanoid_amp_amd.workloads import WORKLOADS, HotPath
 
 envs = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
-mode = sys.argv[3] if len(sys.argv) > 3 else "graph"   # graph | eager | two (two-stream schedule of amp_hot_step)
+mode = sys.argv[3] if len(sys.argv) > 3 else "graph"   # graph | eager
 graph = mode == "graph"
 with contextlib.redirect_stdout(io.StringIO()):
-    hot = HotPath(WORKLOADS[sys.argv[4] if len(sys.argv) > 4 else "g1_walk"], envs, "cuda:0", seed=1, state_sets=3,
-                  two_streams=mode == "two")
+    hot = HotPath(WORKLOADS[sys.argv[4] if len(sys.argv) > 4 else "g1_walk"], envs, "cuda:0", seed=1, state_sets=3)
 if graph:
     hot.capture()
 for _ in range(50):
