@@ -726,7 +726,7 @@ class AmpDiscriminatorTrainer:
         motion ``[batch_size, K*D]``): :meth:`step_captured` copies three batches in and replays it.  Every launch of the
         step is asynchronous and allocation-free, and what advances from step to step (scaler sample count, Adam step and
         bias corrections) lives on the device, so a replay IS the next step.  The ~45 small launches of a step then cost
-        the queue a graph's node-to-node latency instead of 45 host launches.  Recording executes nothing:
+        the queue a graph's node-to-node latency instead of 45 host launches (profiles/NOTEBOOK_r01_r04.md section 7b).  Recording executes nothing:
         the trainer's state is untouched by :meth:`capture` itself."""
         B, dim = self.batch_size, self.disc.in_dim
         f32 = dict(dtype=torch.float32, device=self.device)

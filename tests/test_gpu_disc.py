@@ -343,7 +343,7 @@ def test_a_rows_logit_does_not_depend_on_the_kernel_plan(in_dim):
     column-split remainder (40 000: 32 768 + 7 232), two rounds (58 000) and two full rounds + a remainder (70 000); at in_dim 830
     256 x 256 tiles (30 000, ragged last tile moved up) and 32 768-row chunks -- give the
     same logits and style rewards bit for bit: every kernel of a layer issues the same MFMA shape in the same k order and reduces
-    the output layer in the same canonical order (DESIGN.md 4.2c)."""
+    the output layer in the same canonical order (DESIGN.md section 4)."""
     from humanoid_amp_amd.engine import AmpDiscriminator
 
     g = torch.Generator().manual_seed(in_dim)
