@@ -919,7 +919,8 @@ int amp_disc_plan_info(const AmpDisc* h, int64_t rows, AmpDiscPlanInfo* out) {
   out->fused_min_rows = fused_min_rows(h);
   auto set = [](const char* name) { const char* e = getenv(name); return e && e[0]; };
   out->env_overrides = (set("AMP_DISC_FUSED") ? AMP_ENV_DISC_FUSED : 0) | (set("AMP_DISC_FUSED_MIN_ROWS") ? AMP_ENV_DISC_FUSED_MIN_ROWS : 0) |
-                       (set("AMP_TRAIN_FORK") ? AMP_ENV_TRAIN_FORK : 0) | (set("AMP_TRAIN_BK32") ? AMP_ENV_TRAIN_BK32 : 0);
+                       (set("AMP_TRAIN_FORK") ? AMP_ENV_TRAIN_FORK : 0) | (set("AMP_TRAIN_BK32") ? AMP_ENV_TRAIN_BK32 : 0) |
+                       (set("AMP_TRAIN_F16_BIG") ? AMP_ENV_TRAIN_F16_BIG : 0);
   if (h->mode != AMP_DISC_F16X3) {
     out->plan = AMP_DISC_PLAN_FP32;
     out->chunk_rows = rows;

@@ -564,7 +564,7 @@ class AmpDiscriminator:
         (layer 1, layer 2) launch pairs on ``plan``."""
         p = nat.AmpDiscPlanInfo()
         nat.check(self._lib.amp_disc_plan_info(self._handle, int(rows), C.byref(p)), "amp_disc_plan_info")
-        env = [name for bit, name in ((1, "AMP_DISC_FUSED"), (2, "AMP_DISC_FUSED_MIN_ROWS"), (4, "AMP_TRAIN_FORK"), (8, "AMP_TRAIN_BK32"))
+        env = [name for bit, name in ((1, "AMP_DISC_FUSED"), (2, "AMP_DISC_FUSED_MIN_ROWS"), (4, "AMP_TRAIN_FORK"), (8, "AMP_TRAIN_BK32"), (16, "AMP_TRAIN_F16_BIG"))
                if p.env_overrides & bit]
         return {"precision": "f32" if p.precision == nat.AMP_DISC_FP32 else "f16x3", "plan": int(p.plan),
                 "plan_name": self.PLAN_NAMES.get(int(p.plan), "?"), "fused_rows": int(p.fused_rows), "chunk_rows": int(p.chunk_rows),

@@ -452,13 +452,14 @@ typedef struct {
 int amp_disc_input_layout(const AmpDisc* h, AmpDiscInputLayout* out);
 /* Which kernels a style-reward call of `rows` rows would launch on this handle, and which process-environment switches are in
  * force (they are read once, at the first call that needs them: AMP_DISC_FUSED=0 switches the fused two-layer plan off,
- * AMP_DISC_FUSED_MIN_ROWS moves its threshold, AMP_TRAIN_FORK=0 / AMP_TRAIN_BK32=0 change the training step's schedule / k-tile:
+ * AMP_DISC_FUSED_MIN_ROWS moves its threshold, AMP_TRAIN_FORK=0 / AMP_TRAIN_BK32=0 / AMP_TRAIN_F16_BIG=1 change the training step's
+ * schedule / k-tile / fp16-pipe tile:
  * A/B switches for measurements, never needed for correctness -- every plan gives the same bits per row).  Pure host
  * arithmetic; a run can log the plan it took.  (Replaces nothing in the reference: skrl's discriminator forward is one
  * torch.nn.Sequential call, agents/skrl_g1_walk_amp_cfg.yaml:31-39.) */
 enum { AMP_DISC_PLAN_REGISTER = 0, AMP_DISC_PLAN_DMA_128 = 1, AMP_DISC_PLAN_DMA_256_128 = 2, AMP_DISC_PLAN_DMA_256 = 3,
        AMP_DISC_PLAN_DMA_128_64 = 4, AMP_DISC_PLAN_FP32 = 16 };
-enum { AMP_ENV_DISC_FUSED = 1, AMP_ENV_DISC_FUSED_MIN_ROWS = 2, AMP_ENV_TRAIN_FORK = 4, AMP_ENV_TRAIN_BK32 = 8 };
+enum { AMP_ENV_DISC_FUSED = 1, AMP_ENV_DISC_FUSED_MIN_ROWS = 2, AMP_ENV_TRAIN_FORK = 4, AMP_ENV_TRAIN_BK32 = 8, AMP_ENV_TRAIN_F16_BIG = 16 };
 typedef struct {
   int32_t precision;        /* AMP_DISC_F16X3 / AMP_DISC_FP32 */
   int32_t plan;             /* AMP_DISC_PLAN_*: tiles of the two-kernel (layer 1, layer 2) launches that take the rows NOT on the fused kernel */
