@@ -575,7 +575,10 @@ def main():
         rows = (fused_rows if fused else envs) // per_step
         # keys are "kernel<template args>@workgroups" of one launch (tools/pmc_summary.py --traffic-json)
         if fused:
-            traffic = (tj.get(f"{FUSED_KERNEL}<6>@{(rows + 127) // 128}") or {}).get("hbm_bytes")
+            kx = (spec.K * spec.D + 31) // 32
+            wgs = (rows + 127) // 128
+            for name in (f"{FUSED_KERNEL}<{kx}, true>", f"{FUSED_KERNEL}<{kx}, false>", f"{FUSED_KERNEL}<{kx}>"):  # raw-row / plane input
+                traffic = traffic or (tj.get(f"{name}@{wgs}") or {}).get("hbm_bytes")
         elif args.disc_precision == "f16x3" and rows >= 24576:
             wg = ((rows + 255) // 256 * 2 + 7) // 8 * 8
             traffic = (tj.get(f"disc_gemm_f16_dma_kernel<1, 4, 2, 0>@{wg}") or tj.get(f"disc_gemm_f16_dma_kernel<1, 4, 2>@{wg}") or {}).get("hbm_bytes")

@@ -3,6 +3,7 @@
 #   gpurun -- 'bash tools/collect_profiles.sh r01_b'
 # Counters are collected in their own runs (no --stats / trace domains next to --pmc).
 set -o pipefail
+# (round 5: bench.py prints per-kernel detail on stderr; the summaries below read the rocprofv3 CSVs only)
 TAG=${1:-r01}
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}/gpurun_out/$TAG
