@@ -643,8 +643,16 @@ struct AmpDiscTrainer {
   // ... and the prediction loss's W1 gradient gW1 = dH1^T Xs (output width kN padded to the 128-column tile: zero rows of Xs^T):
   _Float16* dh1tp;               // [h1][Mp / 32][2][32]   planes of dH1^T          (A of gW1)
   _Float16* xstp;                // [kNp][Mp / 32][2][32]  planes of Xs^T, kNp = kN rounded up to 128 (rows >= kN stay zero)
+  // ... and the other three of the penalty chain (output / reduction width kN padded to kNp = kN rounded up to 128):
+  _Float16* w1tp;                // [kNp][h1 / 32][2][32]  planes of W1^T (rows >= kN stay zero)      (W of g = a1 W1)
+  _Float16* w1kp;                // [h1][kNp / 32][2][32]  planes of W1, k padded to kNp with zeros   (W of e1 = g W1^T)
+  _Float16* a1p;                 // [Bp][h1 / 32][2][32]   planes of a1                               (A of g)
+  _Float16* a1tp;                // [h1][Bp / 32][2][32]   planes of a1^T                             (A of gW1 += a1^T g)
+  _Float16* gp;                  // [Bp][kNp / 32][2][32]  planes of g (after its in-place scaling)   (A of e1)
+  _Float16* gtp;                 // [kNp][Bp / 32][2][32]  planes of g^T                              (W of gW1 += a1^T g)
   float* bound;                  // [16]: [0] bound of |dH2|, [1] max|W2|, [2] max|H1|, [3] max|w3| (bounds |a2|), [4] max|e1|,
-                                 //      [5] h2 x [0] x [1] (bounds |dH1|), [6] max|Xs|, [8] max row sum of |W1|, [9] max|b1|; [2] = [8] x [6] + [9]
+                                 //      [5] h2 x [0] x [1] (bounds |dH1|), [6] max|Xs|, [8] max row sum of |W1|, [9] max|b1|; [2] = [8] x [6] + [9],
+                                 //      [10] max|W1|, [11] h2 x [3] x [1] (bounds |a1|), [12] max|g|
   // the gradient-penalty chain (six GEMMs over the motion rows, grids that do not fill the chip) runs beside the prediction
   // loss's backward on a stream of the trainer's own: fork / join through these events (capturable: the side stream joins back)
   hipStream_t side;
@@ -701,9 +709,10 @@ __global__ __launch_bounds__(kBlock) void rowsum_bound_kernel(const float* __res
     if (bm > __builtin_nontemporal_load(out + 1)) atomicMax(reinterpret_cast<unsigned int*>(out + 1), __float_as_uint(bm));
   }
 }
-// out[0] = a[0] * b[0] * 1.0001f + c[0]  (the row sums were rounded: keep the bound a bound)
-__global__ void bound_affine_kernel(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c) {
-  out[0] = a[0] * b[0] * 1.0001f + c[0];
+// out[0] = factor * a[0] * b[0] * 1.0001f + (c ? c[0] : 0)  (sums were rounded: keep the bound a bound)
+__global__ void bound_affine_kernel(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                    float factor = 1.0f) {
+  out[0] = factor * a[0] * b[0] * 1.0001f + (c ? c[0] : 0.0f);
 }
 // (rows x cols contiguous floats, rows * cols % 4 == 0)
 void amax_flat(hipStream_t st, const float* x, int64_t n, float* out) {
@@ -1035,6 +1044,12 @@ int amp_disc_trainer_destroy(AmpDiscTrainer* t) {
   (void)hipFree(t->dh2tp);
   (void)hipFree(t->h1tp);
   (void)hipFree(t->w2p);
+  (void)hipFree(t->w1tp);
+  (void)hipFree(t->w1kp);
+  (void)hipFree(t->a1p);
+  (void)hipFree(t->a1tp);
+  (void)hipFree(t->gp);
+  (void)hipFree(t->gtp);
   (void)hipFree(t->dh1tp);
   (void)hipFree(t->xstp);
   (void)hipFree(t->a2p);
@@ -1098,7 +1113,7 @@ int amp_disc_trainer_create(AmpDisc* disc, const AmpDiscTrainCfg* cfg, const dou
   t->ws_floats = f + (int64_t)16 * p.h2 * p.h1 + (int64_t)16 * p.h1 * t->kN + 64 + 2 * ((M + 3) / 4) + 16 + (int64_t)kChunks * 1024 + 1024 + 3 * (up((int64_t)kChunks * p.in_dim * 2, 8) * 2) + 16 +
                  16 * 40 + 6 * up(p.k1p, 16) + M * (t->kN - p.k1p) + 2 * (int64_t)kChunks * 1024;
   t->ws_floats += (int64_t)16 * p.h2 * p.h1 + (int64_t)16 * p.h1 * t->kN + (int64_t)3 * kChunks * 1024 + 1024 + 64;  // the side stream's slices + partials
-  t->ws_floats += (int64_t)32 * p.h1 * (up(t->kN, 128) - t->kN) + 64;                                                 // gW1's slices at the padded pitch
+  t->ws_floats += (int64_t)32 * p.h1 * (up(t->kN, 128) - t->kN) + B * (up(t->kN, 128) - t->kN) + 64;                  // gW1's slices / g at the padded pitch
   if (e == hipSuccess) e = hipMalloc(&t->ws, sizeof(float) * t->ws_floats);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking);
   // device-side ordering between two streams of this device only: no timing, no system-scope fence at the record (that fence
@@ -1115,6 +1130,13 @@ int amp_disc_trainer_create(AmpDisc* disc, const AmpDiscTrainCfg* cfg, const dou
     if (e == hipSuccess) e = hipMalloc(&t->dh1tp, sizeof(_Float16) * 2 * Mk * p.h1);
     if (e == hipSuccess) e = hipMalloc(&t->xstp, sizeof(_Float16) * 2 * Mk * kNp);
     if (e == hipSuccess) e = hipMemsetAsync(t->xstp, 0, sizeof(_Float16) * 2 * Mk * kNp, st);   // rows [kN, kNp) are never written again
+    if (e == hipSuccess) e = hipMalloc(&t->w1tp, sizeof(_Float16) * 2 * kNp * p.h1);
+    if (e == hipSuccess) e = hipMemsetAsync(t->w1tp, 0, sizeof(_Float16) * 2 * kNp * p.h1, st);     // rows [kN, kNp) stay zero
+    if (e == hipSuccess) e = hipMalloc(&t->w1kp, sizeof(_Float16) * 2 * kNp * p.h1);
+    if (e == hipSuccess) e = hipMalloc(&t->a1p, sizeof(_Float16) * 2 * Bk * p.h1);
+    if (e == hipSuccess) e = hipMalloc(&t->a1tp, sizeof(_Float16) * 2 * Bk * p.h1);
+    if (e == hipSuccess) e = hipMalloc(&t->gp, sizeof(_Float16) * 2 * Bk * kNp);
+    if (e == hipSuccess) e = hipMalloc(&t->gtp, sizeof(_Float16) * 2 * Bk * kNp);
     if (e == hipSuccess) e = hipMalloc(&t->w2p, sizeof(_Float16) * 2 * (size_t)p.h1 * p.h2);
     if (e == hipSuccess) e = hipMalloc(&t->a2p, sizeof(_Float16) * 2 * Bk * p.h2);
     if (e == hipSuccess) e = hipMalloc(&t->a2tp, sizeof(_Float16) * 2 * Bk * p.h2);
@@ -1205,7 +1227,7 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
   float* XsT = take((int64_t)kN * Mp);
   float* a2 = take(B * H2n);
   float* a1 = take(B * H1n);
-  float* g = take(B * kN);
+  float* g = take(B * up(kN, 128));   // row pitch kN, or kN rounded up to 128 when the fp16 pipe writes it
   float* e1 = take(B * H1n);
   float* da2 = take(B * H2n);
   float* a1T = take((int64_t)H1n * Bp);
@@ -1294,6 +1316,19 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
     sl_w2[0] = plan_gw2.slices;
     sl_w1[0] = plan_gw1.slices;
   }
+  // ... and, for a WIDE input only (K D = 830: kN = 832), its other three: g = a1 W1, gW1's second product a1^T g, e1 = g W1^T.  At
+  // kN = 192 they are 1.6 GFLOP each: the fp32 kernels take 25-35 us beside the other stream, the fp16 ones the same plus their operand
+  // passes, and more LDS-DMA workgroups on the side stream slow the caller's fp16 products down (K D = 166: 0.568 -> 0.607 ms per
+  // step, same box; K D = 830: 0.989 -> 0.896, profiles/r05_train_step.md)
+  const bool f16g = f16p && kN >= 512;
+  F16Plan plan_g{}, plan_e1{}, plan_gw1p{};
+  const int64_t gP = f16g ? kNp : kN;   // row pitch of g
+  if (f16g) {
+    plan_g = f16_planes_plan(B, kNp, H1n / 32, 1);
+    plan_e1 = f16_planes_plan(B, H1n, kNp / 32, 1);
+    plan_gw1p = f16_planes_plan(H1n, kNp, (int)(Bk / 32), 16);
+    sl_w1[1] = plan_gw1p.slices;
+  }
   if (f16p) {
     plan_a1 = f16_planes_plan(B, H1n, H2n / 32, 1);
     plan_gw2p = f16_planes_plan(H2n, H1n, (int)(Bk / 32), 16);
@@ -1320,12 +1355,21 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
     if (f16) {
       // the planes of W2^T (the W operand of dH1) with the scale of max|W2|: 2 MB, under the scaler passes
       // (abs-max kernels: one atomic per workgroup on one address -- ~50 ns each in the L2 --, so few, long workgroups)
-      AMP_HIP(hipMemsetAsync(t->bound + 1, 0, 9 * sizeof(float), side));
+      AMP_HIP(hipMemsetAsync(t->bound + 1, 0, 12 * sizeof(float), side));
       amax_flat(side, p.w2, (int64_t)H2n * H1n, t->bound + 1);
       amax_flat(side, p.w3, H2n, t->bound + 3);
       rowsum_bound_kernel<<<(unsigned)((H1n + 3) / 4), kBlock, 0, side>>>(p.w1p, H1n, k1p, k1p, p.b1, t->bound + 8);
       split_transpose_blocks_kernel<<<dim3(H1n / 64, H2n / 32), kBlock, 0, side>>>(p.w2, H2n, H1n, H1n, t->bound + 1, t->w2tp, H2n);
-      if (f16p) split_rows_blocks_kernel<<<blocks((int64_t)H2n * (H1n / 4)), kBlock, 0, side>>>(p.w2, H2n, H1n, H1n, t->bound + 1, t->w2p, H1n, 1);
+      if (f16p) {
+        split_rows_blocks_kernel<<<blocks((int64_t)H2n * (H1n / 4)), kBlock, 0, side>>>(p.w2, H2n, H1n, H1n, t->bound + 1, t->w2p, H1n, 1);
+      }
+      if (f16g) {
+        // W1 in both orientations (t->w1t = W1^T [kN, h1] was written just above), one scale: max|W1|;  |a1| <= h2 max|w3| max|W2|
+        amax_flat(side, p.w1p, (int64_t)H1n * k1p, t->bound + 10);
+        split_rows_blocks_kernel<<<blocks((int64_t)kN * (H1n / 4)), kBlock, 0, side>>>(t->w1t, kN, H1n, H1n, t->bound + 10, t->w1tp, H1n, 1);
+        split_rows_blocks_kernel<<<blocks((int64_t)H1n * (kNp / 4)), kBlock, 0, side>>>(p.w1p, H1n, k1p, k1p, t->bound + 10, t->w1kp, kNp, 1);
+        bound_affine_kernel<<<1, 1, 0, side>>>(t->bound + 11, t->bound + 3, t->bound + 1, nullptr, (float)H2n);
+      }
     }
     AMP_HIP(hipEventRecord(t->ev[1], side));
   }
@@ -1411,11 +1455,23 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
       r = nt_on(s_, a2, H2n, B, t->w2t, H2n, H1n, a1, H1n, H1m, H1n, 0);        // a1 = (a2 W2) * m1
     }
     if (r != AMP_OK) return r;
-    r = nt_on(s_, a1, H1n, B, t->w1t, H1n, kN, g, kN, nullptr, 0, 0);         // g = a1 W1      [B, kN]
+    if (f16g) {
+      // a1's planes in both orientations (bound: h2 max|w3| max|W2|), then g = a1 W1 on the fp16 pipe (N padded to kNp: zero rows of W1^T)
+      split_transpose_blocks_kernel<<<dim3(H1n / 64, (unsigned)(Bk / 32)), kBlock, 0, s_>>>(a1, B, H1n, H1n, t->bound + 11, t->a1tp, Bk, t->a1p);
+      r = gemm_f16_planes(s_, t->a1p, B, t->w1tp, kNp, H1n, t->bound + 11, t->bound + 10, g, gP, nullptr, 0, plan_g, 0);
+    } else {
+      r = nt_on(s_, a1, H1n, B, t->w1t, H1n, kN, g, kN, nullptr, 0, 0);         // g = a1 W1      [B, kN]
+    }
     if (r != AMP_OK) return r;
     // loss[1] = gp_scale * mean_rows |g|^2 ;  g <- dL/dg = (2 gp_scale loss_scale / B) g
-    sumsq(s_, part_, g, B, p.in_dim, kN, 2.0f * c.grad_penalty_scale * c.loss_scale / (float)B, 1, c.grad_penalty_scale / (float)B, 1, 0);
-    if (fork) {
+    sumsq(s_, part_, g, B, p.in_dim, gP, 2.0f * c.grad_penalty_scale * c.loss_scale / (float)B, 1, c.grad_penalty_scale / (float)B, 1, 0);
+    if (f16g) {
+      // g's planes in both orientations (abs-max of 4 MB), gW1's penalty slices = a1^T g on the fp16 pipe
+      amax_flat(s_, g, B * gP, t->bound + 12);
+      split_transpose_blocks_kernel<<<dim3(kNp / 64, (unsigned)(Bk / 32)), kBlock, 0, s_>>>(g, B, kNp, gP, t->bound + 12, t->gtp, Bk, t->gp);
+      r = gemm_f16_planes(s_, t->a1tp, H1n, t->gtp, kNp, (int)Bk, t->bound + 11, t->bound + 12, split1 + sl_w1[0] * n_w1, gN, nullptr, 0,
+                          plan_gw1p, n_w1);
+    } else if (fork) {
       int n = 0;
       r = gemm_tt(s_, a1, H1n, H1n, g, kN, kN, B, nullptr, gN, 0, split1 + sl_w1[0] * n_w1, nullptr, &n);   // gW1's penalty slices
     } else {
@@ -1427,7 +1483,8 @@ int amp_disc_train_step(AmpDiscTrainer* t, const float* policy, const float* rep
       }
     }
     if (r != AMP_OK) return r;
-    r = nt_on(s_, g, kN, B, p.w1p, k1p, H1n, e1, H1n, H1m, H1n, 0);           // e1 = (dg W1^T) * m1   (K = k1p <= kN)
+    if (f16g) r = gemm_f16_planes(s_, t->gp, B, t->w1kp, H1n, kNp, t->bound + 12, t->bound + 10, e1, H1n, H1m, H1n, plan_e1, 0);
+    else r = nt_on(s_, g, kN, B, p.w1p, k1p, H1n, e1, H1n, H1m, H1n, 0);      // e1 = (dg W1^T) * m1   (K = k1p <= kN)
     if (r != AMP_OK) return r;
     if (f16p) {
       // e1's abs-max (16 MB) and planes in both orientations; gW2's penalty slices = a2^T e1 and da2 = e1 W2^T on the fp16 pipe

@@ -649,7 +649,8 @@ class AmpDiscriminatorTrainer:
         two fp16 planes per operand, three MFMAs per product (the inference path's engine), planes written once per step with one
         power-of-two scale per operand from a bound that costs no pass on the step's critical path (a-priori bounds, or abs-max
         passes on the side stream).  The forward GEMMs stay on the fp32 pipe in both modes (they decide the ReLU masks).  Same
-        gradients to 1e-5 of each tensor's scale; 0.66 -> 0.58 ms per step at K D = 166, 1.14 -> 0.99 at 830
+        gradients to 1e-5 of each tensor's scale; 0.66 -> 0.56 ms per step at K D = 166, 1.14 -> 0.89 at 830 (where the chain's other
+        three products run there too)
         (profiles/r05_train_step.md).  Needs the forked step (gradient penalty on, hidden widths multiples of 128); otherwise
         the fp32 products run."""
         if gemm_precision not in ("f16x3", "f32"):
