@@ -633,9 +633,9 @@ def main():
                        "collective": collective, "update": upd},
             # achieved = ALGORITHMIC FLOPs / launch time against the dense MFMA peak of the operand type the kernel
             # issues; the fp16-split engine executes 3 MFMA products per algorithmic one (frac_executed counts those)
-            "roofline": {"bound": "mfma", "kernel": dominant, "achieved": r3(achieved), "peak": peak,
-                         "unit": "TFLOP/s", "frac": r3(achieved / peak), "traffic": traffic,
-                         "avg_launch_ms": r3(gemm2_ms), "launches_timed": len(recs), "launches_per_step": per_step, "timing": timing,
+            "roofline": {"bound": "mfma", "kernel": dominant, "achieved": achieved, "peak": peak,
+                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                         "avg_launch_ms": gemm2_ms, "launches_timed": len(recs), "launches_per_step": per_step, "timing": timing,
                          "rows_per_launch": n_dom // per_step, "flops_per_launch": flops2,
                          "mfma_products_per_flop": nprod, "frac_executed": r3(nprod * achieved / peak),
                          "vs_fp32_mfma_peak": r3(achieved / MFMA_F32_PEAK_TFLOPS),

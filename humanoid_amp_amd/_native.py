@@ -230,6 +230,7 @@ SIGNATURES = {
     "amp_ring_size": (_i64, [_vp]),
     "amp_ring_head": (_i64, [_vp]),
     "amp_ring_append": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
+    "amp_rows_take_permuted": (C.c_int, [_vp, _i64, _i64, _i32, C.c_uint64, C.c_uint64, _i64, _i64, _vp, _i64, _vp, _vp]),
     "amp_ring_sample": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _i64, _i64, _vp, _i64, _vp, _vp]),
     "amp_disc_style_reward_prescaled": (C.c_int, [_vp, _vp, _i64, _f32, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "amp_disc_style_reward_prescaled_compact": (C.c_int, [_vp, _vp, _i64, _f32, _vp, _f32, _f32, _vp, _vp, _vp, _vp,

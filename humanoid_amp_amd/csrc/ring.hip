@@ -50,6 +50,44 @@ __global__ __launch_bounds__(kBlock) void ring_sample_kernel(const float* __rest
   if (idx_out && c == 0) idx_out[i] = row;
 }
 
+// Pseudo-random PERMUTATION of [0, n) evaluated point-wise (no sort, no n-element index array): a 6-round balanced Feistel network
+// over 2 * hb bits (2^(2 hb) >= n, < 4 n) keyed by (seed, epoch), cycle-walked until the image falls inside [0, n) -- a bijection of
+// the 2^(2 hb) domain restricted by cycle walking is a bijection of [0, n).  Used for the epoch shuffle of an agent update's rollout
+// rows (skrl memory.sample_all: shuffle all indices, split into mini-batches; third-party, parity unpinned): minibatch m of an
+// epoch takes positions [m * per, m * per + batch) of the permutation, i.e. `batch` DISTINCT rows, and two minibatches of one epoch
+// never share a row.  Bit-exact restatement: oracle/rng.py::feistel_permutation.
+__device__ __forceinline__ uint32_t feistel_round(uint32_t r, uint32_t k0, uint32_t k1) {
+  const uint64_t p = (uint64_t)(r ^ k0) * 0xD2511F53ull;
+  return (uint32_t)(p >> 32) ^ (uint32_t)p ^ k1;
+}
+__device__ __forceinline__ int64_t feistel_permute(int64_t x, int64_t n, int hb, uint64_t seed, uint64_t epoch) {
+  const uint32_t mask = (1u << hb) - 1u;
+  uint64_t v = (uint64_t)x;
+  do {
+    uint32_t L = (uint32_t)(v >> hb) & mask, R = (uint32_t)v & mask;
+#pragma unroll
+    for (int rd = 0; rd < 6; ++rd) {
+      const uint32_t k0 = (uint32_t)seed + 0x9E3779B9u * (uint32_t)(rd + 1), k1 = (uint32_t)(seed >> 32) ^ (uint32_t)epoch ^ (0xBB67AE85u * (uint32_t)(rd + 1)) ^ (uint32_t)(epoch >> 32);
+      const uint32_t t = L ^ (feistel_round(R, k0, k1) & mask);
+      L = R;
+      R = t;
+    }
+    v = ((uint64_t)L << hb) | R;
+  } while ((int64_t)v >= n);
+  return (int64_t)v;
+}
+__global__ __launch_bounds__(kBlock) void rows_take_permuted_kernel(const float* __restrict__ rows, int64_t n, int64_t stride, int dim, int hb,
+                                                                    uint64_t seed, uint64_t epoch, int64_t first, int64_t count,
+                                                                    float* __restrict__ out, int64_t out_stride, int64_t* __restrict__ idx_out) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= count * dim) return;
+  const int64_t i = e / dim;
+  const int c = (int)(e - i * dim);
+  const int64_t src = feistel_permute(first + i, n, hb, seed, epoch);
+  out[i * out_stride + c] = rows[src * stride + c];
+  if (idx_out && c == 0) idx_out[i] = src;
+}
+
 }  // namespace amp
 
 using namespace amp;
@@ -107,6 +145,27 @@ int amp_ring_append(AmpRing* r, const float* rows_dev, int64_t n, int64_t row_st
   r->head = (r->head + n) % r->capacity;
   r->size = r->size + n < r->capacity ? r->size + n : r->capacity;
   return AMP_OK;
+}
+
+int amp_rows_take_permuted(const float* rows_dev, int64_t n_rows, int64_t row_stride, int32_t row_dim, uint64_t seed, uint64_t epoch, int64_t first,
+                           int64_t count, float* out_dev, int64_t out_stride, int64_t* indices_dev, amp_stream_t stream) {
+  AMP_REQUIRE(count >= 0 && first >= 0, "amp_rows_take_permuted: negative range");
+  if (count == 0) return AMP_OK;
+  AMP_REQUIRE(rows_dev && out_dev, "amp_rows_take_permuted: null buffer");
+  AMP_REQUIRE(n_rows >= 1 && n_rows < ((int64_t)1 << 40), "amp_rows_take_permuted: n_rows must be in [1, 2^40)");
+  AMP_REQUIRE(first + count <= n_rows, "amp_rows_take_permuted: positions [%lld, %lld) exceed the %lld rows", (long long)first,
+              (long long)(first + count), (long long)n_rows);
+  AMP_REQUIRE(row_dim >= 1 && row_stride >= row_dim && out_stride >= row_dim, "amp_rows_take_permuted: bad row_dim / strides");
+  int bits = 1;
+  while (((int64_t)1 << bits) < n_rows) ++bits;
+  const int hb = (bits + 1) / 2;   // half-width: 2^(2 hb) >= n_rows
+  hipStream_t st = (hipStream_t)stream;
+  {
+    amp::TraceScope trace__("rows_take_permuted_kernel", st);
+    rows_take_permuted_kernel<<<(unsigned)((count * row_dim + kBlock - 1) / kBlock), kBlock, 0, st>>>(rows_dev, n_rows, row_stride, row_dim, hb, seed, epoch,
+                                                                                                  first, count, out_dev, out_stride, indices_dev);
+  }
+  return launch_status("rows_take_permuted_kernel");
 }
 
 int amp_ring_sample(const AmpRing* r, uint64_t seed, uint64_t draw, int64_t first_row, int64_t n, float* out_dev, int64_t out_stride,

@@ -508,12 +508,18 @@ class AmpDiscriminator:
         return ws
 
     def style_reward(self, amp_obs: torch.Tensor, task_reward: Optional[torch.Tensor] = None, *, want_logits: bool = False,
-                     inputs_consumed: Optional[torch.cuda.Event] = None, workspace_slot: int = 0):
+                     inputs_consumed: Optional[torch.cuda.Event] = None, workspace_slot: int = 0,
+                     compact: Optional["EnvStepKernel"] = None):
         """amp_obs [M, K*D] -> dict(style [M,1], combined [M,1] (if task_reward given), logits [M,1] (optional)).
 
         ``inputs_consumed`` (a torch.cuda.Event) is recorded on the current stream right after the last read of
         ``amp_obs`` / ``task_reward``; ``workspace_slot`` selects one of several private workspaces so that two calls
-        may be in flight on the same stream queue (see workloads.HotPath, overlap=True)."""
+        may be in flight on the same stream queue (see workloads.HotPath, overlap=True).  ``compact`` (the
+        :class:`EnvStepKernel` whose DONES phase ran this step): its reset-id compaction rides on the call's tail launch
+        (``amp_disc_style_reward_compact``), as with :meth:`style_reward_prescaled`.
+
+        Where the whole batch takes the one-launch two-layer kernel (``plan_info(M)["raw_input"]``) that kernel reads the fp32
+        rows itself: no scaler pass, no scaled copy (8-B aligned rows of even stride; otherwise the scaler pass runs)."""
         if amp_obs.dim() != 2 or amp_obs.shape[1] != self.in_dim or amp_obs.dtype != torch.float32 or amp_obs.stride(1) != 1:
             raise nat.AmpEngineError(f"amp_obs must be float32 [M, {self.in_dim}] with a contiguous last dim")
         nat.require_gpu(amp_obs.device)
@@ -529,12 +535,21 @@ class AmpDiscriminator:
             combined = torch.empty((M, 1), **f32)
         ws = self._workspace(M, workspace_slot)
         ev = C.c_void_p(inputs_consumed.cuda_event) if inputs_consumed is not None else C.c_void_p(None)
-        with torch.cuda.device(self.device):
-            nat.check(self._lib.amp_disc_style_reward(self._handle, C.c_void_p(amp_obs.data_ptr()), M, int(amp_obs.stride(0)) if M > 1 else self.in_dim,
-                                                      self.reward_scale, nat.dptr(task), self.task_reward_weight,
-                                                      self.style_reward_weight, nat.dptr(logits), nat.dptr(style),
-                                                      nat.dptr(combined), nat.dptr(ws), ev, nat.stream_ptr()),
-                      "amp_disc_style_reward")
+        if compact is not None:
+            if inputs_consumed is not None:
+                raise nat.AmpEngineError("style_reward: inputs_consumed and compact are mutually exclusive")
+            c = compact.compact_args()
+            with torch.cuda.device(self.device):
+                nat.check(self._lib.amp_disc_style_reward_compact(
+                    self._handle, C.c_void_p(amp_obs.data_ptr()), M, int(amp_obs.stride(0)) if M > 1 else self.in_dim, self.reward_scale,
+                    nat.dptr(task), self.task_reward_weight, self.style_reward_weight, nat.dptr(logits), nat.dptr(style), nat.dptr(combined),
+                    nat.dptr(ws), C.byref(c), nat.stream_ptr()), "amp_disc_style_reward_compact")
+        else:
+            with torch.cuda.device(self.device):
+                nat.check(self._lib.amp_disc_style_reward(
+                    self._handle, C.c_void_p(amp_obs.data_ptr()), M, int(amp_obs.stride(0)) if M > 1 else self.in_dim, self.reward_scale,
+                    nat.dptr(task), self.task_reward_weight, self.style_reward_weight, nat.dptr(logits), nat.dptr(style), nat.dptr(combined),
+                    nat.dptr(ws), ev, nat.stream_ptr()), "amp_disc_style_reward")
         out = {"style": style}
         if combined is not None:
             out["combined"] = combined
@@ -785,6 +800,27 @@ class AmpDiscriminatorTrainer:
 # ---------------------------------------------------------------------------------------------------
 
 
+def take_permuted_rows(rows: torch.Tensor, seed: int, epoch: int, first: int, count: int, *, out: Optional[torch.Tensor] = None,
+                       return_indices: bool = False):
+    """``out[i] = rows[pi(first + i)]`` for ``i < count`` with ``pi`` a pseudo-random permutation of the rows keyed by ``(seed, epoch)``
+    and evaluated point-wise on the device (``amp_rows_take_permuted``: Feistel network + cycle walking; no sort, no index array):
+    the epoch shuffle of an agent update's rollout rows.  Positions ``[m * per, m * per + batch)`` of one epoch are ``batch`` distinct
+    rows, disjoint from every other minibatch's."""
+    if rows.dim() != 2 or rows.dtype != torch.float32 or rows.stride(1) != 1:
+        raise nat.AmpEngineError("rows must be a float32 [n, dim] tensor with a contiguous last dim")
+    dev = nat.require_gpu(rows.device)
+    if out is None:
+        out = torch.empty((count, rows.shape[1]), device=dev)
+    elif out.dim() != 2 or out.dtype != torch.float32 or tuple(out.shape) != (count, rows.shape[1]) or out.stride(1) != 1 or out.device != rows.device:
+        raise nat.AmpEngineError("out must be a float32 [count, dim] tensor on the rows' device with a contiguous last dim")
+    idx = torch.empty(count, dtype=torch.int64, device=dev) if return_indices else None
+    with torch.cuda.device(dev):
+        nat.check(nat.load().amp_rows_take_permuted(C.c_void_p(rows.data_ptr()), rows.shape[0], int(rows.stride(0)), rows.shape[1], int(seed),
+                                                    int(epoch), int(first), int(count), C.c_void_p(out.data_ptr()), int(out.stride(0)),
+                                                    nat.dptr(idx), nat.stream_ptr()), "amp_rows_take_permuted")
+    return (out, idx) if return_indices else out
+
+
 class AmpReplayBuffer:
     """Device ring buffer of AMP observation rows with skrl ``RandomMemory`` semantics [third-party, absent: parity
     unpinned]: :meth:`add_samples` writes a batch at the write head and wraps around, :meth:`sample` draws
@@ -846,8 +882,8 @@ class AmpDiscriminatorUpdate:
       buffer is empty) and ``batch_size`` rows drawn from the motion dataset (:class:`AmpReplayBuffer` rings);
     * after the update the rollout's rows are appended to the replay buffer.
 
-    Every draw is on the device (ring draws: counter-based; the shuffle: a seeded ``torch.randperm``); nothing is
-    read back.
+    Every draw is on the device and counter-based -- the ring draws (Philox) and the epoch shuffle (a point-wise pseudo-random
+    permutation keyed by ``(seed, epoch)``: :func:`take_permuted_rows`; no host RNG, no torch generator) --; nothing is read back.
 
     **Multi-rank** (``group`` = a ``torch.distributed`` process group; the reference's ``--distributed`` mode,
     train.py:54-58,183-196, keeps one agent replica per GPU in step through skrl's gradient all-reduce): the trainer's
@@ -865,14 +901,17 @@ class AmpDiscriminatorUpdate:
 
     def __init__(self, trainer: AmpDiscriminatorTrainer, replay: AmpReplayBuffer, motion_dataset: AmpReplayBuffer, *,
                  learning_epochs: int = 6, mini_batches: int = 2, seed: int = 0, record_batches: bool = False, prefetch: bool = True,
-                 group=None):
+                 group=None, take_rows=None):
         """``prefetch`` (default; single-rank flow only): the three batches of training step k + 1 (shuffle, row gather, two
         ring draws: ~45 us of sort / gather launches) are produced on a side stream while step k trains, into two alternating
         sets of static buffers; the same draws in the same order, so the rows are identical to the in-line flow
         (``prefetch=False``).  With a ``group`` every batch of the update is produced up front (the exchange needs them all)."""
         self.trainer, self.replay, self.motion_dataset = trainer, replay, motion_dataset
         self.learning_epochs, self.mini_batches = int(learning_epochs), int(mini_batches)
-        self.gen = torch.Generator(device=trainer.device).manual_seed(seed)
+        # the epoch shuffle: take_rows(rows, seed, epoch, first, count, out=...) -- the engine's point-wise permutation (a test double
+        # on CPU tensors passes its own restatement); `_epoch` counts the epochs of all updates so far
+        self.seed, self._epoch = int(seed), 0
+        self._take_rows = take_rows or take_permuted_rows
         self.record_batches = bool(record_batches)
         self.batches = []  # (policy, replay, motion) of every trainer step of the last update, when recording
         self.prefetch = bool(prefetch)
@@ -920,9 +959,9 @@ class AmpDiscriminatorUpdate:
         if self.prefetch and self.learning_epochs * self.mini_batches > 0:
             return self._update_prefetched(rows, per, bs)
         for _ in range(self.learning_epochs):
-            perm = torch.randperm(rows.shape[0], generator=self.gen, device=rows.device)
+            epoch, self._epoch = self._epoch, self._epoch + 1
             for mb in range(self.mini_batches):
-                policy = rows.index_select(0, perm[mb * per: mb * per + bs])
+                policy = self._take_rows(rows, self.seed, epoch, mb * per, bs)
                 replay = self.replay.sample(bs) if len(self.replay) > 0 else policy
                 motion = self.motion_dataset.sample(bs)
                 losses.append(self.trainer.step(policy, replay, motion)["loss"])
@@ -955,13 +994,13 @@ class AmpDiscriminatorUpdate:
             raise nat.AmpEngineError("the motion dataset is empty: fill it with collect_reference rows first")
         per = rows.shape[0] // self.mini_batches
         have_replay = len(self.replay) > 0
-        perm = None
+        epoch = self._epoch
         for k in range(n):
             mb = k % self.mini_batches
             if mb == 0:
-                perm = torch.randperm(rows.shape[0], generator=self.gen, device=rows.device)
+                epoch, self._epoch = self._epoch, self._epoch + 1
             policy, replay, motion = ex.contrib[k].unbind(0)
-            torch.index_select(rows, 0, perm[mb * per: mb * per + r], out=policy)
+            self._take_rows(rows, self.seed, epoch, mb * per, r, out=policy)
             if have_replay:
                 self.replay.sample(r, out=replay, first_row=ex.first_row)
             else:
@@ -984,9 +1023,9 @@ class AmpDiscriminatorUpdate:
         """The same flow with the batches of step k + 1 produced on a side stream under step k.  Two static buffer sets:
         the side stream refills a set only behind the training step that last read it (an event recorded on the main
         stream), the main stream trains on a set only behind its refill (an event recorded on the side stream).  The
-        shuffles and the ring draws consume their generators / counters in the in-line order.  The batches of step k + 1 are
-        drawn before step k trains: if a training step raises, the generator and the ring draw counters are one step ahead of
-        the in-line flow's (they are not rolled back)."""
+        shuffles and the ring draws consume their counters in the in-line order.  The batches of step k + 1 are drawn before step k
+        trains: if a training step raises, the epoch and ring draw counters are one step ahead of the in-line flow's (they are not
+        rolled back)."""
         dev = rows.device
         main = torch.cuda.current_stream(dev)
         if self._side is None:
@@ -998,7 +1037,7 @@ class AmpDiscriminatorUpdate:
         n = self.learning_epochs * self.mini_batches
         ready, done = [None, None], [None, None]
         have_replay = len(self.replay) > 0
-        state = {"perm": None}
+        state = {"epoch": self._epoch}
         side.wait_stream(main)  # the rollout rows (and whatever used the buffer sets before) are complete
 
         def produce(k):
@@ -1007,9 +1046,9 @@ class AmpDiscriminatorUpdate:
                 if done[st] is not None:
                     side.wait_event(done[st])
                 if mb == 0:
-                    state["perm"] = torch.randperm(rows.shape[0], generator=self.gen, device=dev)
+                    state["epoch"], self._epoch = self._epoch, self._epoch + 1
                 policy, replay, motion = bufs[st]
-                torch.index_select(rows, 0, state["perm"][mb * per: mb * per + bs], out=policy)
+                self._take_rows(rows, self.seed, state["epoch"], mb * per, bs, out=policy)
                 if have_replay:
                     self.replay.sample(bs, out=replay)
                 else:

@@ -268,13 +268,14 @@ class HotPath:
         k.launch(nat.AMP_PHASE_ALL, key_body_indexes=[0, 1, 2, 3], reference=reference, **self._sim)
         amp = k.amp_observation_buffer.view(self.num_envs, -1)
         tail = self.fused_scaler and self.fused_tail
-        if not tail:
+        raw_tail = self.fused_tail and not self.fused_scaler and not self.overlap   # style_reward(compact=k): the same ride on raw rows
+        if not tail and not raw_tail:
             k.compact_resets()
         if self.fused_scaler:
             # fused tail: the reset-id compaction rides on the finalize launch (one launch fewer; same results)
             self.last = self.disc.style_reward_prescaled(k.disc_input, k.reward, compact=k if tail else None)
         elif not self.overlap:
-            self.last = self.disc.style_reward(amp, k.reward)
+            self.last = self.disc.style_reward(amp, k.reward, compact=k if raw_tail else None)
         else:
             slot = self._n & 1
             self._obs_ready.record(env_stream)

@@ -644,6 +644,14 @@ int amp_ring_append(AmpRing* r, const float* rows_dev, int64_t n, int64_t row_st
 int amp_ring_sample(const AmpRing* r, uint64_t seed, uint64_t draw, int64_t first_row, int64_t n, float* out_dev,
                     int64_t out_stride, int64_t* indices_dev, amp_stream_t stream);
 
+/* out_dev[i] = rows_dev[pi(first + i)], i < count, where pi is a pseudo-random PERMUTATION of [0, n_rows) keyed by (seed, epoch) and
+ * evaluated point-wise (6-round Feistel network + cycle walking: no sort, no index array): the epoch shuffle of an agent update's
+ * rollout rows (skrl memory.sample_all + mini-batch split, agents/skrl_g1_walk_amp_cfg.yaml:65-66; third-party: parity unpinned) --
+ * minibatch m of an epoch takes positions [m * per, m * per + batch): `batch` distinct rows, disjoint from the other minibatches'.
+ * indices_dev [count] optional.  first + count <= n_rows. */
+int amp_rows_take_permuted(const float* rows_dev, int64_t n_rows, int64_t row_stride, int32_t row_dim, uint64_t seed, uint64_t epoch,
+                           int64_t first, int64_t count, float* out_dev, int64_t out_stride, int64_t* indices_dev, amp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * CSV -> npz motion converter  (replaces motions/data_convert.py:161-390: 30 -> 60 fps
  * up-sampling, forward kinematics, finite-difference + Gaussian-smoothed velocities, quaternion-difference angular

@@ -51,6 +51,33 @@ def ring_sample_indices(size: int, seed: int, draw: int, n: int, first_row: int 
     return ((r0 * np.uint64(size)) >> np.uint64(32)).astype(np.int64)
 
 
+def feistel_permutation(n: int, seed: int, epoch: int, positions: np.ndarray) -> np.ndarray:
+    """pi(positions) of csrc/ring.hip::feistel_permute: the point-wise pseudo-random permutation of [0, n) keyed by (seed, epoch)."""
+    bits = 1
+    while (1 << bits) < n:
+        bits += 1
+    hb = (bits + 1) // 2
+    mask = np.uint64((1 << hb) - 1)
+    M32 = np.uint64(0xFFFFFFFF)
+    v = np.asarray(positions, dtype=np.uint64).copy()
+    todo = np.ones(v.shape, dtype=bool)
+    first = True
+    while todo.any():
+        x = v[todo]
+        L, R = (x >> np.uint64(hb)) & mask, x & mask
+        for rd in range(6):
+            k0 = np.uint64((seed + 0x9E3779B9 * (rd + 1)) & 0xFFFFFFFF)
+            k1 = np.uint64(((seed >> 32) ^ epoch ^ ((0xBB67AE85 * (rd + 1)) & 0xFFFFFFFF) ^ (epoch >> 32)) & 0xFFFFFFFF)
+            p = ((R ^ k0) & M32) * np.uint64(0xD2511F53)
+            f = ((p >> np.uint64(32)) ^ (p & M32) ^ k1) & M32
+            L, R = R, (L ^ (f & mask)) & mask
+        x = (L << np.uint64(hb)) | R
+        v[todo] = x
+        todo = v >= np.uint64(n)
+        first = False
+    return v.astype(np.int64)
+
+
 class RingOracle:
     """numpy restatement of skrl RandomMemory.add_samples on one tensor (write head wraps; oldest rows overwritten)."""
 

@@ -30,10 +30,13 @@ def test_committed_json_line_has_the_contract_fields():
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-9 and 0.0 < r["frac"] < 1.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 5e-4 * r["frac"] and 0.0 < r["frac"] < 1.0   # (a line may carry 4 significant digits)
     assert r["traffic"] is None or r["traffic"] > 0
     # achieved = algorithmic FLOPs per launch / average launch duration
-    assert abs(r["achieved"] - r["flops_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12) <= 1e-6 * r["achieved"]
+    assert abs(r["achieved"] - r["flops_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12) <= 1e-3 * r["achieved"]
+    # round 5: the line stays under 4 KB and carries the strict-fp32 engine and the small shards inside `roofline`
+    if "fp32_engine" in r:
+        assert len(json.dumps(d)) < 4096 and r["fp32_engine"]["value"] > 0 and r["envs_4096"]["value"] > 0 and r["envs_8192"]["value"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
 

@@ -75,6 +75,12 @@ def _worker(rank, world, port, out_dir):
         def add_samples(self, rows):
             self.appended.append(rows.clone())
 
+    def cpu_take(rows, seed, epoch, first, count, out=None):
+        """The engine's epoch shuffle (amp_rows_take_permuted) on CPU tensors through its restatement in oracle/rng.py."""
+        idx = torch.from_numpy(orng.feistel_permutation(rows.shape[0], seed, epoch, np.arange(first, first + count)))
+        res = rows[idx]
+        return res if out is None else out.copy_(res)
+
     class RecordingTrainer:
         batch_size, device, defer_refresh = 8, torch.device("cpu"), False
 
@@ -91,7 +97,8 @@ def _worker(rank, world, port, out_dir):
     rollout = tag(0, 40)                                     # [rank, group tag, local row, 0]
     replay, motion = CpuRing(tag(1, 30 + 7 * rank), seed=5), CpuRing(tag(2, 50), seed=6)   # replay rings of different sizes
     trainer = RecordingTrainer()
-    upd = AmpDiscriminatorUpdate(trainer, replay, motion, learning_epochs=3, mini_batches=2, seed=9, group=dist.group.WORLD)
+    upd = AmpDiscriminatorUpdate(trainer, replay, motion, learning_epochs=3, mini_batches=2, seed=9 + rank, group=dist.group.WORLD,
+                                 take_rows=cpu_take)
     losses = upd.update(rollout.view(5, 8, cols))
     bs, rr = trainer.batch_size, trainer.batch_size // world
     assert len(losses) == len(trainer.steps) == 6 and upd.exchange.rows_per_rank == rr
@@ -109,8 +116,10 @@ def _worker(rank, world, port, out_dir):
             d, first, idx = ring.drawn[k]
             assert (d, first) == (k, rank * rr)
             assert torch.equal(mine[k, g, rank * rr:(rank + 1) * rr, 2], torch.from_numpy(idx).float())
-        # policy rows: rr distinct rows of this rank's minibatch k % 2 of the epoch's shuffle
-        assert len(set(mine[k, 0, rank * rr:(rank + 1) * rr, 2].tolist())) == rr
+        # policy rows: positions [mb * per, mb * per + rr) of this rank's epoch permutation (per = 40 rows / 2 minibatches)
+        want = orng.feistel_permutation(40, 9 + rank, k // 2, np.arange((k % 2) * 20, (k % 2) * 20 + rr))
+        assert torch.equal(mine[k, 0, rank * rr:(rank + 1) * rr, 2], torch.from_numpy(want).float())
+        assert len(set(want.tolist())) == rr
     # an epoch's two minibatches take disjoint rollout rows
     for e in range(3):
         a, b = (set(mine[2 * e + i, 0, rank * rr:(rank + 1) * rr, 2].tolist()) for i in range(2))

@@ -42,10 +42,11 @@ def test_update_feeds_the_trainer_what_the_oracle_flow_selects():
             else:
                 want_rep = o_replay.rows[orng.ring_sample_indices(o_replay.size, 5, rep_draw0 + i, bs)]
                 assert np.array_equal(rep.cpu().numpy(), want_rep)
-            # the policy batch: bs distinct rows of this rollout
-            pn = pol.cpu().numpy()
-            assert len({r.tobytes() for r in pn}) == bs
-            assert np.isin(pn[:, 0], rows[:, 0]).all()
+            # the policy batch: positions [mb * per, mb * per + bs) of the epoch's permutation of this rollout's rows (bs distinct rows)
+            epoch, mb = it * epochs + i // mbs, i % mbs
+            per = rows.shape[0] // mbs
+            sel = orng.feistel_permutation(rows.shape[0], 9, epoch, np.arange(mb * per, mb * per + bs))
+            assert np.array_equal(pol.cpu().numpy(), rows[sel]) and len(set(sel.tolist())) == bs
         o_replay.add(rows)
         assert len(replay) == o_replay.size and replay.memory_index == o_replay.head
         got, idx = replay.sample(4096, return_indices=True)

@@ -84,3 +84,35 @@ def test_first_row_slices_one_minibatch_draw():
     buf._draw = 1
     _, hi = buf.sample(64, return_indices=True, first_row=(1 << 32) + 5)
     assert np.array_equal(hi.cpu().numpy(), orng.ring_sample_indices(3333, 11, 1, 64, first_row=(1 << 32) + 5))
+
+
+def test_point_wise_permutation_is_a_bijection_and_bit_exact():
+    """amp_rows_take_permuted: out[i] = rows[pi(first + i)] with pi a Feistel / cycle-walking permutation keyed by (seed, epoch).
+    pi is a bijection of [0, n) for every n tried (1, powers of two, primes, the 1 M rows of a 65 536-env rollout), equals
+    oracle/rng.py::feistel_permutation bit for bit, differs between epochs and seeds, and the rows it selects are the rows."""
+    from humanoid_amp_amd import _native as nat
+    from humanoid_amp_amd.engine import take_permuted_rows
+
+    for n in (1, 2, 3, 64, 1000, 4099, 65536):
+        rows = torch.arange(n * 3, dtype=torch.float32, device="cuda").view(n, 3)
+        got, idx = take_permuted_rows(rows, seed=5, epoch=2, first=0, count=n, return_indices=True)
+        want = orng.feistel_permutation(n, 5, 2, np.arange(n))
+        assert np.array_equal(idx.cpu().numpy(), want) and sorted(want.tolist()) == list(range(n))
+        assert torch.equal(got, rows[idx])
+    n = 1 << 20
+    big = torch.randn(n, 4, device="cuda")
+    _, a = take_permuted_rows(big, seed=(7 << 32) + 3, epoch=(1 << 33) + 1, first=300000, count=8192, return_indices=True)
+    assert np.array_equal(a.cpu().numpy(), orng.feistel_permutation(n, (7 << 32) + 3, (1 << 33) + 1, np.arange(300000, 308192)))
+    _, b = take_permuted_rows(big, seed=(7 << 32) + 3, epoch=(1 << 33) + 2, first=300000, count=8192, return_indices=True)
+    _, c = take_permuted_rows(big, seed=(7 << 32) + 4, epoch=(1 << 33) + 1, first=300000, count=8192, return_indices=True)
+    assert not torch.equal(a, b) and not torch.equal(a, c)
+    _, whole = take_permuted_rows(big, seed=1, epoch=0, first=0, count=n, return_indices=True)
+    assert int(torch.bincount(whole, minlength=n).max()) == 1                      # a permutation of all 1 048 576 rows
+    pos = torch.arange(n, device="cuda")
+    assert 0.45 < float((whole < n // 2)[: n // 2].float().mean()) < 0.55 and not bool((whole == pos).all())
+    view = torch.randn(100, 2, 6, device="cuda")[:, 1, :]                           # a strided view, into a strided output
+    out = torch.zeros(10, 8, device="cuda")
+    _, i2 = take_permuted_rows(view, 1, 1, 20, 10, out=out[:, :6], return_indices=True)
+    assert torch.equal(out[:, :6], view[i2]) and float(out[:, 6:].abs().max()) == 0.0
+    with pytest.raises(nat.AmpEngineError):
+        take_permuted_rows(big, 1, 1, n - 5, 10)
