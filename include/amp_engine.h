@@ -485,7 +485,9 @@ int amp_disc_set_plan(AmpDisc* h, int32_t fused, int64_t fused_min_rows);
  * amp_obs and task_reward are read only by the first kernel (scaler pass, which also snapshots the task reward
  * into the workspace); `inputs_consumed` (hipEvent_t, may be NULL) is recorded on `stream` right after it, so a
  * caller running the env on another stream may overwrite both buffers (the in-place AMP history shift of the next
- * env step) as soon as that event has completed, while the GEMMs are still running. */
+ * env step) as soon as that event has completed, while the GEMMs are still running.  Exception: where the whole batch takes the fused
+ * two-layer kernel straight from the fp32 rows (amp_disc_plan_info: raw_input; no scaler pass exists then) the rows and the task reward
+ * are read until the call's last kernel, and the event is recorded behind it. */
 int amp_disc_style_reward(const AmpDisc* h, const float* amp_obs_dev, int64_t rows, int64_t row_stride,
                           float reward_scale, const float* task_reward_dev, float task_weight, float style_weight,
                           float* logits_dev, float* style_dev, float* combined_dev, void* workspace_dev,

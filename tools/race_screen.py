@@ -10,13 +10,13 @@ from humanoid_amp_amd.workloads import make_disc_weights
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 torch.manual_seed(0)
 worst, launches, t_end = 0.0, 0, time.time() + seconds
-for in_dim in (166, 830, 162):
+for in_dim in (166, 830, 162, 142, 100):
     w = make_disc_weights(in_dim, 0)
     kw = dict(running_mean=torch.zeros(in_dim, dtype=torch.float64), running_variance=torch.ones(in_dim, dtype=torch.float64))
     fast = AmpDiscriminator(w, "cuda:0", precision="f16x3", **kw)
     slow = AmpDiscriminator(w, "cuda:0", precision="f32", **kw)
     g = torch.Generator(device="cuda").manual_seed(in_dim)
-    deadline = time.time() + seconds / 3
+    deadline = time.time() + seconds / 5
     t_print = time.time()
     while time.time() < deadline:
         if time.time() - t_print > 30:  # a run that stays silent for minutes is taken to be hung by the GPU harness
