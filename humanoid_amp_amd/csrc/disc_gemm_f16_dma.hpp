@@ -97,8 +97,12 @@ static __global__ __launch_bounds__(kBlock) void split_rows_blocks_kernel(const 
 // step, gpurun_out/r03_y.)
 #define AMP_L1_STORE_AUX 16
 #endif
-#ifdef AMP_DMA_TIMELINE  // microbenchmark builds only (tools/gemm_f16_bench.hip TIMELINE=1): per-workgroup phase stamps
-__device__ unsigned long long* g_dma_timeline;  // [grid][8]: start, k-loop start, k-loop end, stores issued, stores done, hw id
+#ifdef AMP_DMA_TIMELINE  // diagnostic builds only (tools/gemm_f16_bench.hip TIMELINE=1, tools/small_shard_timeline.py): per-workgroup phase stamps
+__device__ unsigned long long* g_dma_timeline;  // [rows][8]: start, k-loop start, k-loop end, stores issued / partials reduced, stores done, hw id
+// (row = block index, + 1024 for layer-2 launches, so that one buffer takes both launches of a small shard's step)
+extern "C" int amp_debug_dma_timeline(unsigned long long* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_dma_timeline), &buf, sizeof(buf)) == hipSuccess ? 0 : -2;
+}
 #define AMP_DMA_STAMP(slot)                                                                                           \
   do {                                                                                                                \
     if (g_dma_timeline && threadIdx.x == 0) g_dma_timeline[(size_t)stamp_row * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
   constexpr int BM = T::BM, BN = T::BN, kOpA = T::kA, kStage = T::kStage;
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
 #ifdef AMP_DMA_TIMELINE
-  unsigned stamp_row = blockIdx.x;
+  unsigned stamp_row = blockIdx.x + (MODE == 1 ? 1024u : 0u);
 #endif
   AMP_DMA_STAMP(0);
   int mt, nt, slice = 0;
@@ -350,6 +354,7 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
     for (int q = 0; q < NS - 1 && q < nq; ++q) fill(q, q);
     wait_younger((nq < NS - 1 ? nq : NS - 1) - 1);
     __builtin_amdgcn_s_barrier();  // k-block 0 is visible to every wave
+    AMP_DMA_STAMP(1);
     if (grp == 1) __builtin_amdgcn_s_barrier();
     // `younger`: k-blocks q + 2 .. that are in flight when k-block q + 1 is awaited (NS - 2 in the steady loop)
     auto kb = [&](const int q, const bool ahead, const int younger) {  // ahead: k-block q + NS - 1 exists and is issued here
@@ -567,6 +572,7 @@ __global__ __launch_bounds__(kDmaThreads, (DmaTile<TM, TN, KB2 ? KB2 : 2>::kWgPe
     }
   }
   __syncthreads();
+  AMP_DMA_STAMP(3);
   constexpr int BPT = 4 * TN;  // 32-column blocks per tile
   const int n_blocks = g.N >> 5;
   for (int e = tid; e < BM * BPT; e += kDmaThreads) {
