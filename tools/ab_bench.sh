@@ -17,7 +17,7 @@ k = det["kernel_us_per_step"]
 gemm = "  ".join(f"{n.replace('disc_', '').replace('_kernel', '')} {v:6.1f}" for n, v in k.items() if n.startswith("disc_"))
 r = d["roofline"]
 print(f"{sys.argv[3]:28s} {d['ms_per_step']*1e3:7.1f} us/step  env {k['env_step_reference_kernel']:6.1f}  {gemm}  "
-      f"tail {k['step_tail_kernel']:4.1f} | 8192: {r['envs_8192']['ms_per_step']*1e3:5.1f}  4096: {r['envs_4096']['ms_per_step']*1e3:5.1f}")
+      f"tail {k.get('step_tail_kernel', 0.0):4.1f} | 8192: {r['envs_8192']['ms_per_step']*1e3:5.1f}  4096: {r['envs_4096']['ms_per_step']*1e3:5.1f}")
 PY
   done
 done
