@@ -86,3 +86,9 @@ G1_KEY_BODY_NAMES = ["right_rubber_hand", "left_rubber_hand", "right_ankle_roll_
 # humanoid_28 (humanoid_amp_env.py:42); its robot-side joint order is not recorded anywhere in the reference
 # (third-party asset HUMANOID_28_CFG): the clip order is used (unpinned)
 HUMANOID_KEY_BODY_NAMES = ["right_hand", "left_hand", "right_foot", "left_foot"]
+
+# The 23-DoF G1 (BASELINE.json configs[1]'s literal wording; the reference's assets and clips are all 29-DoF): the
+# 29-DoF order above without the joints the 23-DoF model does not have -- waist roll / pitch and both wrists' pitch / yaw.
+G1_23DOF_DROPPED = ('waist_roll_joint', 'waist_pitch_joint', 'left_wrist_pitch_joint', 'right_wrist_pitch_joint',
+                    'left_wrist_yaw_joint', 'right_wrist_yaw_joint')
+G1_23DOF_JOINT_NAMES = [n for n in G1_JOINT_NAMES if n not in G1_23DOF_DROPPED]

@@ -20,7 +20,7 @@ import torch
 from . import _native as nat
 from .engine import AmpDiscriminator, EnvStepConfig, EnvStepKernel
 from .motions import MOTIONS_DIR, MotionLoader
-from .robots import G1_JOINT_NAMES, G1_KEY_BODY_NAMES, HUMANOID_KEY_BODY_NAMES
+from .robots import G1_23DOF_DROPPED, G1_23DOF_JOINT_NAMES, G1_JOINT_NAMES, G1_KEY_BODY_NAMES, HUMANOID_KEY_BODY_NAMES
 from .synthetic import make_state
 
 # reward scales of the self-consistent G1 config family (g1_amp_env_cfg.py:86-91)
@@ -41,6 +41,12 @@ class WorkloadSpec:
     decimation: int
     task_weight: float       # agents/*.yaml task_reward_weight
     style_weight: float
+    drop_dofs: tuple = ()    # synthetic variant: the clips WITHOUT these DoF columns (derived files, see clip_files)
+
+    @property
+    def joint_names(self):
+        """Robot-side joint order (g1 only; the humanoid takes the clip's own order)."""
+        return G1_23DOF_JOINT_NAMES if self.drop_dofs else G1_JOINT_NAMES
 
     @property
     def D(self) -> int:
@@ -58,12 +64,45 @@ WORKLOADS = {
     "g1_walk": WorkloadSpec("g1_walk", "G1-AMP-Walk, G1_walk.npz (399 frames, 11 bodies), 29-DoF, K=2, D=83", ("G1_walk",),
                             29, 2, "g1", "pelvis", 10.0, 2, 0.0, 1.0),
     # configs[2]: long multi-phase clip, K = 10
+    # configs[1] read literally ("23-DoF"): a SYNTHETIC variant -- G1_walk.npz without the six DoF columns the 23-DoF G1 lacks
+    # (D = 71, K D = 142, policy obs 84); the derived clip is written next to the system's temp files on first use
+    "g1_walk_23dof": WorkloadSpec("g1_walk_23dof", "G1-AMP-Walk, synthetic 23-DoF variant of G1_walk.npz (399 frames, 11 bodies; waist roll / "
+                                  "pitch and wrist pitch / yaw columns dropped), K=2, D=71", ("G1_walk",), 23, 2, "g1", "pelvis", 10.0, 2,
+                                  0.0, 1.0, drop_dofs=G1_23DOF_DROPPED),
     "g1_dance": WorkloadSpec("g1_dance", "G1-AMP-Dance, G1_dance.npz (601 frames, 39 bodies), 29-DoF, K=10, D=83", ("G1_dance",),
                              29, 10, "g1", "pelvis", 10.0, 1, 1.0, 1.0),
     # configs[3]: walk+run+dance multi-clip blend, 28 DoF
     "humanoid3": WorkloadSpec("humanoid3", "Humanoid-AMP walk+run+dance 3-clip table (1138 frames, 15 bodies), 28-DoF, K=2, D=81",
                               ("humanoid_walk", "humanoid_run", "humanoid_dance"), 28, 2, "humanoid", "torso", 10.0, 2, 0.0, 1.0),
 }
+
+
+def clip_files(spec: WorkloadSpec) -> list:
+    """The npz files of a workload's clips.  A synthetic variant (``drop_dofs``) gets DERIVED clips: the source arrays with those DoF
+    columns removed (``dof_names``, ``dof_positions``, ``dof_velocities``; bodies untouched), written once per process tree into the
+    temp directory -- data derived from the shipped clips, nothing fetched."""
+    src = [os.path.join(MOTIONS_DIR, c + ".npz") for c in spec.clips]
+    if not spec.drop_dofs:
+        return src
+    import tempfile
+
+    out_dir = os.path.join(tempfile.gettempdir(), "humanoid_amp_amd_clips")
+    os.makedirs(out_dir, exist_ok=True)
+    out = []
+    for path in src:
+        dst = os.path.join(out_dir, f"{os.path.basename(path)[:-4]}_{spec.n_dof}dof.npz")
+        if not os.path.exists(dst):
+            with np.load(path, allow_pickle=False) as d:
+                arrays = {k: d[k] for k in d.files}
+            keep = [i for i, n in enumerate(arrays["dof_names"].tolist()) if n not in spec.drop_dofs]
+            assert len(keep) == spec.n_dof, (len(keep), spec.n_dof)
+            for k in ("dof_names", "dof_positions", "dof_velocities"):
+                arrays[k] = np.ascontiguousarray(arrays[k][..., keep])
+            tmp = dst + f".{os.getpid()}.tmp.npz"
+            np.savez(tmp, **arrays)
+            os.replace(tmp, dst)
+        out.append(dst)
+    return out
 
 
 def algorithmic_bytes_per_env_step(spec: WorkloadSpec) -> int:
@@ -114,11 +153,11 @@ class HotPath:
         self.one_call = bool(one_call)      # the whole step as one amp_hot_step call on prebuilt arguments
         self.fused_scaler = bool(fused_scaler) and not self.overlap  # the overlapped schedule needs the snapshot pass
         self.device = nat.require_gpu(device)
-        files = ",".join(os.path.join(MOTIONS_DIR, c + ".npz") for c in spec.clips)
+        files = ",".join(clip_files(spec))
         self.motion = MotionLoader(files, self.device)
         ml = self.motion
         if spec.robot == "g1":
-            perm, keys = ml.get_dof_index(G1_JOINT_NAMES), ml.get_body_index(G1_KEY_BODY_NAMES)
+            perm, keys = ml.get_dof_index(spec.joint_names), ml.get_body_index(G1_KEY_BODY_NAMES)
         else:
             perm, keys = list(range(ml.num_dofs)), ml.get_body_index(HUMANOID_KEY_BODY_NAMES)
         D = ml.set_obs_layout(perm, ml.get_body_index([spec.reference_body])[0], keys)

@@ -23,17 +23,18 @@ TOL = 1e-5
 
 
 @pytest.mark.parametrize("workload,num_envs", [("g1_walk", 4096), ("g1_walk", 20000), ("g1_dance", 1000), ("humanoid3", 3000),
-                                               ("g1_walk", 36000), ("humanoid3", 25000)])
+                                               ("g1_walk", 36000), ("humanoid3", 25000), ("g1_walk_23dof", 4096), ("g1_walk_23dof", 30000)])
 def test_hot_step_matches_the_oracle(workload, num_envs):
-    from humanoid_amp_amd.motions import MOTIONS_DIR
     from humanoid_amp_amd.robots import G1_JOINT_NAMES, G1_KEY_BODY_NAMES, HUMANOID_KEY_BODY_NAMES
-    from humanoid_amp_amd.workloads import WORKLOADS, HotPath
+    from humanoid_amp_amd.workloads import WORKLOADS, HotPath, clip_files
 
     spec = WORKLOADS[workload]
     hot = HotPath(spec, num_envs, "cuda:0", seed=3, state_sets=3)
     assert hot.one_call and (hot.fused_scaler or hot.raw_rows) and hot.fused_tail and hot.fused_expert  # the benchmark's configuration
-    mt = om.load_tables([os.path.join(MOTIONS_DIR, c + ".npz") for c in spec.clips])
-    lay = ohot.layout(mt, spec.robot, G1_JOINT_NAMES, G1_KEY_BODY_NAMES, HUMANOID_KEY_BODY_NAMES)
+    # (g1_walk_23dof: BASELINE configs[1] read literally -- a synthetic 23-DoF variant of the clip, D = 71, K D = 142: the 160-wide
+    #  two-kernel plan at 4 096 envs, 5 k-blocks of activation fragments in the fused two-layer kernel at 30 000)
+    mt = om.load_tables(clip_files(spec))
+    lay = ohot.layout(mt, spec.robot, spec.joint_names if spec.robot == "g1" else G1_JOINT_NAMES, G1_KEY_BODY_NAMES, HUMANOID_KEY_BODY_NAMES)
     shadow = hot.kernel.amp_observation_buffer.cpu().clone()  # the oracle's own history from here on
     tile = hot.kernel.tile_envs
     assert tile == (8 if spec.K == 10 else (32 if num_envs >= 16384 else 16))
