@@ -1025,7 +1025,7 @@ class AmpDiscriminatorUpdate:
         stream), the main stream trains on a set only behind its refill (an event recorded on the side stream).  The
         shuffles and the ring draws consume their counters in the in-line order.  The batches of step k + 1 are drawn before step k
         trains: if a training step raises, the epoch and ring draw counters are one step ahead of the in-line flow's (they are not
-        rolled back)."""
+        rolled back).  The replay append follows the last draw on the side stream (see ``append`` below)."""
         dev = rows.device
         main = torch.cuda.current_stream(dev)
         if self._side is None:
@@ -1057,11 +1057,22 @@ class AmpDiscriminatorUpdate:
                 ready[st] = torch.cuda.Event()
                 ready[st].record(side)
 
+        def append():
+            # the rollout's rows into the replay ring, on the side stream BEHIND the update's last ring draw (the same stream: ordered),
+            # i.e. under the last training steps instead of after them (0.66 GB in + 0.66 GB out at the reference's sizes).  Like the draw
+            # counters it is not rolled back if a later training step raises.
+            with torch.cuda.stream(side):
+                self.replay.add_samples(rows)
+
         losses = []
         produce(0)
+        if n == 1:
+            append()
         for k in range(n):
             if k + 1 < n:
                 produce(k + 1)
+                if k + 2 == n:
+                    append()
             st = k & 1
             main.wait_event(ready[st])
             policy, replay, motion = bufs[st]
@@ -1070,7 +1081,8 @@ class AmpDiscriminatorUpdate:
                 self.batches.append((policy.clone(), replay.clone(), motion.clone()))
             done[st] = torch.cuda.Event()
             done[st].record(main)
-        return self._finish(rows, losses)
+        main.wait_stream(side)   # the ring holds the rollout's rows for whatever follows on the caller's stream
+        return self._finish(rows, losses, append=False)
 
 
 def _group_world(group) -> int:
